@@ -1,0 +1,220 @@
+"""
+Pins the oracle (oracle/cpu_ref.py) to the reference: its own known-answer tests and the outputs
+of the reference itself on fixed inputs (tests/golden/reference_golden.npz).  CPU only.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref as ref
+
+
+def pack_rows(mat):
+    mat = np.asarray(mat) & 1
+    m, n = mat.shape
+    ld = max(1, (n + 63) // 64)
+    padded = np.zeros((m, ld * 64), dtype=np.uint8)
+    padded[:, :n] = mat
+    return np.packbits(padded, axis=1, bitorder="little").view("<u8").reshape(m, ld)
+
+
+def sha(arr):
+    return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()
+
+
+# ---- the reference's own known-answer tests ----------------------------------------------------
+
+def test_kat_rref():
+    # test/test_bin_matrix.py:8-20
+    mat = np.array([[1, 0, 1, 1, 0, 1, 0], [0, 1, 1, 0, 0, 1, 1], [1, 0, 1, 0, 1, 0, 1]], dtype='int')
+    expected = np.array([[1, 0, 1, 0, 1, 0, 1], [0, 1, 1, 0, 0, 1, 1], [0, 0, 0, 1, 1, 1, 1]], dtype='int')
+    before = mat.copy()
+    assert np.array_equal(ref.reduced_row_echelon_form(mat), expected)
+    assert np.array_equal(mat, before)
+
+
+def test_kat_vec_int():
+    # test/test_bin_matrix.py:22-31
+    assert ref.vec_to_int(np.array([0, 1, 0, 1, 1])) == 11
+    assert np.array_equal(ref.int_to_vec(11, 5), np.array([0, 1, 0, 1, 1]))
+    with pytest.raises(ValueError):
+        ref.int_to_vec(11, 3)
+
+
+def test_kat_steane(steane_h):
+    # test/test_css_code.py:13-59,108-118
+    code = ref.CSSCode(steane_h, steane_h)
+    assert np.array_equal(code.parity_check_c1[:, 0:3], np.identity(3))
+    assert np.array_equal(code.parity_check_c2[:, 3:6], np.identity(3))
+    assert code.stabiliser_labels() == ["X0*X3*X4*X5", "X1*X3*X5*X6", "X2*X4*X5*X6",
+                                        "Z0*Z2*Z3*Z6", "Z0*Z1*Z4*Z6", "Z0*Z1*Z2*Z5"]
+    zeros = np.zeros(7, dtype='int')
+    assert ref.pauli_label_for_row(zeros, code.z_operator_matrix()[0]) == "Z1*Z2*Z6"
+    assert ref.pauli_label_for_row(code.x_operator_matrix()[0], zeros) == "X3*X4*X6"
+    assert ref.pauli_label_for_row(code.x_operator_matrix()[0],
+                                   code.z_operator_matrix()[0]) == "Z1*Z2*X3*X4*Y6"
+    # css_code.py:199 registers 'S' (the reference test asks for 'PHASE' and fails as written)
+    for gate in ('I', 'CNOT', 'H', 'CZ', 'S'):
+        assert code.is_transversal(gate)
+    t, table = ref.syndrome_table(code.parity_check_c1)
+    assert t == 1 and len(table) == 8
+    for s, e in table.items():
+        assert s == ref.vec_to_int(np.mod(np.matmul(code.parity_check_c1, e), 2))
+
+
+def test_kat_doubly_even():
+    # test/test_css_code.py:120-143
+    a = np.array([[0] * 8, [0, 0, 1, 1, 0, 1, 1, 0], [1, 1, 1, 0, 0, 0, 0, 1], [1] * 8])
+    b = np.array([[0] * 8, [0, 0, 1, 1, 0, 1, 1, 0], [0, 1, 1, 0, 0, 0, 0, 1], [1] * 8])
+    c = np.array([[0] * 8, [1, 0, 1, 1, 0, 1, 1, 0], [1, 1, 1, 0, 0, 0, 0, 1], [1] * 8])
+    assert ref.is_doubly_even(a) and not ref.is_doubly_even(b) and not ref.is_doubly_even(c)
+
+
+# ---- outputs of the reference itself -----------------------------------------------------------
+
+def test_golden_rref(golden):
+    tags = [str(i) for i in golden["rref_shape_ids"]] + ["def", "zero", "norows", "nonbin", "u8", "i8"]
+    for tag in tags:
+        a = golden["rref_in_" + tag]
+        out = ref.reduced_row_echelon_form(a)
+        assert out.dtype == golden["rref_out_" + tag].dtype
+        assert np.array_equal(out, golden["rref_out_" + tag]), tag
+
+
+def test_golden_vec_int(golden):
+    pos = 0
+    for length, want in zip(golden["v2i_lens"], golden["v2i_vals"]):
+        vec = golden["v2i_bits"][pos:pos + length]
+        pos += length
+        assert int(ref.vec_to_int(vec)) == int(want)
+        assert np.array_equal(ref.int_to_vec(int(want), int(length)), vec)
+    with np.errstate(over="ignore"):
+        got = [int(ref.vec_to_int(np.ones(L, dtype=np.int64))) for L in (63, 64, 65, 100)]
+    assert got == [int(v) for v in golden["v2i_allones64"]]
+    assert np.array_equal(ref.int_to_vec((1 << 100) + 12345, 101), golden["i2v_big"])
+
+
+def test_golden_weight_w_vectors(golden):
+    for (n, w) in ((4, 2), (7, 0), (7, 1), (7, 2), (7, 3), (5, 5), (3, 4)):
+        items = list(ref.weight_w_vectors(n, w))
+        want = golden["wwv_%d_%d" % (n, w)]
+        assert len(items) == want.shape[0]
+        if items:
+            assert np.array_equal(np.array(items), want)
+    first = next(ref.weight_w_vectors(4, 2))
+    first[:] = 9                                    # fresh copies: mutating one does not leak
+    assert np.array_equal(next(ref.weight_w_vectors(4, 2)), [1, 1, 0, 0])
+
+
+def test_golden_normalize(golden):
+    for tag in golden["norm_tags"]:
+        tag = str(tag)
+        work = np.array(golden["norm_in_" + tag])
+        out, swaps = ref.normalize_parity_check(work, int(golden["norm_off_" + tag]))
+        assert np.array_equal(out, golden["norm_out_" + tag]), tag
+        assert np.array_equal(work, golden["norm_mut_" + tag]), tag
+        assert [tuple(s) for s in swaps] == [tuple(s) for s in golden["norm_swaps_" + tag]], tag
+    assert [tuple(s) for s in golden["norm_swaps_steane0"]] == [(2, 3)]
+    with pytest.raises(ref.InvalidCodeError):
+        ref.normalize_parity_check(np.array(golden["norm_dep_in"]), 0)
+    with pytest.raises(ValueError):
+        ref.normalize_parity_check(np.zeros((3, 5), dtype=np.int64), 3)
+
+
+@pytest.mark.parametrize("tag", ["steane", "rm15"])
+def test_golden_css_code(golden, tag):
+    code = ref.CSSCode(golden[tag + "_in1"], golden[tag + "_in2"])
+    assert np.array_equal(code.parity_check_c1, golden[tag + "_h1"])
+    assert np.array_equal(code.parity_check_c2, golden[tag + "_h2"])
+    assert [code.n, code.k, code.t, code.r_1, code.r_2] == list(golden[tag + "_nktr"])
+    assert sorted(code._transversal_gates) == [str(g) for g in golden[tag + "_gates"]]
+    assert np.array_equal(code.z_operator_matrix(), golden[tag + "_zop"])
+    assert np.array_equal(code.x_operator_matrix(), golden[tag + "_xop"])
+    for which, tab in (("c1", code._c1_syndromes), ("c2", code._c2_syndromes)):
+        keys = golden["%s_%s_keys" % (tag, which)]
+        errs = golden["%s_%s_errs" % (tag, which)]
+        assert [int(k) for k in tab.keys()] == [int(k) for k in keys]      # insertion order too
+        for k, e in zip(keys, errs):
+            assert np.array_equal(tab[int(k)], e)
+    for which, h in (("h1", code.parity_check_c1), ("h2", code.parity_check_c2)):
+        t, tab = ref.syndrome_table(h)
+        assert t == int(golden["%s_tab_%s_t" % (tag, which)])
+        assert [int(k) for k in tab.keys()] == [int(k) for k in golden["%s_tab_%s_keys" % (tag, which)]]
+
+
+def test_css_code_errors(steane_h):
+    with pytest.raises(ValueError, match="same code word length"):
+        ref.CSSCode(steane_h, steane_h[:, :6])
+    with pytest.raises(ValueError, match="C_1 parity check matrix must be binary"):
+        ref.CSSCode(steane_h * 2, steane_h)
+    with pytest.raises(ValueError, match="C_2 parity check matrix must be binary"):
+        ref.CSSCode(steane_h, steane_h * 3)
+    with pytest.raises(ValueError, match="dual code must be a subspace"):
+        ref.CSSCode(steane_h, np.array([[1, 0, 0, 0, 0, 0, 0]]))
+    with pytest.raises(ref.InvalidCodeError):
+        ref.CSSCode(np.array([[1, 1, 1, 1]]), np.array([[1, 1, 1, 1]]))
+
+
+def test_golden_codes_equal_doubly_even(golden):
+    a, b, c = golden["ceq_a"], golden["ceq_b"], golden["ceq_c"]
+    got = [ref.codes_equal(a, b), ref.codes_equal(a, c), ref.codes_equal(a, a[:5])]
+    assert got == [bool(v) for v in golden["ceq_res"]]
+    de = golden["de_in"]
+    assert [ref.is_doubly_even(de[i:i + 1]) for i in range(10)] == [bool(v) for v in golden["de_rows"]]
+
+
+def test_golden_syndromes(golden):
+    for tag in ("steane", "rm15", "r64x128", "r70x200"):
+        h, e, s = golden["syn_h_" + tag], golden["syn_e_" + tag], golden["syn_s_" + tag]
+        assert np.array_equal(ref.syndrome_batch(h, e), s)
+        assert np.array_equal(ref.syndrome_product(h, e[3]), s[3])
+
+
+def test_golden_big512(golden):
+    a = np.random.default_rng(1024).integers(0, 2, (512, 1024)).astype(np.int64)
+    red = ref.reduced_row_echelon_form(a)
+    assert sha(pack_rows(red)) == str(golden["big512_rref_sha"])
+    assert int(np.count_nonzero(red.any(axis=1))) == int(golden["big512_rank"])
+
+
+# ---- build-defined pieces: internal consistency -------------------------------------------------
+
+def test_nullspace_properties(golden, steane_h):
+    for mat in (steane_h, golden["rref_in_4"], golden["rref_in_def"], golden["rref_in_5"]):
+        mat = np.asarray(mat) & 1
+        basis = ref.nullspace(mat)
+        rank = int(np.count_nonzero(ref.reduced_row_echelon_form(mat).any(axis=1)))
+        assert basis.shape == (mat.shape[1] - rank, mat.shape[1])
+        assert not np.any(np.mod(mat @ basis.T, 2))
+        if basis.shape[0]:
+            assert int(np.count_nonzero(ref.reduced_row_echelon_form(basis).any(axis=1))) == basis.shape[0]
+    # H = [I A]  ->  nullspace = [A^T I] (same shape of answer as css_code.py:124-161)
+    a = np.random.default_rng(5).integers(0, 2, (4, 6))
+    h = np.hstack([np.identity(4, dtype=int), a])
+    assert np.array_equal(ref.nullspace(h), np.hstack([a.T, np.identity(6, dtype=int)]))
+
+
+def test_sampler_is_a_function_of_seed_and_index():
+    e1 = ref.sample_pauli_error(7, 123, 70, 0.05, 0.02, 0.1)
+    e2 = ref.sample_pauli_error(7, 123, 70, 0.05, 0.02, 0.1)
+    e3 = ref.sample_pauli_error(8, 123, 70, 0.05, 0.02, 0.1)
+    assert np.array_equal(e1[0], e2[0]) and np.array_equal(e1[1], e2[1])
+    assert not (np.array_equal(e1[0], e3[0]) and np.array_equal(e1[1], e3[1]))
+    assert not ref.sample_pauli_error(1, 2, 130, 0, 0, 0)[0].any()
+    ex, ez = ref.sample_pauli_error(1, 2, 130, 1.0, 0, 0)
+    assert ex.all() and not ez.any()
+    ex, ez = ref.sample_pauli_error(1, 2, 130, 0, 1.0, 0)
+    assert ex.all() and ez.all()
+    ex, ez = ref.sample_pauli_error(1, 2, 130, 0, 0, 1.0)
+    assert ez.all() and not ex.any()
+
+
+def test_sampler_rates():
+    n, count = 64 * 4, 300
+    tot = np.zeros(3)
+    for i in range(count):
+        ex, ez = ref.sample_pauli_error(99, i, n, 0.10, 0.05, 0.20)
+        tot += [np.sum(ex & (1 - ez)), np.sum(ex & ez), np.sum((1 - ex) & ez)]
+    rates = tot / (n * count)
+    assert np.allclose(rates, [0.10, 0.05, 0.20], atol=0.01)
