@@ -1,0 +1,176 @@
+/*
+ * gf2hip.h -- C ABI of libgf2hip.so, the MI355X (gfx950) GF(2) engine behind the bin_matrix /
+ * CSSCode hot path of jimpo/quantum-css-codes.
+ *
+ * The reference has no FFI layer: its boundary is the Python module surface (bin_matrix.py,
+ * css_code.py).  The Python package quantum_css_codes_amd keeps that surface and binds these entry
+ * points with ctypes (quantum_css_codes_amd/_native.py; INTEGRATION.md shows the stub a reference
+ * maintainer would add).  Each entry point names the reference lines it replaces; paths are
+ * relative to the reference repository.
+ *
+ * Conventions
+ *   - Every function returns an int: GF2_OK or a negative GF2_E_* code.  gf2_last_error() returns
+ *     a thread-local human-readable message for the last failure on the calling thread.
+ *   - Packed layout: row-major uint64_t words, column j in word j>>6 at bit j&63, `ld` words per
+ *     row (ld >= ceil(n/64)).  Pad bits (columns >= n) must be zero on input and are zero on output.
+ *   - "host" pointers are caller-owned host memory; the library never keeps them past return.
+ *     "dev" pointers are device memory from gf2_dev_alloc (or any hipMalloc'ed / torch-allocated
+ *     buffer on the context's device).
+ *   - A gf2_ctx owns one HIP stream.  Host-buffer entry points are synchronous.  `_dev` entry points
+ *     enqueue on the context's stream and return; gf2_ctx_sync() waits.  A context is not
+ *     thread-safe; distinct contexts are independent.
+ *   - There is no CPU fallback: without a usable GPU, compute entry points fail with GF2_E_HIP.
+ */
+#ifndef GF2HIP_H
+#define GF2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GF2_OK            0
+#define GF2_E_ARG        (-1)  /* bad argument                                                   */
+#define GF2_E_COLUMNS    (-2)  /* ValueError("not enough columns"), css_code.py:811-812          */
+#define GF2_E_DEPENDENT  (-3)  /* InvalidCodeError("rows are not independent"), css_code.py:825  */
+#define GF2_E_HIP        (-4)  /* HIP runtime error / no device                                  */
+#define GF2_E_NOMEM      (-5)  /* allocation failure                                             */
+
+#define GF2_LAYOUT_SAMPLE_MAJOR 0  /* E: B rows of lde words (one error per row); S: B rows of lds words */
+#define GF2_LAYOUT_BIT_SLICED   1  /* E: n rows of ceil(B/64) words (word b of row q = qubit q of samples
+                                      64b..64b+63); S: r rows likewise.  Requires n <= 64 and r <= 64. */
+
+#define GF2_HIST_FULL    0     /* bins indexed by vec_to_int(syndrome) (bin_matrix.py:36-43), 2^r bins  */
+#define GF2_HIST_WEIGHT  1     /* bins indexed by the syndrome's Hamming weight, r+1 bins               */
+
+typedef struct gf2_ctx gf2_ctx;
+typedef struct gf2_check gf2_check;   /* a parity-check matrix prepared on the device */
+
+/* ---- library / context ------------------------------------------------------------------------ */
+int gf2_version(void);
+const char* gf2_last_error(void);
+int gf2_device_count(int* count_out);
+int gf2_ctx_create(int device, gf2_ctx** ctx_out);
+int gf2_ctx_destroy(gf2_ctx* ctx);
+int gf2_ctx_sync(gf2_ctx* ctx);
+
+/* Device memory and stream-ordered copies on the context's stream (copies are synchronous). */
+int gf2_dev_alloc(gf2_ctx* ctx, size_t bytes, void** dev_out);
+int gf2_dev_free(gf2_ctx* ctx, void* dev);
+int gf2_dev_zero(gf2_ctx* ctx, void* dev, size_t bytes);
+int gf2_h2d(gf2_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes);
+int gf2_d2h(gf2_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes);
+
+/* HIP-event timing on the context's stream: bracket any sequence of _dev calls. */
+int gf2_timer_start(gf2_ctx* ctx);
+int gf2_timer_stop(gf2_ctx* ctx, float* elapsed_ms_out);   /* synchronises on the stop event */
+/* Accumulated HIP-event time of one kernel family since the last reset (see GF2_K_*); each launch of
+ * that family is bracketed by its own pair of events when profiling is enabled. */
+#define GF2_K_SYNDROME 0
+#define GF2_K_HIST     1
+#define GF2_K_SAMPLER  2
+#define GF2_K_ELIM     3
+#define GF2_K_COUNT    4
+int gf2_profile_enable(gf2_ctx* ctx, int on);
+int gf2_profile_reset(gf2_ctx* ctx);
+int gf2_profile_get(gf2_ctx* ctx, int kernel_family, double* total_ms_out, int64_t* launches_out);
+
+/* ---- host-side packing (pure host code, no GPU needed) -------------------------------------------
+ * Dense integer arrays <-> packed words.  Packing applies `& 1` (the reference reduces lazily with
+ * np.mod(.,2), bin_matrix.py:34, css_code.py:39-40).  Strides are in elements. */
+int gf2_pack_rows_u8(const uint8_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld);
+int gf2_pack_rows_i64(const int64_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld);
+int gf2_unpack_rows_u8(const uint64_t* src, int64_t m, int64_t n, int64_t ld, uint8_t* dst, int64_t dst_stride);
+int gf2_unpack_rows_i64(const uint64_t* src, int64_t m, int64_t n, int64_t ld, int64_t* dst, int64_t dst_stride);
+
+/* ---- GF(2) linear algebra on host buffers -------------------------------------------------------- */
+
+/* bin_matrix.reduced_row_echelon_form (bin_matrix.py:8-34).  In place on the packed matrix.
+ * pivots_out (capacity min(m,n)) receives the pivot column of each of the first *rank_out rows. */
+int gf2_rref(gf2_ctx* ctx, uint64_t* a, int64_t m, int64_t n, int64_t ld,
+             int64_t* pivots_out, int64_t* rank_out);
+
+/* Batched form: `batch` independent m x n matrices, matrix b at a + b*m*ld.  One workgroup per
+ * matrix.  pivots_out: batch x min(m,n); rank_out: batch. */
+int gf2_rref_batch(gf2_ctx* ctx, uint64_t* a, int64_t batch, int64_t m, int64_t n, int64_t ld,
+                   int64_t* pivots_out, int64_t* rank_out);
+
+/* Device-resident forms (asynchronous on the context's stream).  pivots_dev: batch x min(m,n) int64
+ * (may be null); rank_dev: batch int64.  gf2_normalize_dev: swaps_dev capacity 2*r int64, nswaps_dev one
+ * int64, status_dev one int (0 = ok, 1 = rows are not independent). */
+int gf2_rref_batch_dev(gf2_ctx* ctx, uint64_t* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld,
+                       int64_t* pivots_dev, int64_t* rank_dev);
+int gf2_normalize_dev(gf2_ctx* ctx, uint64_t* h_dev, int64_t r, int64_t n, int64_t ld, int64_t offset,
+                      int64_t* swaps_dev, int64_t* nswaps_dev, int* status_dev);
+
+/* [build-defined; anchored on bin_matrix.py:8-34 + css_code.py:124-161]  Canonical
+ * nullspace basis read off the RREF: row t has a 1 at free column F[t] and R[i,F[t]] at pivot column
+ * P[i].  n_out needs capacity n rows of ldn words (at most n - rank are written); *rows_out = n-rank. */
+int gf2_nullspace(gf2_ctx* ctx, const uint64_t* a, int64_t m, int64_t n, int64_t ld,
+                  uint64_t* n_out, int64_t ldn, int64_t* rows_out);
+
+/* css_code.normalize_parity_check (css_code.py:809-836).  In place; identity block lands in columns
+ * offset..offset+r-1; swaps_out (capacity 2*r) receives (column, column) pairs in order.
+ * Returns GF2_E_COLUMNS / GF2_E_DEPENDENT for the two reference exceptions. */
+int gf2_normalize(gf2_ctx* ctx, uint64_t* h, int64_t r, int64_t n, int64_t ld, int64_t offset,
+                  int64_t* swaps_out, int64_t* nswaps_out);
+
+/* css_code.swap_columns (css_code.py:783-785).  In place. */
+int gf2_swap_columns(gf2_ctx* ctx, uint64_t* a, int64_t m, int64_t n, int64_t ld, int64_t i, int64_t j);
+
+/* np.mod(np.matmul(A, B.T), 2): the commutation check of css_code.py:47.  C is ra x rb packed
+ * (ldc >= ceil(rb/64)). */
+int gf2_matmul_abt(gf2_ctx* ctx, const uint64_t* a, int64_t ra, int64_t lda,
+                   const uint64_t* b, int64_t rb, int64_t ldb, int64_t n,
+                   uint64_t* c, int64_t ldc);
+
+/* Row Hamming weights: np.sum(mat, axis=1) of css_code.is_doubly_even (css_code.py:846-850). */
+int gf2_row_weights(gf2_ctx* ctx, const uint64_t* a, int64_t m, int64_t n, int64_t ld, uint32_t* weights_out);
+
+/* ---- syndrome extraction -------------------------------------------------------------------------
+ * np.mod(np.matmul(parity_check, e), 2) of css_code.py:728 for B errors at once
+ * [build-defined batching, SURVEY.md 8a x2]. */
+
+/* Uploads H and builds its device-side lookup tables.  The handle belongs to ctx. */
+int gf2_check_create(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, int64_t ld, gf2_check** check_out);
+int gf2_check_destroy(gf2_ctx* ctx, gf2_check* check);
+
+/* Host buffers, synchronous. */
+int gf2_syndrome_batch(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, int64_t ldh,
+                       const uint64_t* e, int64_t batch, int64_t lde, int layout,
+                       uint64_t* s_out, int64_t lds);
+
+/* Device buffers, asynchronous on the context's stream.
+ * Sample-major: e_dev is batch x lde, s_dev is batch x lds (lds >= ceil(r/64)).
+ * Bit-sliced:   e_dev is n x lde with lde >= ceil(batch/64); s_dev is r x lds, lds >= ceil(batch/64). */
+int gf2_syndrome_dev(gf2_ctx* ctx, const gf2_check* check, const uint64_t* e_dev, int64_t batch, int64_t lde,
+                     int layout, uint64_t* s_dev, int64_t lds);
+
+/* Histogram of sample-major packed syndromes (device), accumulated into hist_dev (uint64 bins).
+ * mode GF2_HIST_FULL needs r <= 24 and nbins == 2^r; GF2_HIST_WEIGHT needs nbins == r+1. */
+int gf2_histogram_dev(gf2_ctx* ctx, const uint64_t* s_dev, int64_t batch, int64_t lds, int64_t r,
+                      int mode, uint64_t* hist_dev, int64_t nbins);
+
+/* ---- Monte-Carlo --------------------------------------------------------------------------------
+ * [build-defined, SURVEY.md 8a x3]  Sample `i` (global index) is a pure function of (seed, i); the
+ * generator is specified in DESIGN.md ("Sampler") and restated in oracle/.  X errors are caught by
+ * parity_check_c2, Z errors by parity_check_c1 (css_code.py:457-470). */
+
+/* Writes packed errors for samples first_sample .. first_sample+count-1 (sample-major, count x lde). */
+int gf2_sample_errors_dev(gf2_ctx* ctx, int64_t n, uint64_t seed, int64_t first_sample, int64_t count,
+                          double p_x, double p_y, double p_z,
+                          uint64_t* ex_dev, uint64_t* ez_dev, int64_t lde);
+
+/* Full pipeline: sample -> syndromes -> histograms, chunked through device workspace owned by ctx.
+ * hist_z (from H1 . e_z) and hist_x (from H2 . e_x) are host uint64 arrays, overwritten. */
+int gf2_mc_run(gf2_ctx* ctx, const gf2_check* check_c1, const gf2_check* check_c2,
+               uint64_t seed, int64_t first_sample, int64_t count,
+               double p_x, double p_y, double p_z, int mode,
+               uint64_t* hist_z, int64_t nbins_z, uint64_t* hist_x, int64_t nbins_x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GF2HIP_H */

@@ -1,0 +1,235 @@
+/*
+ * ORACLE -- test infrastructure only.  NOT part of the product.
+ *
+ * Plain-C, single-threaded restatement on packed words of the hot path of jimpo/quantum-css-codes, used
+ * by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg to check libgf2hip.so at sizes
+ * where the NumPy restatement (oracle/cpu_ref.py) would take minutes.  Parity status: PINNED -- the
+ * functions that restate reference functions are checked against the reference-generated fixtures
+ * (tests/test_oracle_golden.py::test_c_oracle_*) and against oracle/cpu_ref.py.
+ *
+ * Packed layout as in include/gf2hip.h: row-major uint64 words, column j at word j>>6 bit j&63.
+ * Nothing here shares code with quantum_css_codes_amd/csrc.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef uint64_t u64;
+
+static inline int bit(const u64* row, int64_t j) { return (int)((row[j >> 6] >> (j & 63)) & 1u); }
+static inline void xor_row(u64* dst, const u64* src, int64_t ld) {
+    for (int64_t w = 0; w < ld; ++w) dst[w] ^= src[w];
+}
+
+/* bin_matrix.py:8-34.  The reference adds the found row into position r (bin_matrix.py:23-24) and then
+ * clears the column in every other row (bin_matrix.py:27-29); on bits, addition is XOR. */
+int orc_rref(u64* a, int64_t m, int64_t n, int64_t ld, int64_t* pivots, int64_t* rank_out) {
+    int64_t lead = 0;
+    for (int64_t c = 0; c < n; ++c) {
+        int64_t found = -1;
+        for (int64_t i = lead; i < m; ++i)
+            if (bit(a + i * ld, c)) { found = i; break; }
+        if (found < 0) continue;
+        if (!bit(a + lead * ld, c)) xor_row(a + lead * ld, a + found * ld, ld);
+        for (int64_t i = 0; i < m; ++i)
+            if (i != lead && bit(a + i * ld, c)) xor_row(a + i * ld, a + lead * ld, ld);
+        if (pivots) pivots[lead] = c;
+        lead += 1;
+    }
+    *rank_out = lead;
+    return 0;
+}
+
+static void swap_cols(u64* a, int64_t m, int64_t ld, int64_t i, int64_t j) {
+    for (int64_t r = 0; r < m; ++r) {
+        u64* row = a + r * ld;
+        int bi = bit(row, i), bj = bit(row, j);
+        if (bi != bj) {
+            row[i >> 6] ^= 1ull << (i & 63);
+            row[j >> 6] ^= 1ull << (j & 63);
+        }
+    }
+}
+
+/* css_code.py:783-785 */
+int orc_swap_columns(u64* a, int64_t m, int64_t ld, int64_t i, int64_t j) {
+    swap_cols(a, m, ld, i, j);
+    return 0;
+}
+
+/* css_code.py:809-836.  Returns 0, -2 ("not enough columns", :811-812) or -3 ("rows are not
+ * independent", :825-826).  swaps receives (i + offset, col) pairs (:828). */
+int orc_normalize(u64* h, int64_t r, int64_t n, int64_t ld, int64_t offset, int64_t* swaps, int64_t* nswaps) {
+    *nswaps = 0;
+    if (n < offset + r) return -2;
+    for (int64_t i = 0; i < r; ++i) {
+        const int64_t c = i + offset;
+        int64_t row = -1;
+        for (int64_t j = i; j < r; ++j)
+            if (bit(h + j * ld, c)) { row = j; break; }
+        if (row >= 0) {
+            if (!bit(h + i * ld, c)) xor_row(h + i * ld, h + row * ld, ld);
+        } else {
+            int64_t col = -1;
+            for (int64_t j = c; j < n; ++j)
+                if (bit(h + i * ld, j)) { col = j; break; }
+            if (col < 0) return -3;
+            swaps[2 * (*nswaps)] = c;
+            swaps[2 * (*nswaps) + 1] = col;
+            *nswaps += 1;
+            swap_cols(h, r, ld, c, col);
+        }
+        for (int64_t j = 0; j < r; ++j)
+            if (j != i && bit(h + j * ld, c)) xor_row(h + j * ld, h + i * ld, ld);
+    }
+    return 0;
+}
+
+/* [build-defined x1] nullspace from the RREF, as oracle/cpu_ref.py:nullspace.  out: (n - rank) x ldn. */
+int orc_nullspace(const u64* a, int64_t m, int64_t n, int64_t ld, u64* out, int64_t ldn, int64_t* rows_out) {
+    u64* red = (u64*)malloc((size_t)(m > 0 ? m : 1) * ld * 8);
+    int64_t* piv = (int64_t*)malloc((size_t)(n > 0 ? n : 1) * 8);
+    int64_t* piv_row = (int64_t*)malloc((size_t)(n > 0 ? n : 1) * 8);
+    int64_t rank = 0;
+    memcpy(red, a, (size_t)m * ld * 8);
+    orc_rref(red, m, n, ld, piv, &rank);
+    for (int64_t c = 0; c < n; ++c) piv_row[c] = -1;
+    for (int64_t i = 0; i < rank; ++i) piv_row[piv[i]] = i;
+    int64_t t = 0;
+    for (int64_t fc = 0; fc < n; ++fc) {
+        if (piv_row[fc] >= 0) continue;
+        u64* dst = out + t * ldn;
+        memset(dst, 0, (size_t)ldn * 8);
+        dst[fc >> 6] |= 1ull << (fc & 63);
+        for (int64_t i = 0; i < rank; ++i)
+            if (bit(red + i * ld, fc)) dst[piv[i] >> 6] |= 1ull << (piv[i] & 63);
+        t += 1;
+    }
+    *rows_out = t;
+    free(red);
+    free(piv);
+    free(piv_row);
+    return 0;
+}
+
+/* css_code.py:728 for a batch, sample-major: s[b] bit i = parity(h[i] & e[b]). */
+int orc_syndrome_batch(const u64* h, int64_t r, int64_t n, int64_t ldh, const u64* e, int64_t batch, int64_t lde,
+                       u64* s, int64_t lds) {
+    const int64_t words = (n + 63) >> 6;
+    for (int64_t b = 0; b < batch; ++b) {
+        u64* out = s + b * lds;
+        memset(out, 0, (size_t)lds * 8);
+        const u64* err = e + b * lde;
+        for (int64_t i = 0; i < r; ++i) {
+            const u64* row = h + i * ldh;
+            u64 acc = 0;
+            for (int64_t w = 0; w < words; ++w) acc ^= row[w] & err[w];
+            out[i >> 6] |= (u64)(__builtin_popcountll(acc) & 1) << (i & 63);
+        }
+    }
+    return 0;
+}
+
+/* mode 0: key = big-endian integer of the r syndrome bits (bin_matrix.py:36-43, css_code.py:729);
+ * mode 1: key = Hamming weight.  hist is accumulated. */
+int orc_histogram(const u64* s, int64_t batch, int64_t lds, int64_t r, int mode, u64* hist) {
+    for (int64_t b = 0; b < batch; ++b) {
+        const u64* row = s + b * lds;
+        u64 key = 0;
+        if (mode == 0) {
+            for (int64_t i = 0; i < r; ++i) key = (key << 1) | (u64)bit(row, i);
+        } else {
+            for (int64_t i = 0; i < r; ++i) key += (u64)bit(row, i);
+        }
+        hist[key] += 1;
+    }
+    return 0;
+}
+
+/* ---- [build-defined x3] sampler: DESIGN.md "Sampler", plain evaluation ------------------------------- */
+
+#define GOLDEN 0x9E3779B97F4A7C15ull
+#define STREAM_MULT 0xD1B54A32D192ED03ull
+
+static u64 mix64(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+static u64 quantise(double x) {
+    double t = __builtin_floor(x * 4294967296.0 + 0.5);
+    if (!(t > 0.0)) return 0;
+    if (t >= 4294967296.0) return 4294967296ull;
+    return (u64)t;
+}
+
+/* Bit j of the result = (u_j < threshold) for positions in `mask`, where u_j's k-th most significant bit
+ * is bit j of draw k.  All 32 draws are always taken; the comparison is a 64-lane ripple comparator. */
+static u64 bernoulli_word(u64 base, u64 threshold, u64 mask) {
+    if (threshold >= (1ull << 32)) return mask;
+    u64 less = 0, equal = ~0ull;
+    for (int k = 0; k < 32; ++k) {
+        const u64 draw = mix64(base + GOLDEN * (u64)(k + 1));
+        const u64 tbit = ((threshold >> (31 - k)) & 1ull) ? ~0ull : 0ull;
+        less |= equal & ~draw & tbit;
+        equal &= ~(draw ^ tbit);
+    }
+    return less & mask;
+}
+
+int orc_sample_errors(int64_t n, u64 seed, int64_t first, int64_t count, double p_x, double p_y, double p_z,
+                      u64* ex, u64* ez, int64_t lde) {
+    const double p_t = p_x + p_y + p_z, p_xy = p_x + p_y;
+    const u64 t_any = quantise(p_t);
+    const u64 t_x = p_t > 0.0 ? quantise(p_xy / p_t) : 0;
+    const u64 t_y = p_xy > 0.0 ? quantise(p_y / p_xy) : 0;
+    const int64_t words = (n + 63) >> 6;
+    for (int64_t i = 0; i < count; ++i) {
+        const u64 ks = mix64(seed + GOLDEN * ((u64)(first + i) + 1));
+        for (int64_t w = 0; w < lde; ++w) {
+            u64 x = 0, z = 0;
+            if (w < words) {
+                const int64_t left = n - w * 64;
+                const u64 valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+                const u64 any_err = bernoulli_word(mix64(ks ^ (STREAM_MULT * (u64)(4 * w + 1))), t_any, valid);
+                const u64 has_x = bernoulli_word(mix64(ks ^ (STREAM_MULT * (u64)(4 * w + 2))), t_x, any_err);
+                const u64 is_y = bernoulli_word(mix64(ks ^ (STREAM_MULT * (u64)(4 * w + 3))), t_y, has_x);
+                x = has_x;
+                z = (any_err & ~has_x) | is_y;
+            }
+            ex[i * lde + w] = x;
+            ez[i * lde + w] = z;
+        }
+    }
+    return 0;
+}
+
+/* Whole Monte-Carlo: X errors against h2, Z errors against h1 (css_code.py:457-470).  Histograms are
+ * overwritten.  Works in chunks of 4096 samples. */
+int orc_mc(const u64* h1, int64_t r1, int64_t ld1, const u64* h2, int64_t r2, int64_t ld2, int64_t n, u64 seed,
+           int64_t first, int64_t count, double p_x, double p_y, double p_z, int mode, u64* hist_z, int64_t nbins_z,
+           u64* hist_x, int64_t nbins_x) {
+    const int64_t lde = (n + 63) >> 6 ? (n + 63) >> 6 : 1;
+    const int64_t ls1 = (r1 + 63) >> 6 ? (r1 + 63) >> 6 : 1, ls2 = (r2 + 63) >> 6 ? (r2 + 63) >> 6 : 1;
+    const int64_t chunk = 4096;
+    u64* ex = (u64*)malloc((size_t)chunk * lde * 8);
+    u64* ez = (u64*)malloc((size_t)chunk * lde * 8);
+    u64* s1 = (u64*)malloc((size_t)chunk * ls1 * 8);
+    u64* s2 = (u64*)malloc((size_t)chunk * ls2 * 8);
+    memset(hist_z, 0, (size_t)nbins_z * 8);
+    memset(hist_x, 0, (size_t)nbins_x * 8);
+    for (int64_t done = 0; done < count; done += chunk) {
+        const int64_t now = count - done < chunk ? count - done : chunk;
+        orc_sample_errors(n, seed, first + done, now, p_x, p_y, p_z, ex, ez, lde);
+        orc_syndrome_batch(h1, r1, n, ld1, ez, now, lde, s1, ls1);
+        orc_syndrome_batch(h2, r2, n, ld2, ex, now, lde, s2, ls2);
+        orc_histogram(s1, now, ls1, r1, mode, hist_z);
+        orc_histogram(s2, now, ls2, r2, mode, hist_x);
+    }
+    free(ex);
+    free(ez);
+    free(s1);
+    free(s2);
+    return 0;
+}

@@ -1,0 +1,370 @@
+"""
+ctypes binding of libgf2hip.so (include/gf2hip.h) and the packed-word helpers the host side uses.
+
+There is no CPU fallback.  If the shared library is missing, or no gfx950 device is usable, the
+first compute call raises GF2Error -- the product never routes through oracle/ or NumPy arithmetic.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgf2hip.so")
+
+GF2_OK, GF2_E_ARG, GF2_E_COLUMNS, GF2_E_DEPENDENT, GF2_E_HIP, GF2_E_NOMEM = 0, -1, -2, -3, -4, -5
+LAYOUT_SAMPLE_MAJOR, LAYOUT_BIT_SLICED = 0, 1
+HIST_FULL, HIST_WEIGHT = 0, 1
+K_SYNDROME, K_HIST, K_SAMPLER, K_ELIM = 0, 1, 2, 3
+
+
+class GF2Error(RuntimeError):
+    """A libgf2hip.so call failed (code and message from gf2_last_error)."""
+
+    def __init__(self, code, message):
+        super().__init__("libgf2hip error %d: %s" % (code, message))
+        self.code = code
+        self.message = message
+
+
+_c_i64 = ctypes.c_int64
+_c_u64 = ctypes.c_uint64
+_p = ctypes.c_void_p
+_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> argument types; every function returns int unless listed in _RESTYPES.  This table is the
+# Python statement of include/gf2hip.h; tests/test_abi.py checks the two against each other.
+SIGNATURES = {
+    "gf2_version": [],
+    "gf2_last_error": [],
+    "gf2_device_count": [ctypes.POINTER(ctypes.c_int)],
+    "gf2_ctx_create": [ctypes.c_int, _pp],
+    "gf2_ctx_destroy": [_p],
+    "gf2_ctx_sync": [_p],
+    "gf2_dev_alloc": [_p, ctypes.c_size_t, _pp],
+    "gf2_dev_free": [_p, _p],
+    "gf2_dev_zero": [_p, _p, ctypes.c_size_t],
+    "gf2_h2d": [_p, _p, _p, ctypes.c_size_t],
+    "gf2_d2h": [_p, _p, _p, ctypes.c_size_t],
+    "gf2_timer_start": [_p],
+    "gf2_timer_stop": [_p, ctypes.POINTER(ctypes.c_float)],
+    "gf2_profile_enable": [_p, ctypes.c_int],
+    "gf2_profile_reset": [_p],
+    "gf2_profile_get": [_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_i64)],
+    "gf2_pack_rows_u8": [_p, _c_i64, _c_i64, _c_i64, _p, _c_i64],
+    "gf2_pack_rows_i64": [_p, _c_i64, _c_i64, _c_i64, _p, _c_i64],
+    "gf2_unpack_rows_u8": [_p, _c_i64, _c_i64, _c_i64, _p, _c_i64],
+    "gf2_unpack_rows_i64": [_p, _c_i64, _c_i64, _c_i64, _p, _c_i64],
+    "gf2_rref": [_p, _p, _c_i64, _c_i64, _c_i64, _p, _p],
+    "gf2_rref_batch": [_p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _p, _p],
+    "gf2_rref_batch_dev": [_p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _p, _p],
+    "gf2_normalize_dev": [_p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _p, _p, _p],
+    "gf2_nullspace": [_p, _p, _c_i64, _c_i64, _c_i64, _p, _c_i64, _p],
+    "gf2_normalize": [_p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _p, _p],
+    "gf2_swap_columns": [_p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64],
+    "gf2_matmul_abt": [_p, _p, _c_i64, _c_i64, _p, _c_i64, _c_i64, _c_i64, _p, _c_i64],
+    "gf2_row_weights": [_p, _p, _c_i64, _c_i64, _c_i64, _p],
+    "gf2_check_create": [_p, _p, _c_i64, _c_i64, _c_i64, _pp],
+    "gf2_check_destroy": [_p, _p],
+    "gf2_syndrome_batch": [_p, _p, _c_i64, _c_i64, _c_i64, _p, _c_i64, _c_i64, ctypes.c_int, _p, _c_i64],
+    "gf2_syndrome_dev": [_p, _p, _p, _c_i64, _c_i64, ctypes.c_int, _p, _c_i64],
+    "gf2_histogram_dev": [_p, _p, _c_i64, _c_i64, _c_i64, ctypes.c_int, _p, _c_i64],
+    "gf2_sample_errors_dev": [_p, _c_i64, _c_u64, _c_i64, _c_i64, ctypes.c_double, ctypes.c_double,
+                              ctypes.c_double, _p, _p, _c_i64],
+    "gf2_mc_run": [_p, _p, _p, _c_u64, _c_i64, _c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                   ctypes.c_int, _p, _c_i64, _p, _c_i64],
+}
+_RESTYPES = {"gf2_last_error": ctypes.c_char_p}
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def lib():
+    """The loaded library.  Raises GF2Error when it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lib_lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise GF2Error(GF2_E_HIP, "%s not found: build it with `python -c 'import "
+                                   "__graft_entry__ as g; g.build()'` (there is no CPU fallback)" % LIB_PATH)
+                handle = ctypes.CDLL(LIB_PATH)
+                for name, argtypes in SIGNATURES.items():
+                    fn = getattr(handle, name)
+                    fn.argtypes = argtypes
+                    fn.restype = _RESTYPES.get(name, ctypes.c_int)
+                _lib = handle
+    return _lib
+
+
+def check(code):
+    if code != GF2_OK:
+        raise GF2Error(code, lib().gf2_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    count = ctypes.c_int(0)
+    rc = lib().gf2_device_count(ctypes.byref(count))
+    return count.value if rc == GF2_OK else 0
+
+
+# ---- packed words ---------------------------------------------------------------------------------------
+
+def words_for(bits):
+    return (int(bits) + 63) >> 6
+
+
+def pack_rows(mat, ld=None):
+    """Dense 2-D integer array -> packed uint64 rows (column j at word j>>6, bit j&63).  Entries are
+    reduced with `& 1`, which is what the reference's lazy np.mod(., 2) amounts to for integers."""
+    mat = np.asarray(mat)
+    if mat.ndim != 2:
+        raise ValueError("expected a 2-D array")
+    m, n = mat.shape
+    width = max(1, words_for(n)) if ld is None else int(ld)
+    if mat.dtype == np.bool_:
+        bits = mat.astype(np.uint8)
+    elif np.issubdtype(mat.dtype, np.integer):
+        bits = (mat & 1).astype(np.uint8)
+    else:
+        bits = np.mod(mat, 2).astype(np.uint8)
+    padded = np.zeros((m, width * 64), dtype=np.uint8)
+    padded[:, :n] = bits
+    return np.ascontiguousarray(np.packbits(padded, axis=1, bitorder="little").view("<u8").reshape(m, width))
+
+
+def unpack_rows(words, n, dtype="int"):
+    """Packed uint64 rows -> dense m x n array of `dtype`."""
+    words = np.ascontiguousarray(words, dtype="<u8")
+    m = words.shape[0]
+    if m == 0 or n == 0:
+        return np.zeros((m, n), dtype=dtype)
+    bits = np.unpackbits(words.view(np.uint8).reshape(m, -1), axis=1, bitorder="little")
+    return bits[:, :n].astype(dtype)
+
+
+def _ptr(arr):
+    return arr.ctypes.data_as(ctypes.c_void_p)
+
+
+# ---- context ----------------------------------------------------------------------------------------------
+
+class DeviceBuffer(object):
+    """Device memory owned by a Context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        out = ctypes.c_void_p()
+        check(lib().gf2_dev_alloc(ctx.handle, self.nbytes, ctypes.byref(out)))
+        self.ptr = out.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.nbytes > self.nbytes:
+            raise ValueError("upload larger than the buffer")
+        check(lib().gf2_h2d(self.ctx.handle, self.ptr, _ptr(arr), arr.nbytes))
+        return self
+
+    def download(self, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes > self.nbytes:
+            raise ValueError("download larger than the buffer")
+        check(lib().gf2_d2h(self.ctx.handle, _ptr(out), self.ptr, out.nbytes))
+        return out
+
+    def zero(self):
+        check(lib().gf2_dev_zero(self.ctx.handle, self.ptr, self.nbytes))
+        return self
+
+    def free(self):
+        if self.ptr:
+            check(lib().gf2_dev_free(self.ctx.handle, self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if self.ptr and self.ctx.handle:
+                lib().gf2_dev_free(self.ctx.handle, self.ptr)
+        except Exception:
+            pass
+
+
+class Check(object):
+    """A parity-check matrix prepared on the device (gf2_check_create)."""
+
+    def __init__(self, ctx, packed, r, n):
+        self.ctx = ctx
+        self.r, self.n = int(r), int(n)
+        packed = np.ascontiguousarray(packed, dtype="<u8")
+        out = ctypes.c_void_p()
+        ld = packed.shape[1] if packed.ndim == 2 and packed.shape[0] else max(1, words_for(n))
+        check(lib().gf2_check_create(ctx.handle, _ptr(packed), self.r, self.n, ld, ctypes.byref(out)))
+        self.handle = out.value
+
+    @property
+    def slabs(self):
+        return max(1, words_for(self.r))
+
+    def free(self):
+        if self.handle:
+            check(lib().gf2_check_destroy(self.ctx.handle, self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            if self.handle and self.ctx.handle:
+                lib().gf2_check_destroy(self.ctx.handle, self.handle)
+        except Exception:
+            pass
+
+
+class Context(object):
+    """One HIP stream on one MI355X (gf2_ctx)."""
+
+    def __init__(self, device=0):
+        out = ctypes.c_void_p()
+        check(lib().gf2_ctx_create(int(device), ctypes.byref(out)))
+        self.handle = out.value
+        self.device = int(device)
+
+    def close(self):
+        if self.handle:
+            lib().gf2_ctx_destroy(self.handle)
+            self.handle = None
+
+    def sync(self):
+        check(lib().gf2_ctx_sync(self.handle))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    # -- timing ---------------------------------------------------------------------------------------
+    def timer_start(self):
+        check(lib().gf2_timer_start(self.handle))
+
+    def timer_stop(self):
+        ms = ctypes.c_float(0)
+        check(lib().gf2_timer_stop(self.handle, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def profile(self, on):
+        check(lib().gf2_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_reset(self):
+        check(lib().gf2_profile_reset(self.handle))
+
+    def profile_get(self, family):
+        ms, count = ctypes.c_double(0), _c_i64(0)
+        check(lib().gf2_profile_get(self.handle, int(family), ctypes.byref(ms), ctypes.byref(count)))
+        return float(ms.value), int(count.value)
+
+    # -- linear algebra on packed host arrays ------------------------------------------------------------
+    def rref(self, packed, m, n):
+        """In place.  Returns (pivot columns, rank)."""
+        cap = max(1, min(m, n))
+        pivots = np.zeros(cap, dtype=np.int64)
+        rank = _c_i64(0)
+        check(lib().gf2_rref(self.handle, _ptr(packed), m, n, packed.shape[1] if m else max(1, words_for(n)),
+                             _ptr(pivots), ctypes.byref(rank)))
+        return pivots[:rank.value], int(rank.value)
+
+    def rref_batch(self, packed, batch, m, n):
+        cap = max(1, min(m, n))
+        pivots = np.zeros((batch, cap), dtype=np.int64)
+        ranks = np.zeros(max(1, batch), dtype=np.int64)
+        check(lib().gf2_rref_batch(self.handle, _ptr(packed), batch, m, n, packed.shape[-1], _ptr(pivots),
+                                   _ptr(ranks)))
+        return pivots, ranks[:batch]
+
+    def nullspace(self, packed, m, n):
+        ld = packed.shape[1] if m else max(1, words_for(n))
+        out = np.zeros((max(1, n), max(1, words_for(n))), dtype="<u8")
+        rows = _c_i64(0)
+        check(lib().gf2_nullspace(self.handle, _ptr(packed), m, n, ld, _ptr(out), out.shape[1], ctypes.byref(rows)))
+        return out[:rows.value]
+
+    def normalize(self, packed, r, n, offset):
+        """In place.  Returns the list of (column, column) swaps."""
+        swaps = np.zeros((max(1, r), 2), dtype=np.int64)
+        count = _c_i64(0)
+        ld = packed.shape[1] if r else max(1, words_for(n))
+        check(lib().gf2_normalize(self.handle, _ptr(packed), r, n, ld, offset, _ptr(swaps), ctypes.byref(count)))
+        return [(int(a), int(b)) for a, b in swaps[:count.value]]
+
+    def swap_columns(self, packed, m, n, i, j):
+        ld = packed.shape[1] if m else max(1, words_for(n))
+        check(lib().gf2_swap_columns(self.handle, _ptr(packed), m, n, ld, int(i), int(j)))
+
+    def matmul_abt(self, a, ra, b, rb, n):
+        out = np.zeros((max(1, ra), max(1, words_for(rb))), dtype="<u8")
+        if ra and rb:
+            check(lib().gf2_matmul_abt(self.handle, _ptr(a), ra, a.shape[1], _ptr(b), rb, b.shape[1], n, _ptr(out),
+                                       out.shape[1]))
+        return out[:ra]
+
+    def row_weights(self, packed, m, n):
+        out = np.zeros(max(1, m), dtype=np.uint32)
+        ld = packed.shape[1] if m else max(1, words_for(n))
+        check(lib().gf2_row_weights(self.handle, _ptr(packed), m, n, ld, _ptr(out)))
+        return out[:m]
+
+    # -- syndromes ----------------------------------------------------------------------------------------
+    def check_create(self, packed, r, n):
+        return Check(self, packed, r, n)
+
+    def syndrome_batch(self, h, r, n, e, batch):
+        """Sample-major host arrays: e is batch x words(n); returns batch x words(r)."""
+        out = np.zeros((max(1, batch), max(1, words_for(r))), dtype="<u8")
+        if batch and r:
+            check(lib().gf2_syndrome_batch(self.handle, _ptr(h), r, n, h.shape[1], _ptr(e), batch, e.shape[1],
+                                           LAYOUT_SAMPLE_MAJOR, _ptr(out), out.shape[1]))
+        return out[:batch]
+
+    def syndrome_batch_sliced(self, h, r, n, e, batch):
+        """Bit-sliced host arrays: e is n x words(batch); returns r x words(batch)."""
+        width = max(1, words_for(batch))
+        out = np.zeros((max(1, r), width), dtype="<u8")
+        if batch and r:
+            check(lib().gf2_syndrome_batch(self.handle, _ptr(h), r, n, h.shape[1], _ptr(e), batch, e.shape[1],
+                                           LAYOUT_BIT_SLICED, _ptr(out), width))
+        return out[:r]
+
+    def syndrome_dev(self, chk, e_buf, batch, lde, s_buf, lds, layout=LAYOUT_SAMPLE_MAJOR):
+        check(lib().gf2_syndrome_dev(self.handle, chk.handle, e_buf.ptr, batch, lde, layout, s_buf.ptr, lds))
+
+    def histogram_dev(self, s_buf, batch, lds, r, mode, hist_buf, nbins):
+        check(lib().gf2_histogram_dev(self.handle, s_buf.ptr, batch, lds, r, mode, hist_buf.ptr, nbins))
+
+    def sample_errors_dev(self, n, seed, first, count, p_x, p_y, p_z, ex_buf, ez_buf, lde):
+        check(lib().gf2_sample_errors_dev(self.handle, n, seed & 0xFFFFFFFFFFFFFFFF, first, count, p_x, p_y, p_z,
+                                          ex_buf.ptr, ez_buf.ptr, lde))
+
+    def mc_run(self, chk1, chk2, seed, first, count, p_x, p_y, p_z, mode):
+        """Returns (hist_z, hist_x) as uint64 arrays."""
+        if mode == HIST_FULL:
+            nz, nx = 1 << chk1.r, 1 << chk2.r
+        else:
+            nz, nx = chk1.r + 1, chk2.r + 1
+        hist_z = np.zeros(nz, dtype=np.uint64)
+        hist_x = np.zeros(nx, dtype=np.uint64)
+        check(lib().gf2_mc_run(self.handle, chk1.handle, chk2.handle, seed & 0xFFFFFFFFFFFFFFFF, first, count,
+                               p_x, p_y, p_z, mode, _ptr(hist_z), nz, _ptr(hist_x), nx))
+        return hist_z, hist_x
+
+
+_default = None
+_default_lock = threading.Lock()
+
+
+def default_context():
+    """Process-wide context on GF2_DEVICE, else LOCAL_RANK, else device 0."""
+    global _default
+    if _default is None:
+        with _default_lock:
+            if _default is None:
+                device = int(os.environ.get("GF2_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+                _default = Context(device)
+    return _default

@@ -1,0 +1,267 @@
+// Context, device memory, timing and host-side bit packing of libgf2hip.so.
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "gf2_internal.h"
+
+static thread_local char g_error[512] = "";
+
+void gf2_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int gf2_version(void) { return GF2_VERSION_NUMBER; }
+
+const char* gf2_last_error(void) { return g_error; }
+
+int gf2_device_count(int* count_out) {
+    if (!count_out) GF2_FAIL(GF2_E_ARG, "gf2_device_count: null output");
+    int count = 0;
+    hipError_t err = hipGetDeviceCount(&count);
+    if (err != hipSuccess) {
+        *count_out = 0;
+        GF2_FAIL(GF2_E_HIP, "hipGetDeviceCount failed: %s", hipGetErrorString(err));
+    }
+    *count_out = count;
+    return GF2_OK;
+}
+
+int gf2_ctx_create(int device, gf2_ctx** ctx_out) {
+    if (!ctx_out) GF2_FAIL(GF2_E_ARG, "gf2_ctx_create: null output");
+    *ctx_out = nullptr;
+    int count = 0;
+    GF2_TRY(gf2_device_count(&count));
+    if (device < 0 || device >= count)
+        GF2_FAIL(GF2_E_HIP, "gf2_ctx_create: device %d not available (%d visible)", device, count);
+    GF2_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    GF2_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        GF2_FAIL(GF2_E_HIP, "gf2_ctx_create: device %d is %s; this library is built for gfx950 only",
+                 device, prop.gcnArchName);
+    gf2_ctx* ctx = (gf2_ctx*)calloc(1, sizeof(gf2_ctx));
+    if (!ctx) GF2_FAIL(GF2_E_NOMEM, "gf2_ctx_create: out of host memory");
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
+    GF2_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    GF2_HIP(hipEventCreate(&ctx->t0));
+    GF2_HIP(hipEventCreate(&ctx->t1));
+    for (int i = 0; i < gf2_ctx::kProfSlots; ++i) {
+        GF2_HIP(hipEventCreate(&ctx->prof_ev[i][0]));
+        GF2_HIP(hipEventCreate(&ctx->prof_ev[i][1]));
+    }
+    *ctx_out = ctx;
+    return GF2_OK;
+}
+
+int gf2_ctx_destroy(gf2_ctx* ctx) {
+    if (!ctx) return GF2_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ws) (void)hipFree(ctx->ws);
+    for (int i = 0; i < gf2_ctx::kProfSlots; ++i) {
+        (void)hipEventDestroy(ctx->prof_ev[i][0]);
+        (void)hipEventDestroy(ctx->prof_ev[i][1]);
+    }
+    (void)hipEventDestroy(ctx->t0);
+    (void)hipEventDestroy(ctx->t1);
+    (void)hipStreamDestroy(ctx->stream);
+    free(ctx);
+    return GF2_OK;
+}
+
+int gf2_ctx_sync(gf2_ctx* ctx) {
+    if (!ctx) GF2_FAIL(GF2_E_ARG, "gf2_ctx_sync: null context");
+    GF2_TRY(gf2_ctx_activate(ctx));
+    GF2_HIP(hipStreamSynchronize(ctx->stream));
+    return GF2_OK;
+}
+
+int gf2_dev_alloc(gf2_ctx* ctx, size_t bytes, void** dev_out) {
+    if (!ctx || !dev_out) GF2_FAIL(GF2_E_ARG, "gf2_dev_alloc: null argument");
+    GF2_TRY(gf2_ctx_activate(ctx));
+    *dev_out = nullptr;
+    hipError_t err = hipMalloc(dev_out, bytes ? bytes : 8);
+    if (err == hipErrorOutOfMemory) GF2_FAIL(GF2_E_NOMEM, "gf2_dev_alloc: %zu bytes: out of device memory", bytes);
+    GF2_HIP(err);
+    return GF2_OK;
+}
+
+int gf2_dev_free(gf2_ctx* ctx, void* dev) {
+    if (!ctx) GF2_FAIL(GF2_E_ARG, "gf2_dev_free: null context");
+    if (!dev) return GF2_OK;
+    GF2_TRY(gf2_ctx_activate(ctx));
+    GF2_HIP(hipStreamSynchronize(ctx->stream));
+    GF2_HIP(hipFree(dev));
+    return GF2_OK;
+}
+
+int gf2_dev_zero(gf2_ctx* ctx, void* dev, size_t bytes) {
+    if (!ctx || (!dev && bytes)) GF2_FAIL(GF2_E_ARG, "gf2_dev_zero: null argument");
+    GF2_TRY(gf2_ctx_activate(ctx));
+    if (bytes) GF2_HIP(hipMemsetAsync(dev, 0, bytes, ctx->stream));
+    return GF2_OK;
+}
+
+int gf2_h2d(gf2_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
+    if (!ctx || ((!dev_dst || !host_src) && bytes)) GF2_FAIL(GF2_E_ARG, "gf2_h2d: null argument");
+    GF2_TRY(gf2_ctx_activate(ctx));
+    if (bytes) {
+        GF2_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        GF2_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return GF2_OK;
+}
+
+int gf2_d2h(gf2_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
+    if (!ctx || ((!host_dst || !dev_src) && bytes)) GF2_FAIL(GF2_E_ARG, "gf2_d2h: null argument");
+    GF2_TRY(gf2_ctx_activate(ctx));
+    if (bytes) {
+        GF2_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        GF2_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return GF2_OK;
+}
+
+int gf2_timer_start(gf2_ctx* ctx) {
+    if (!ctx) GF2_FAIL(GF2_E_ARG, "gf2_timer_start: null context");
+    GF2_TRY(gf2_ctx_activate(ctx));
+    GF2_HIP(hipEventRecord(ctx->t0, ctx->stream));
+    return GF2_OK;
+}
+
+int gf2_timer_stop(gf2_ctx* ctx, float* elapsed_ms_out) {
+    if (!ctx || !elapsed_ms_out) GF2_FAIL(GF2_E_ARG, "gf2_timer_stop: null argument");
+    GF2_TRY(gf2_ctx_activate(ctx));
+    GF2_HIP(hipEventRecord(ctx->t1, ctx->stream));
+    GF2_HIP(hipEventSynchronize(ctx->t1));
+    GF2_HIP(hipEventElapsedTime(elapsed_ms_out, ctx->t0, ctx->t1));
+    return GF2_OK;
+}
+
+int gf2_profile_enable(gf2_ctx* ctx, int on) {
+    if (!ctx) GF2_FAIL(GF2_E_ARG, "gf2_profile_enable: null context");
+    GF2_TRY(gf2_prof_drain(ctx));
+    ctx->profile_on = on ? 1 : 0;
+    return GF2_OK;
+}
+
+int gf2_profile_reset(gf2_ctx* ctx) {
+    if (!ctx) GF2_FAIL(GF2_E_ARG, "gf2_profile_reset: null context");
+    GF2_TRY(gf2_prof_drain(ctx));
+    for (int k = 0; k < GF2_K_COUNT; ++k) {
+        ctx->prof_ms[k] = 0.0;
+        ctx->prof_launches[k] = 0;
+    }
+    return GF2_OK;
+}
+
+int gf2_profile_get(gf2_ctx* ctx, int kernel_family, double* total_ms_out, int64_t* launches_out) {
+    if (!ctx || kernel_family < 0 || kernel_family >= GF2_K_COUNT)
+        GF2_FAIL(GF2_E_ARG, "gf2_profile_get: bad argument");
+    GF2_TRY(gf2_prof_drain(ctx));
+    if (total_ms_out) *total_ms_out = ctx->prof_ms[kernel_family];
+    if (launches_out) *launches_out = ctx->prof_launches[kernel_family];
+    return GF2_OK;
+}
+
+// ---- host-side packing ------------------------------------------------------------------------------
+
+#define GF2_PACK_BODY(T)                                                                     \
+    if ((!src || !dst) && m > 0 && n > 0) GF2_FAIL(GF2_E_ARG, "pack: null buffer");          \
+    if (m < 0 || n < 0 || ld < gf2_words(n) || src_stride < n) GF2_FAIL(GF2_E_ARG, "pack: bad shape"); \
+    for (int64_t i = 0; i < m; ++i) {                                                        \
+        const T* row = src + i * src_stride;                                                 \
+        uint64_t* out = dst + i * ld;                                                        \
+        for (int64_t w = 0; w < ld; ++w) {                                                   \
+            uint64_t acc = 0;                                                                \
+            int64_t base = w * 64;                                                           \
+            int64_t lim = n - base < 64 ? n - base : 64;                                     \
+            for (int64_t b = 0; b < lim; ++b) acc |= (uint64_t)(row[base + b] & 1) << b;     \
+            out[w] = acc;                                                                    \
+        }                                                                                    \
+    }                                                                                        \
+    return GF2_OK;
+
+int gf2_pack_rows_u8(const uint8_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld) {
+    GF2_PACK_BODY(uint8_t)
+}
+
+int gf2_pack_rows_i64(const int64_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld) {
+    GF2_PACK_BODY(int64_t)
+}
+
+#define GF2_UNPACK_BODY(T)                                                                   \
+    if ((!src || !dst) && m > 0 && n > 0) GF2_FAIL(GF2_E_ARG, "unpack: null buffer");        \
+    if (m < 0 || n < 0 || ld < gf2_words(n) || dst_stride < n) GF2_FAIL(GF2_E_ARG, "unpack: bad shape"); \
+    for (int64_t i = 0; i < m; ++i) {                                                        \
+        const uint64_t* row = src + i * ld;                                                  \
+        T* out = dst + i * dst_stride;                                                       \
+        for (int64_t j = 0; j < n; ++j) out[j] = (T)((row[j >> 6] >> (j & 63)) & 1);         \
+    }                                                                                        \
+    return GF2_OK;
+
+int gf2_unpack_rows_u8(const uint64_t* src, int64_t m, int64_t n, int64_t ld, uint8_t* dst, int64_t dst_stride) {
+    GF2_UNPACK_BODY(uint8_t)
+}
+
+int gf2_unpack_rows_i64(const uint64_t* src, int64_t m, int64_t n, int64_t ld, int64_t* dst, int64_t dst_stride) {
+    GF2_UNPACK_BODY(int64_t)
+}
+
+}  // extern "C"
+
+// ---- internals --------------------------------------------------------------------------------------
+
+int gf2_ctx_activate(gf2_ctx* ctx) {
+    GF2_HIP(hipSetDevice(ctx->device));
+    return GF2_OK;
+}
+
+int gf2_ws_reserve(gf2_ctx* ctx, size_t bytes) {
+    if (ctx->ws_bytes >= bytes) return GF2_OK;
+    GF2_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->ws) GF2_HIP(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+    hipError_t err = hipMalloc(&ctx->ws, bytes);
+    if (err == hipErrorOutOfMemory) GF2_FAIL(GF2_E_NOMEM, "workspace of %zu bytes: out of device memory", bytes);
+    GF2_HIP(err);
+    ctx->ws_bytes = bytes;
+    return GF2_OK;
+}
+
+int gf2_prof_drain(gf2_ctx* ctx) {
+    if (ctx->prof_used == 0) return GF2_OK;
+    GF2_TRY(gf2_ctx_activate(ctx));
+    GF2_HIP(hipEventSynchronize(ctx->prof_ev[ctx->prof_used - 1][1]));
+    for (int i = 0; i < ctx->prof_used; ++i) {
+        float ms = 0.f;
+        GF2_HIP(hipEventElapsedTime(&ms, ctx->prof_ev[i][0], ctx->prof_ev[i][1]));
+        ctx->prof_ms[ctx->prof_family[i]] += ms;
+        ctx->prof_launches[ctx->prof_family[i]] += 1;
+    }
+    ctx->prof_used = 0;
+    return GF2_OK;
+}
+
+int gf2_prof_begin(gf2_ctx* ctx, int family) {
+    if (!ctx->profile_on) return GF2_OK;
+    if (ctx->prof_used == gf2_ctx::kProfSlots) GF2_TRY(gf2_prof_drain(ctx));
+    ctx->prof_family[ctx->prof_used] = family;
+    GF2_HIP(hipEventRecord(ctx->prof_ev[ctx->prof_used][0], ctx->stream));
+    return GF2_OK;
+}
+
+int gf2_prof_end(gf2_ctx* ctx) {
+    if (!ctx->profile_on) return GF2_OK;
+    GF2_HIP(hipEventRecord(ctx->prof_ev[ctx->prof_used][1], ctx->stream));
+    ctx->prof_used += 1;
+    return GF2_OK;
+}

@@ -1,0 +1,87 @@
+// Internal definitions shared by the translation units of libgf2hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "gf2hip.h"
+
+#define GF2_VERSION_NUMBER 100
+
+typedef unsigned long long u64;   // HIP's 64-bit atomics/intrinsics are declared on this type
+
+// ---- error plumbing ------------------------------------------------------------------------------
+void gf2_set_error(const char* fmt, ...);
+
+#define GF2_FAIL(code, ...)          \
+    do {                             \
+        gf2_set_error(__VA_ARGS__);  \
+        return (code);               \
+    } while (0)
+
+#define GF2_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t gf2_err_ = (expr);                                                         \
+        if (gf2_err_ != hipSuccess) {                                                         \
+            gf2_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(gf2_err_),        \
+                          __FILE__, __LINE__);                                                \
+            return GF2_E_HIP;                                                                 \
+        }                                                                                     \
+    } while (0)
+
+#define GF2_TRY(expr)                 \
+    do {                              \
+        int gf2_rc_ = (expr);         \
+        if (gf2_rc_ != GF2_OK) return gf2_rc_; \
+    } while (0)
+
+// ---- context -------------------------------------------------------------------------------------
+struct gf2_ctx {
+    int device;
+    int num_cus;
+    hipStream_t stream;
+    hipEvent_t t0, t1;            // gf2_timer_*
+    // per-kernel-family profiling: ring of event pairs resolved lazily
+    int profile_on;
+    double prof_ms[GF2_K_COUNT];
+    int64_t prof_launches[GF2_K_COUNT];
+    static const int kProfSlots = 256;
+    hipEvent_t prof_ev[kProfSlots][2];
+    int prof_family[kProfSlots];
+    int prof_used;
+    // Monte-Carlo workspace (grown on demand)
+    void* ws;
+    size_t ws_bytes;
+};
+
+int gf2_ctx_activate(gf2_ctx* ctx);
+int gf2_ws_reserve(gf2_ctx* ctx, size_t bytes);
+// Profiling brackets around one kernel launch of `family` (no-ops unless enabled).
+int gf2_prof_begin(gf2_ctx* ctx, int family);
+int gf2_prof_end(gf2_ctx* ctx);
+int gf2_prof_drain(gf2_ctx* ctx);
+
+// ---- prepared parity check -------------------------------------------------------------------------
+// Rows are grouped in slabs of 64 (one output word per slab); columns in groups of 4.  tables_dev holds,
+// for slab s and column group g, the 16 XOR-combinations of the slab's four column words:
+//     tables[(s * groups + g) * 16 + v]  bit i  =  XOR_{c : v bit c} H[64 s + i][4 g + c]
+struct gf2_check {
+    int64_t r, n, ld;
+    int64_t slabs;       // ceil(r / 64)
+    int64_t groups;      // ceil(n / 4), padded to a multiple of 32 (one uint4 of error bits = 32 groups)
+    uint64_t* h_dev;     // r x ld packed rows
+    uint64_t* tables_dev;
+    uint64_t rows_small[64];   // host copy of the rows when n <= 64 and r <= 64
+};
+
+static inline int64_t gf2_words(int64_t bits) { return (bits + 63) >> 6; }
+static inline int64_t gf2_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Quantised probability threshold in [0, 2^32] (DESIGN.md "Sampler").
+static inline uint64_t gf2_quantise(double x) {
+    double t = __builtin_floor(x * 4294967296.0 + 0.5);
+    if (!(t > 0.0)) return 0;
+    if (t >= 4294967296.0) return 4294967296ull;
+    return (uint64_t)t;
+}

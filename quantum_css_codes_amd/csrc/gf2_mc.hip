@@ -1,0 +1,157 @@
+// Counter-based Pauli-error sampler and the Monte-Carlo pipeline (sample -> syndromes -> histograms).
+//
+// Build-defined: the reference has no sampler; its only Monte-Carlo is the QVM run of
+// test/test_fidelity.py.  The generator is specified in DESIGN.md ("Sampler") and restated independently
+// in oracle/cpu_ref.py (plain evaluation) and oracle/gf2_oracle.c; this file is the lazy evaluation of
+// the same definition.  Sample i is a pure function of (seed, i), so any sharding of the index range over
+// GPUs gives the same histograms.
+#include <string.h>
+
+#include "gf2_internal.h"
+
+#define GF2_GOLDEN 0x9E3779B97F4A7C15ull
+#define GF2_STREAM_MULT 0xD1B54A32D192ED03ull
+
+__host__ __device__ static inline u64 mix64(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// 64 Bernoulli(threshold / 2^32) bits at the positions set in `undecided`.  Position j owns an implicit
+// 32-bit uniform whose k-th most significant bit is bit j of draw k; output = (uniform < threshold).
+// Evaluated most-significant-bit first and only while some position is still undecided.
+__device__ static inline u64 bernoulli_word(u64 base, u64 threshold, u64 undecided) {
+    if (threshold >= (1ull << 32)) return undecided;
+    u64 out = 0;
+    for (int k = 0; k < 32 && undecided; ++k) {
+        const u64 draw = mix64(base + GF2_GOLDEN * (u64)(k + 1));
+        if ((threshold >> (31 - k)) & 1ull) {
+            out |= undecided & ~draw;
+            undecided &= draw;
+        } else {
+            undecided &= ~draw;
+        }
+    }
+    return out;
+}
+
+struct PauliThresholds {
+    u64 t_any, t_x, t_y;
+};
+
+__device__ static inline void sample_word(u64 seed, u64 sample, u64 w, u64 valid, PauliThresholds th, u64* ex, u64* ez) {
+    const u64 ks = mix64(seed + GF2_GOLDEN * (sample + 1));
+    const u64 any_err = bernoulli_word(mix64(ks ^ (GF2_STREAM_MULT * (4 * w + 1))), th.t_any, valid);
+    const u64 has_x = bernoulli_word(mix64(ks ^ (GF2_STREAM_MULT * (4 * w + 2))), th.t_x, any_err);
+    const u64 is_y = bernoulli_word(mix64(ks ^ (GF2_STREAM_MULT * (4 * w + 3))), th.t_y, has_x);
+    *ex = has_x;
+    *ez = (any_err & ~has_x) | is_y;
+}
+
+// One lane per (sample, word); consecutive lanes write consecutive words of a row.
+__global__ __launch_bounds__(256) void sampler_kernel(u64 seed, int64_t first_sample, int64_t count, int64_t n,
+                                                      int64_t words, int64_t lde, PauliThresholds th,
+                                                      uint64_t* __restrict__ ex, uint64_t* __restrict__ ez) {
+    const int64_t total = count * lde;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int64_t i = idx / lde, w = idx - i * lde;
+        u64 x = 0, z = 0;
+        if (w < words) {
+            const int64_t left = n - w * 64;
+            const u64 valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+            sample_word(seed, (u64)(first_sample + i), (u64)w, valid, th, &x, &z);
+        }
+        ex[idx] = x;
+        ez[idx] = z;
+    }
+}
+
+static int make_thresholds(double p_x, double p_y, double p_z, PauliThresholds* th) {
+    if (!(p_x >= 0.0) || !(p_y >= 0.0) || !(p_z >= 0.0) || p_x + p_y + p_z > 1.0 + 1e-12)
+        GF2_FAIL(GF2_E_ARG, "probabilities must be non-negative and sum to at most 1");
+    const double p_t = p_x + p_y + p_z, p_xy = p_x + p_y;
+    th->t_any = gf2_quantise(p_t);
+    th->t_x = p_t > 0.0 ? gf2_quantise(p_xy / p_t) : 0;
+    th->t_y = p_xy > 0.0 ? gf2_quantise(p_y / p_xy) : 0;
+    return GF2_OK;
+}
+
+extern "C" {
+
+int gf2_sample_errors_dev(gf2_ctx* ctx, int64_t n, uint64_t seed, int64_t first_sample, int64_t count, double p_x,
+                          double p_y, double p_z, uint64_t* ex_dev, uint64_t* ez_dev, int64_t lde) {
+    if (!ctx) GF2_FAIL(GF2_E_ARG, "gf2_sample_errors_dev: null context");
+    if (n < 0 || count < 0 || first_sample < 0 || lde < gf2_words(n) || lde < 1)
+        GF2_FAIL(GF2_E_ARG, "gf2_sample_errors_dev: bad shape");
+    PauliThresholds th;
+    GF2_TRY(make_thresholds(p_x, p_y, p_z, &th));
+    if (count == 0) return GF2_OK;
+    if (!ex_dev || !ez_dev) GF2_FAIL(GF2_E_ARG, "gf2_sample_errors_dev: null buffer");
+    GF2_TRY(gf2_ctx_activate(ctx));
+    int64_t blocks = gf2_cdiv(count * lde, 256);
+    if (blocks > 16384) blocks = 16384;
+    GF2_TRY(gf2_prof_begin(ctx, GF2_K_SAMPLER));
+    hipLaunchKernelGGL(sampler_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (u64)seed, first_sample, count,
+                       n, gf2_words(n), lde, th, ex_dev, ez_dev);
+    GF2_TRY(gf2_prof_end(ctx));
+    GF2_HIP(hipGetLastError());
+    return GF2_OK;
+}
+
+int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t seed, int64_t first_sample,
+               int64_t count, double p_x, double p_y, double p_z, int mode, uint64_t* hist_z, int64_t nbins_z,
+               uint64_t* hist_x, int64_t nbins_x) {
+    if (!ctx || !c1 || !c2 || !hist_z || !hist_x) GF2_FAIL(GF2_E_ARG, "gf2_mc_run: null argument");
+    if (c1->n != c2->n) GF2_FAIL(GF2_E_ARG, "gf2_mc_run: the two checks have different n");
+    if (count < 0 || first_sample < 0) GF2_FAIL(GF2_E_ARG, "gf2_mc_run: negative range");
+    const int64_t n = c1->n;
+    const int64_t want_z = mode == GF2_HIST_FULL ? (c1->r <= 24 ? (1ll << c1->r) : -1) : c1->r + 1;
+    const int64_t want_x = mode == GF2_HIST_FULL ? (c2->r <= 24 ? (1ll << c2->r) : -1) : c2->r + 1;
+    if (mode != GF2_HIST_FULL && mode != GF2_HIST_WEIGHT) GF2_FAIL(GF2_E_ARG, "gf2_mc_run: unknown mode %d", mode);
+    if (want_z < 0 || want_x < 0) GF2_FAIL(GF2_E_ARG, "gf2_mc_run: full histograms need r <= 24");
+    if (nbins_z != want_z || nbins_x != want_x)
+        GF2_FAIL(GF2_E_ARG, "gf2_mc_run: expected %lld and %lld bins", (long long)want_z, (long long)want_x);
+    PauliThresholds th;
+    GF2_TRY(make_thresholds(p_x, p_y, p_z, &th));
+    GF2_TRY(gf2_ctx_activate(ctx));
+
+    const int64_t lde = gf2_words(n) > 0 ? gf2_words(n) : 1;
+    const int64_t ls1 = c1->slabs > 0 ? c1->slabs : 1, ls2 = c2->slabs > 0 ? c2->slabs : 1;
+    // chunk sized to about 256 MiB of error words
+    int64_t chunk = (int64_t)(256ll << 20) / (2 * lde * 8);
+    if (chunk > (1ll << 22)) chunk = 1ll << 22;
+    if (chunk < 4096) chunk = 4096;
+    if (chunk > count) chunk = count > 0 ? count : 1;
+    const size_t e_bytes = (size_t)chunk * lde * 8;
+    const size_t s1_bytes = (size_t)chunk * ls1 * 8, s2_bytes = (size_t)chunk * ls2 * 8;
+    const size_t hz_bytes = (size_t)nbins_z * 8, hx_bytes = (size_t)nbins_x * 8;
+    auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t total = 2 * align(e_bytes) + align(s1_bytes) + align(s2_bytes) + align(hz_bytes) + align(hx_bytes);
+    GF2_TRY(gf2_ws_reserve(ctx, total));
+    char* p = (char*)ctx->ws;
+    uint64_t* ex = (uint64_t*)p; p += align(e_bytes);
+    uint64_t* ez = (uint64_t*)p; p += align(e_bytes);
+    uint64_t* s1 = (uint64_t*)p; p += align(s1_bytes);
+    uint64_t* s2 = (uint64_t*)p; p += align(s2_bytes);
+    uint64_t* hz = (uint64_t*)p; p += align(hz_bytes);
+    uint64_t* hx = (uint64_t*)p;
+    GF2_TRY(gf2_dev_zero(ctx, hz, hz_bytes));
+    GF2_TRY(gf2_dev_zero(ctx, hx, hx_bytes));
+    for (int64_t done = 0; done < count; done += chunk) {
+        const int64_t now = count - done < chunk ? count - done : chunk;
+        GF2_TRY(gf2_sample_errors_dev(ctx, n, seed, first_sample + done, now, p_x, p_y, p_z, ex, ez, lde));
+        if (c1->r > 0) GF2_TRY(gf2_syndrome_dev(ctx, c1, ez, now, lde, GF2_LAYOUT_SAMPLE_MAJOR, s1, ls1));
+        if (c2->r > 0) GF2_TRY(gf2_syndrome_dev(ctx, c2, ex, now, lde, GF2_LAYOUT_SAMPLE_MAJOR, s2, ls2));
+        if (c1->r == 0) GF2_TRY(gf2_dev_zero(ctx, s1, (size_t)now * ls1 * 8));
+        if (c2->r == 0) GF2_TRY(gf2_dev_zero(ctx, s2, (size_t)now * ls2 * 8));
+        GF2_TRY(gf2_histogram_dev(ctx, s1, now, ls1, c1->r, mode, hz, nbins_z));
+        GF2_TRY(gf2_histogram_dev(ctx, s2, now, ls2, c2->r, mode, hx, nbins_x));
+    }
+    GF2_TRY(gf2_d2h(ctx, hist_z, hz, hz_bytes));
+    GF2_TRY(gf2_d2h(ctx, hist_x, hx, hx_bytes));
+    return GF2_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,339 @@
+"""
+Calderbank-Shor-Steane codes: the numeric core of the reference's css_code.py with every GF(2)
+product and elimination running on the MI355X (libgf2hip.so).
+
+Drop-in surface (same names, arguments, mutation and exception behaviour):
+    CSSCode(parity_check_c1, parity_check_c2)         css_code.py:32-75
+      .n .k .t .r_1 .r_2 .parity_check_c1 .parity_check_c2 ._c1_syndromes ._c2_syndromes
+      .z_operator_matrix() .x_operator_matrix()       css_code.py:124-136, 149-161
+      .stabilisers() .x_operators() .z_operators() .y_operators()   css_code.py:98-172
+      .is_transversal(gate_name)                      css_code.py:174-201
+    syndrome_table, normalize_parity_check, swap_columns, codes_equal, is_doubly_even,
+    pauli_term_for_row                                css_code.py:715-735, 783-850
+
+Quil program emission (encode_*, error_correct, measure, ...) is out of scope.
+pyQuil is not required: Pauli operators are returned as text labels ("X0*X3*X4*X5") unless pyQuil is
+importable, in which case PauliTerm objects are returned as in the reference.
+
+Build-defined additions: CSSCode(..., max_table_weight=), CSSCode.syndromes,
+CSSCode.monte_carlo, syndrome_batch.
+"""
+import itertools
+
+import numpy as np
+
+from . import _native
+from . import bin_matrix
+from .errors import InvalidCodeError
+from .qecc import QECC
+
+try:                                                # optional, as in SURVEY.md 7.3 item 7
+    from pyquil.paulis import ID as _ID, sX as _sX, sY as _sY, sZ as _sZ
+    _HAVE_PYQUIL = True
+except Exception:                                   # pragma: no cover - pyquil is absent in this image
+    _HAVE_PYQUIL = False
+
+
+class CSSCode(QECC):
+    """
+    A CSS code defined by two binary linear codes C_1, C_2 with the dual of C_2 inside C_1, given by
+    their parity check matrices.  Measured in the X basis a codeword is a codeword of C_1, in the Z
+    basis a codeword of C_2 (the reference's convention, css_code.py:22-31).
+    """
+
+    def __init__(self, parity_check_c1, parity_check_c2, max_table_weight=None):
+        parity_check_c1 = np.asarray(parity_check_c1)
+        parity_check_c2 = np.asarray(parity_check_c2)
+        r_1, n_1 = parity_check_c1.shape
+        r_2, n_2 = parity_check_c2.shape
+        if n_1 != n_2:
+            raise ValueError("C_1 and C_2 must have the same code word length")
+
+        h_1 = np.mod(np.array(parity_check_c1, dtype='int'), 2)
+        h_2 = np.mod(np.array(parity_check_c2, dtype='int'), 2)
+        if not np.array_equal(h_1, parity_check_c1):
+            raise ValueError("C_1 parity check matrix must be binary")
+        if not np.array_equal(h_2, parity_check_c2):
+            raise ValueError("C_2 parity check matrix must be binary")
+
+        ctx = _native.default_context()
+        # css_code.py:47-49 -- H1 . H2^T must vanish over GF(2)
+        product = ctx.matmul_abt(_native.pack_rows(h_1), r_1, _native.pack_rows(h_2), r_2, n_1)
+        if np.any(product):
+            raise ValueError("C_2 dual code must be a subspace of C_1")
+
+        # css_code.py:51-61 -- standard forms H1 = [I A1 A2], H2 = [D I E]; each normalisation's qubit
+        # swaps are applied to the other matrix as well.
+        h_1, qubit_swaps = normalize_parity_check(h_1, offset=0)
+        for indices in qubit_swaps:
+            swap_columns(h_2, indices)
+        h_2, qubit_swaps = normalize_parity_check(h_2, offset=r_1)
+        for indices in qubit_swaps:
+            swap_columns(h_1, indices)
+
+        self._n = n_1
+        self._k = n_1 - r_1 - r_2
+        self.r_1 = r_1
+        self.r_2 = r_2
+        self.parity_check_c1 = h_1
+        self.parity_check_c2 = h_2
+        t_1, self._c1_syndromes = syndrome_table(h_1, max_weight=max_table_weight)
+        t_2, self._c2_syndromes = syndrome_table(h_2, max_weight=max_table_weight)
+        self._t = min(t_1, t_2)
+        self._transversal_gates = self._determine_transversal_gates(h_1, h_2)
+        self._checks = None
+
+        if self.k != 1:
+            raise InvalidCodeError("currently only supports CSS codes for a single logical qubit")
+
+    @property
+    def n(self):
+        """Number of physical qubits per code block."""
+        return self._n
+
+    @property
+    def k(self):
+        """Number of logical qubits per code block."""
+        return self._k
+
+    @property
+    def t(self):
+        """Maximum number of errors per code block that can be corrected."""
+        return self._t
+
+    # -- operators ----------------------------------------------------------------------------------------
+    def stabilisers(self):
+        """Generators of the stabiliser group: the rows of H1 as X-type operators, then the rows of H2
+        as Z-type operators (css_code.py:98-111)."""
+        zeros = np.zeros(self.n, dtype='int')
+        x_type = (pauli_term_for_row(self.parity_check_c1[i, :], zeros) for i in range(self.r_1))
+        z_type = (pauli_term_for_row(zeros, self.parity_check_c2[i, :]) for i in range(self.r_2))
+        return list(itertools.chain(x_type, z_type))
+
+    def stabiliser_matrix(self):
+        """[build-defined]  The same generators as a (r_1 + r_2) x 2n check matrix [X part | Z part]."""
+        out = np.zeros((self.r_1 + self.r_2, 2 * self.n), dtype='int')
+        out[:self.r_1, :self.n] = self.parity_check_c1
+        out[self.r_1:, self.n:] = self.parity_check_c2
+        return out
+
+    def z_operator_matrix(self):
+        """Check matrix of the logical Z operators, the row [A2^T 0 I] (css_code.py:124-136)."""
+        n, r_1, r_2, k = self.n, self.r_1, self.r_2, self.k
+        check_mat = np.zeros((k, n), dtype='int')
+        check_mat[:, 0:r_1] = np.transpose(self.parity_check_c1[:, (r_1 + r_2):n])
+        check_mat[:, (r_1 + r_2):n] = np.identity(k)
+        return check_mat
+
+    def x_operator_matrix(self):
+        """Check matrix of the logical X operators, the row [0 E^T I] (css_code.py:149-161)."""
+        n, r_1, r_2, k = self.n, self.r_1, self.r_2, self.k
+        check_mat = np.zeros((k, n), dtype='int')
+        check_mat[:, r_1:(r_1 + r_2)] = np.transpose(self.parity_check_c2[:, (r_1 + r_2):n])
+        check_mat[:, (r_1 + r_2):n] = np.identity(k)
+        return check_mat
+
+    def z_operators(self):
+        """css_code.py:113-122."""
+        z_matrix = self.z_operator_matrix()
+        zeros = np.zeros_like(z_matrix, dtype='int')
+        return [pauli_term_for_row(zeros[i, :], z_matrix[i, :]) for i in range(self.k)]
+
+    def x_operators(self):
+        """css_code.py:138-147."""
+        x_matrix = self.x_operator_matrix()
+        zeros = np.zeros_like(x_matrix, dtype='int')
+        return [pauli_term_for_row(x_matrix[i, :], zeros[i, :]) for i in range(self.k)]
+
+    def y_operators(self):
+        """Y = iXZ (css_code.py:163-172): qubits carrying both X and Z carry Y."""
+        x_matrix, z_matrix = self.x_operator_matrix(), self.z_operator_matrix()
+        return [pauli_term_for_row(x_matrix[i, :], z_matrix[i, :]) for i in range(self.k)]
+
+    def is_transversal(self, gate_name):
+        """Whether the gate is known to be fault tolerant when applied transversally (css_code.py:174-180)."""
+        return gate_name in self._transversal_gates
+
+    def _determine_transversal_gates(self, parity_check_c1, parity_check_c2):
+        # css_code.py:182-201 (Steane 1998, Lemmas 2 and 3)
+        names = ['I', 'CNOT']
+        if codes_equal(parity_check_c1, parity_check_c2):
+            names += ['H', 'CZ']
+            if is_doubly_even(parity_check_c1):
+                names.append('S')
+        return frozenset(names)
+
+    # -- build-defined: batched syndromes and Monte-Carlo ---------------------------------------------------
+    def _device_checks(self):
+        if self._checks is None:
+            ctx = _native.default_context()
+            self._checks = (ctx.check_create(_native.pack_rows(self.parity_check_c1), self.r_1, self.n),
+                            ctx.check_create(_native.pack_rows(self.parity_check_c2), self.r_2, self.n))
+        return self._checks
+
+    def syndromes(self, x_errors, z_errors):
+        """[build-defined, x2]  Syndromes of B errors at once.  x_errors and z_errors are B x n 0/1
+        arrays.  X errors are detected by parity_check_c2 and Z errors by parity_check_c1
+        (css_code.py:457-470).  Returns (s_x: B x r_2, s_z: B x r_1)."""
+        return (syndrome_batch(self.parity_check_c2, x_errors), syndrome_batch(self.parity_check_c1, z_errors))
+
+    def monte_carlo(self, num_samples, p_x, p_y, p_z, seed=0, first_sample=0, mode=None):
+        """[build-defined, x3]  Histograms of the syndromes of `num_samples` independent Pauli errors
+        (X, Y, Z with probability p_x, p_y, p_z per qubit); sample i of the global stream is a pure
+        function of (seed, i).  mode 'full': bins indexed by bin_matrix.vec_to_int(syndrome), needs
+        r_1, r_2 <= 24; mode 'weight': bins indexed by syndrome weight.  Default: 'full' when possible.
+        Returns {'hist_z': from parity_check_c1 . e_z, 'hist_x': from parity_check_c2 . e_x, 'mode'}."""
+        from . import montecarlo
+        return montecarlo.run_local(self, num_samples, p_x, p_y, p_z, seed=seed, first_sample=first_sample,
+                                    mode=mode)
+
+
+# -- free functions -----------------------------------------------------------------------------------------
+
+def syndrome_batch(parity_check, errors):
+    """[build-defined, x2]  np.mod(np.matmul(parity_check, e), 2) (css_code.py:728) for every row e of
+    `errors` (B x n).  Returns a B x r array of dtype 'int'."""
+    parity_check = np.asarray(parity_check)
+    errors = np.asarray(errors)
+    r, n = parity_check.shape
+    if errors.ndim != 2 or errors.shape[1] != n:
+        raise ValueError("errors must be B x n")
+    batch = errors.shape[0]
+    if batch == 0 or r == 0:
+        return np.zeros((batch, r), dtype='int')
+    ctx = _native.default_context()
+    out = ctx.syndrome_batch(_native.pack_rows(parity_check), r, n, _native.pack_rows(errors), batch)
+    return _native.unpack_rows(out, r, dtype='int')
+
+
+def syndrome_table(parity_check, max_weight=None):
+    """
+    Given a parity check matrix of a binary linear code, determine the unique decoding threshold t and
+    return it along with a lookup table from syndromes (as bin_matrix.vec_to_int keys) to error vectors
+    of weight at most t (css_code.py:715-735).
+
+    Each weight class is enumerated in bin_matrix.weight_w_vectors order and its syndromes computed in
+    one batch on the GPU; a class containing a syndrome already seen (in an earlier class or earlier in
+    the same class) ends the search and is discarded as a whole, exactly as the reference's loop does.
+    max_weight [build-defined] caps the search for large codes, where the reference cannot finish.
+    """
+    parity_check = np.asarray(parity_check)
+    r, n = parity_check.shape
+    ctx = _native.default_context()
+    packed_h = _native.pack_rows(parity_check)
+    table = {}
+    for w in range(n + 1):
+        if max_weight is not None and w > max_weight:
+            return max_weight, table
+        supports = bin_matrix.weight_w_supports(n, w)
+        count = supports.shape[0]
+        errors = np.zeros((count, n), dtype=np.uint8)
+        if w:
+            errors[np.arange(count)[:, None], supports] = 1
+        syndromes = _native.unpack_rows(ctx.syndrome_batch(packed_h, r, n, _native.pack_rows(errors), count), r)
+        keys = [bin_matrix.vec_to_int(row) for row in syndromes]
+        layer = {}
+        for key, err in zip(keys, errors):
+            if key in table or key in layer:
+                return w - 1, table
+            layer[key] = err.astype('int')
+        table = {**table, **layer}
+    return n, table
+
+
+def swap_columns(mat, indices):
+    """In-place swap of two columns (css_code.py:783-785).  The two columns travel to the GPU as packed
+    bits (gf2_swap_columns), so their entries come back reduced modulo 2; the reference's callers
+    (css_code.py:56-61) only pass binary matrices."""
+    i, j = indices
+    m, n = mat.shape
+    if m == 0 or i == j:
+        return
+    packed = _native.pack_rows(mat[:, [i, j]])
+    _native.default_context().swap_columns(packed, m, 2, 0, 1)
+    mat[:, [i, j]] = _native.unpack_rows(packed, 2, dtype=mat.dtype)
+
+
+def pauli_term_for_row(x_check, z_check):
+    """
+    The Pauli operator of a check-matrix row (css_code.py:787-807; Nielsen & Chuang 10.5.1): Y where
+    both checks are set, else X or Z.  A pyQuil PauliTerm when pyQuil is importable, otherwise the text
+    label with factors in qubit order ("X0*X3*X4*X5"; "I" for the identity).
+    """
+    x_check = np.asarray(x_check)
+    z_check = np.asarray(z_check)
+    n = x_check.size
+    if not x_check.shape == (n,):
+        raise ValueError("x_check has the wrong dimensions")
+    if not z_check.shape == (n,):
+        raise ValueError("z_check has the wrong dimensions")
+    if _HAVE_PYQUIL:                                # pragma: no cover
+        result = _ID()
+        for i in range(n):
+            if x_check[i] and z_check[i]:
+                result *= _sY(i)
+            elif x_check[i]:
+                result *= _sX(i)
+            elif z_check[i]:
+                result *= _sZ(i)
+        return result
+    factors = []
+    for i in range(n):
+        if x_check[i] and z_check[i]:
+            factors.append("Y%d" % i)
+        elif x_check[i]:
+            factors.append("X%d" % i)
+        elif z_check[i]:
+            factors.append("Z%d" % i)
+    return "*".join(factors) if factors else "I"
+
+
+def normalize_parity_check(h, offset):
+    """
+    Put h into the form with an identity block in columns offset..offset+r-1 (css_code.py:809-836),
+    swapping qubits (columns) where a pivot is missing.  Like the reference it works in place AND returns
+    (h mod 2, list of (column, column) swaps).  The swaps and the result are bit-identical to the
+    reference's: the GPU kernel performs the same operations in the same order.
+    After the call `h` holds the reduced matrix (the reference leaves un-reduced integers congruent to
+    it modulo 2).
+    """
+    r, n = h.shape
+    if n < offset + r:
+        raise ValueError("not enough columns")
+    if r == 0:
+        return np.mod(h, 2), []
+    packed = _native.pack_rows(h)
+    try:
+        swaps = _native.default_context().normalize(packed, r, n, offset)
+    except _native.GF2Error as err:
+        if err.code == _native.GF2_E_DEPENDENT:
+            raise InvalidCodeError("rows are not independent") from None
+        if err.code == _native.GF2_E_COLUMNS:
+            raise ValueError("not enough columns") from None
+        raise
+    h[...] = _native.unpack_rows(packed, n, dtype=h.dtype)
+    return np.mod(h, 2), swaps
+
+
+def codes_equal(parity_check_1, parity_check_2):
+    """Two parity checks define the same code iff their RREFs agree (css_code.py:838-844)."""
+    parity_check_1 = np.asarray(parity_check_1)
+    parity_check_2 = np.asarray(parity_check_2)
+    if parity_check_1.shape != parity_check_2.shape:
+        return False
+    return np.array_equal(bin_matrix.reduced_row_echelon_form(parity_check_1),
+                          bin_matrix.reduced_row_echelon_form(parity_check_2))
+
+
+def is_doubly_even(mat):
+    """Whether every row weight is a multiple of 4 (css_code.py:846-850).  Row weights by popcount on
+    the GPU; for 0/1 matrices this is np.sum(mat, axis=1)."""
+    mat = np.asarray(mat)
+    m, n = mat.shape
+    if m == 0:
+        return True
+    if np.issubdtype(mat.dtype, np.integer) and mat.size and (mat.min() < 0 or mat.max() > 1):
+        # the reference sums the raw entries; outside {0,1} that is not a popcount
+        return not np.any(np.mod(np.sum(mat, axis=1), 4))
+    weights = _native.default_context().row_weights(_native.pack_rows(mat), m, n)
+    return not np.any(weights % 4)

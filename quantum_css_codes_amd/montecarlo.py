@@ -1,0 +1,80 @@
+"""
+Monte-Carlo syndrome histograms [build-defined, SURVEY.md 8a x3 and 8e].
+
+Every sample is independent and sample i is a pure function of (seed, i), so the global index range
+[first, first + count) is cut into contiguous shards, one per GPU / process, with no exchange on the
+data path.  The only collective is the final sum of the histograms: one all-reduce of at most
+(r_1 + 1) + (r_2 + 1) uint64 bins (about 32 KiB at n = 4096) -- RCCL over xGMI when torch.distributed
+runs on the "nccl" backend, gloo on CPU.  The result is identical for every number of shards.
+"""
+import numpy as np
+
+from . import _native
+
+
+def shard_range(first, count, rank, world):
+    """Contiguous shard of [first, first + count) for `rank` of `world`: the first (count % world)
+    ranks take one extra sample.  Returns (shard_first, shard_count)."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("bad rank/world")
+    base, extra = divmod(int(count), int(world))
+    mine = base + (1 if rank < extra else 0)
+    start = int(first) + rank * base + min(rank, extra)
+    return start, mine
+
+
+def pick_mode(r_1, r_2, mode=None):
+    if mode is None:
+        mode = 'full' if (r_1 <= 24 and r_2 <= 24) else 'weight'
+    if mode not in ('full', 'weight'):
+        raise ValueError("mode must be 'full' or 'weight'")
+    if mode == 'full' and (r_1 > 24 or r_2 > 24):
+        raise ValueError("full histograms need r_1, r_2 <= 24")
+    return mode
+
+
+def run_local(code, num_samples, p_x, p_y, p_z, seed=0, first_sample=0, mode=None):
+    """Histograms of samples [first_sample, first_sample + num_samples) on this process's GPU."""
+    mode = pick_mode(code.r_1, code.r_2, mode)
+    chk1, chk2 = code._device_checks()
+    ctx = _native.default_context()
+    hist_z, hist_x = ctx.mc_run(chk1, chk2, int(seed), int(first_sample), int(num_samples), float(p_x), float(p_y),
+                                float(p_z), _native.HIST_FULL if mode == 'full' else _native.HIST_WEIGHT)
+    return {'hist_z': hist_z, 'hist_x': hist_x, 'mode': mode}
+
+
+def all_reduce_histograms(hists, group=None, device=None):
+    """Sum a list of uint64 histograms over the ranks of torch.distributed (one all-reduce of the
+    concatenation).  Counts stay below 2^63, so the int64 transport is exact.  With no process group
+    initialised the input is returned unchanged."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [np.array(h, dtype=np.uint64) for h in hists]
+    sizes = [int(h.size) for h in hists]
+    flat = np.concatenate([np.asarray(h, dtype=np.uint64).view(np.int64) for h in hists])
+    if device is None:
+        device = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+    buf = torch.from_numpy(flat.copy()).to(device)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    total = buf.cpu().numpy().view(np.uint64)
+    out, pos = [], 0
+    for size in sizes:
+        out.append(total[pos:pos + size].copy())
+        pos += size
+    return out
+
+
+def run_sharded(code, num_samples, p_x, p_y, p_z, seed=0, first_sample=0, mode=None, group=None, local_fn=None):
+    """This rank's shard of the global range, then the histogram all-reduce.  `local_fn` (same signature
+    as run_local) replaces the GPU computation; the CPU tests of the sharding use it."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    start, mine = shard_range(first_sample, num_samples, rank, world)
+    fn = local_fn or run_local
+    part = fn(code, mine, p_x, p_y, p_z, seed=seed, first_sample=start, mode=mode)
+    hist_z, hist_x = all_reduce_histograms([part['hist_z'], part['hist_x']], group=group)
+    return {'hist_z': hist_z, 'hist_x': hist_x, 'mode': part['mode'], 'shard': (start, mine)}

@@ -1,0 +1,363 @@
+"""
+Parity of the HIP path (through the C ABI) against the oracle and the reference-generated fixtures.
+Needs a real MI355X: run with `pytest -m gpu`.  Bit-exact everywhere (integer work only).
+"""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle, cpu_ref
+from quantum_css_codes_amd import _native, bin_matrix, css_code
+from quantum_css_codes_amd.css_code import CSSCode
+from quantum_css_codes_amd.errors import InvalidCodeError
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(arr):
+    return hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return _native.default_context()
+
+
+def test_native_library_is_loaded(ctx):
+    assert _native.lib().gf2_version() >= 100
+    assert _native.device_count() >= 1
+    with open("/proc/self/maps") as maps:
+        assert "libgf2hip.so" in maps.read()
+
+
+# ---- bin_matrix ------------------------------------------------------------------------------------------
+
+def test_rref_kat():
+    # test/test_bin_matrix.py:8-20
+    mat = np.array([[1, 0, 1, 1, 0, 1, 0], [0, 1, 1, 0, 0, 1, 1], [1, 0, 1, 0, 1, 0, 1]], dtype='int')
+    expected = np.array([[1, 0, 1, 0, 1, 0, 1], [0, 1, 1, 0, 0, 1, 1], [0, 0, 0, 1, 1, 1, 1]], dtype='int')
+    before = mat.copy()
+    assert np.array_equal(bin_matrix.reduced_row_echelon_form(mat), expected)
+    assert np.array_equal(mat, before)
+
+
+def test_rref_golden(golden):
+    tags = [str(i) for i in golden["rref_shape_ids"]] + ["def", "zero", "norows", "nonbin", "u8", "i8"]
+    for tag in tags:
+        a = golden["rref_in_" + tag]
+        out = bin_matrix.reduced_row_echelon_form(a)
+        assert out.dtype == golden["rref_out_" + tag].dtype, tag
+        assert out.shape == a.shape
+        assert np.array_equal(out, golden["rref_out_" + tag]), tag
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (2, 130), (64, 64), (65, 64), (130, 70), (300, 1000), (1025, 200),
+                                   (1100, 1100)])
+def test_rref_random_vs_oracle(shape, ctx):
+    rng = np.random.default_rng(shape[0] * 7919 + shape[1])
+    a = rng.integers(0, 2, shape)
+    if shape[0] > 4:
+        a[3] = a[0] ^ a[1]                      # some dependence
+        a[:, shape[1] // 2] = 0                 # a pivot-free column
+    packed = _native.pack_rows(a)
+    pivots, rank = ctx.rref(packed, *shape)
+    want, want_piv, want_rank = c_oracle.rref(c_oracle.pack_rows(a), *shape)
+    assert rank == want_rank and list(pivots) == list(want_piv)
+    assert np.array_equal(packed, want)
+
+
+def test_rref_big512(golden):
+    a = np.random.default_rng(1024).integers(0, 2, (512, 1024)).astype(np.int64)
+    out = bin_matrix.reduced_row_echelon_form(a)
+    assert sha(_native.pack_rows(out)) == str(golden["big512_rref_sha"])
+    assert bin_matrix.rank(a) == int(golden["big512_rank"])
+
+
+def test_rref_full_size_config4(golden, ctx):
+    # BASELINE.json configs[3]: random 2048 x 4096; digest of the reference's own output
+    a = np.random.default_rng(4096).integers(0, 2, (2048, 4096)).astype(np.int64)
+    packed = _native.pack_rows(a)
+    pivots, rank = ctx.rref(packed, 2048, 4096)
+    assert rank == int(golden["big4096_rank"])
+    assert sha(packed) == str(golden["big4096_rref_sha"])
+    # idempotence: the RREF of an RREF is itself
+    again = packed.copy()
+    ctx.rref(again, 2048, 4096)
+    assert np.array_equal(again, packed)
+
+
+def test_rref_batch(ctx):
+    rng = np.random.default_rng(3)
+    mats = rng.integers(0, 2, (5, 70, 150))
+    packed = np.stack([_native.pack_rows(m) for m in mats])
+    pivots, ranks = ctx.rref_batch(packed, 5, 70, 150)
+    for b in range(5):
+        want, want_piv, want_rank = c_oracle.rref(c_oracle.pack_rows(mats[b]), 70, 150)
+        assert ranks[b] == want_rank and np.array_equal(packed[b], want)
+        assert list(pivots[b, :want_rank]) == list(want_piv)
+
+
+def test_nullspace(golden, steane_h, ctx):
+    for mat in (steane_h, golden["rref_in_4"], golden["rref_in_def"], golden["rref_in_5"], golden["rref_in_7"]):
+        mat = np.asarray(mat) & 1
+        got = bin_matrix.nullspace(mat)
+        assert np.array_equal(got, cpu_ref.nullspace(mat))
+        assert not np.any(np.mod(mat @ got.T, 2))
+    a = np.random.default_rng(5).integers(0, 2, (4, 6))
+    h = np.hstack([np.identity(4, dtype=int), a])
+    assert np.array_equal(bin_matrix.nullspace(h), np.hstack([a.T, np.identity(6, dtype=int)]))
+    assert bin_matrix.nullspace(np.zeros((0, 5), dtype=int)).shape == (5, 5)
+
+
+def test_nullspace_full_size(ctx):
+    a = np.random.default_rng(4096).integers(0, 2, (2048, 4096)).astype(np.uint8)
+    packed = _native.pack_rows(a)
+    basis = ctx.nullspace(packed, 2048, 4096)
+    assert np.array_equal(basis, c_oracle.nullspace(packed, 2048, 4096))
+    # H . N^T = 0 at full size, on the GPU
+    assert not np.any(ctx.matmul_abt(packed, 2048, basis, basis.shape[0], 4096))
+
+
+# ---- css_code free functions -------------------------------------------------------------------------------
+
+def test_normalize_golden(golden):
+    for tag in golden["norm_tags"]:
+        tag = str(tag)
+        work = np.array(golden["norm_in_" + tag])
+        out, swaps = css_code.normalize_parity_check(work, int(golden["norm_off_" + tag]))
+        assert np.array_equal(out, golden["norm_out_" + tag]), tag
+        assert np.array_equal(work, np.mod(golden["norm_mut_" + tag], 2)), tag      # in place, mod 2
+        assert [tuple(s) for s in swaps] == [tuple(s) for s in golden["norm_swaps_" + tag]], tag
+    with pytest.raises(InvalidCodeError, match="rows are not independent"):
+        css_code.normalize_parity_check(np.array(golden["norm_dep_in"]), 0)
+    with pytest.raises(ValueError, match="not enough columns"):
+        css_code.normalize_parity_check(np.zeros((3, 5), dtype=np.int64), 3)
+
+
+@pytest.mark.parametrize("case", [(40, 100, 0, 11), (40, 100, 60, 12), (130, 300, 64, 13), (1030, 1200, 100, 14)])
+def test_normalize_random_vs_oracle(case, ctx):
+    r, n, off, seed = case
+    rng = np.random.default_rng(seed)
+    for _ in range(50):
+        h = rng.integers(0, 2, (r, n))
+        h[:, rng.integers(off, off + r, 4)] = 0          # force column swaps
+        packed = _native.pack_rows(h)
+        rc, want, want_swaps = c_oracle.normalize(packed, r, n, off)
+        if rc == 0:
+            break
+    assert rc == 0 and len(want_swaps) > 0
+    swaps = ctx.normalize(packed, r, n, off)
+    assert swaps == want_swaps
+    assert np.array_equal(packed, want)
+
+
+def test_normalize_full_size_config4(golden, ctx):
+    a = np.random.default_rng(4096).integers(0, 2, (2048, 4096)).astype(np.int64)
+    packed = _native.pack_rows(a)
+    swaps = ctx.normalize(packed, 2048, 4096, 0)
+    assert swaps == [tuple(s) for s in golden["big4096_norm_swaps"]]
+    assert sha(packed) == str(golden["big4096_norm_sha"])
+
+
+def test_swap_columns(ctx):
+    rng = np.random.default_rng(9)
+    mat = rng.integers(0, 2, (37, 200))
+    want = mat.copy()
+    for pair in ((0, 199), (63, 64), (5, 6), (70, 70), (130, 2)):
+        css_code.swap_columns(mat, pair)
+        cpu_ref.swap_columns(want, pair)
+        assert np.array_equal(mat, want)
+    packed = _native.pack_rows(mat)
+    ctx.swap_columns(packed, 37, 200, 64, 191)
+    cpu_ref.swap_columns(want, (64, 191))
+    assert np.array_equal(_native.unpack_rows(packed, 200), want)
+
+
+def test_codes_equal_doubly_even(golden):
+    a, b, c = golden["ceq_a"], golden["ceq_b"], golden["ceq_c"]
+    got = [css_code.codes_equal(a, b), css_code.codes_equal(a, c), css_code.codes_equal(a, a[:5])]
+    assert got == [bool(v) for v in golden["ceq_res"]]
+    de = golden["de_in"]
+    assert [css_code.is_doubly_even(de[i:i + 1]) for i in range(10)] == [bool(v) for v in golden["de_rows"]]
+    # test/test_css_code.py:120-143
+    a = np.array([[0] * 8, [0, 0, 1, 1, 0, 1, 1, 0], [1, 1, 1, 0, 0, 0, 0, 1], [1] * 8])
+    b = np.array([[0] * 8, [0, 0, 1, 1, 0, 1, 1, 0], [0, 1, 1, 0, 0, 0, 0, 1], [1] * 8])
+    assert css_code.is_doubly_even(a) and not css_code.is_doubly_even(b)
+    wide = np.random.default_rng(2).integers(0, 2, (70, 1000))
+    assert css_code.is_doubly_even(wide) == cpu_ref.is_doubly_even(wide)
+
+
+def test_matmul_abt(ctx):
+    rng = np.random.default_rng(21)
+    for (ra, rb, n) in ((3, 3, 7), (70, 130, 200), (5, 300, 4100)):
+        a, b = rng.integers(0, 2, (ra, n)), rng.integers(0, 2, (rb, n))
+        got = _native.unpack_rows(ctx.matmul_abt(_native.pack_rows(a), ra, _native.pack_rows(b), rb, n), rb)
+        assert np.array_equal(got, np.mod(a @ b.T, 2))
+
+
+# ---- syndromes -------------------------------------------------------------------------------------------------
+
+def test_syndromes_golden(golden):
+    for tag in ("steane", "rm15", "r64x128", "r70x200"):
+        h, e, s = golden["syn_h_" + tag], golden["syn_e_" + tag], golden["syn_s_" + tag]
+        assert np.array_equal(css_code.syndrome_batch(h, e), s), tag
+
+
+@pytest.mark.parametrize("shape", [(1, 65, 3), (64, 64, 100), (65, 127, 1000), (200, 1000, 4097), (130, 4096, 300),
+                                   (70, 4100, 50), (64, 9000, 20), (3, 7, 5000), (10, 15, 5000), (64, 64, 5000)])
+def test_syndrome_batch_vs_oracle(shape, ctx):
+    r, n, batch = shape
+    rng = np.random.default_rng(r * 31 + n)
+    h = _native.pack_rows(rng.integers(0, 2, (r, n)))
+    e = _native.pack_rows(rng.integers(0, 2, (batch, n)))
+    got = ctx.syndrome_batch(h, r, n, e, batch)
+    assert np.array_equal(got, c_oracle.syndrome_batch(h, r, n, e, batch))
+
+
+def test_syndrome_batch_full_size(golden, ctx):
+    a = np.random.default_rng(4096).integers(0, 2, (2048, 4096)).astype(np.int64)
+    e = np.random.default_rng(77).integers(0, 2, (32, 4096)).astype(np.int64)
+    h = _native.pack_rows(a)
+    got = ctx.syndrome_batch(h, 2048, 4096, _native.pack_rows(e), 32)
+    assert sha(got) == str(golden["big4096_syn_sha"])          # the reference's own products
+    # linearity at full size: S(e1 ^ e2) = S(e1) ^ S(e2)
+    rng = np.random.default_rng(5)
+    e1 = rng.integers(0, 2**63, (5000, 64), dtype=np.int64).view(np.uint64)
+    e2 = rng.integers(0, 2**63, (5000, 64), dtype=np.int64).view(np.uint64)
+    s1, s2 = ctx.syndrome_batch(h, 2048, 4096, e1, 5000), ctx.syndrome_batch(h, 2048, 4096, e2, 5000)
+    assert np.array_equal(ctx.syndrome_batch(h, 2048, 4096, e1 ^ e2, 5000), s1 ^ s2)
+    assert np.array_equal(s1[:200], c_oracle.syndrome_batch(h, 2048, 4096, e1[:200], 200))
+
+
+@pytest.mark.parametrize("shape", [(3, 7, 1000), (10, 15, 64 * 300 + 5), (4, 15, 63), (20, 31, 4096), (64, 64, 1000)])
+def test_syndrome_bit_sliced(shape, ctx):
+    r, n, batch = shape
+    rng = np.random.default_rng(r + n)
+    hm, em = rng.integers(0, 2, (r, n)), rng.integers(0, 2, (batch, n))
+    h = _native.pack_rows(hm)
+    e_sliced = _native.pack_rows(em.T)                 # n x words(batch)
+    got = ctx.syndrome_batch_sliced(h, r, n, e_sliced, batch)
+    want = np.mod(em @ hm.T, 2)                        # batch x r
+    assert np.array_equal(_native.unpack_rows(got, batch).T, want)
+
+
+# ---- CSSCode ---------------------------------------------------------------------------------------------------
+
+def test_steane_kat(steane_h):
+    # test/test_css_code.py:13-59, 108-118
+    code = CSSCode(steane_h, steane_h)
+    assert np.array_equal(code.parity_check_c1[:, 0:3], np.identity(3))
+    assert np.array_equal(code.parity_check_c2[:, 3:6], np.identity(3))
+    assert code.stabilisers() == ["X0*X3*X4*X5", "X1*X3*X5*X6", "X2*X4*X5*X6",
+                                  "Z0*Z2*Z3*Z6", "Z0*Z1*Z4*Z6", "Z0*Z1*Z2*Z5"]
+    assert code.z_operators() == ["Z1*Z2*Z6"]
+    assert code.x_operators() == ["X3*X4*X6"]
+    assert code.y_operators() == ["Z1*Z2*X3*X4*Y6"]
+    for gate in ('I', 'CNOT', 'H', 'CZ', 'S'):
+        assert code.is_transversal(gate)
+    t, table = css_code.syndrome_table(code.parity_check_c1)
+    assert t == 1 and len(table) == 8
+    for s, e in table.items():
+        assert s == bin_matrix.vec_to_int(np.mod(np.matmul(code.parity_check_c1, e), 2))
+
+
+@pytest.mark.parametrize("tag", ["steane", "rm15"])
+def test_css_code_golden(golden, tag):
+    code = CSSCode(golden[tag + "_in1"], golden[tag + "_in2"])
+    assert np.array_equal(code.parity_check_c1, golden[tag + "_h1"])
+    assert np.array_equal(code.parity_check_c2, golden[tag + "_h2"])
+    assert [code.n, code.k, code.t, code.r_1, code.r_2] == list(golden[tag + "_nktr"])
+    assert sorted(code._transversal_gates) == [str(g) for g in golden[tag + "_gates"]]
+    assert np.array_equal(code.z_operator_matrix(), golden[tag + "_zop"])
+    assert np.array_equal(code.x_operator_matrix(), golden[tag + "_xop"])
+    for which, tab in (("c1", code._c1_syndromes), ("c2", code._c2_syndromes)):
+        keys, errs = golden["%s_%s_keys" % (tag, which)], golden["%s_%s_errs" % (tag, which)]
+        assert [int(k) for k in tab.keys()] == [int(k) for k in keys]
+        for k, e in zip(keys, errs):
+            assert np.array_equal(tab[int(k)], e)
+
+
+def test_css_code_errors(steane_h):
+    with pytest.raises(ValueError, match="same code word length"):
+        CSSCode(steane_h, steane_h[:, :6])
+    with pytest.raises(ValueError, match="C_1 parity check matrix must be binary"):
+        CSSCode(steane_h * 2, steane_h)
+    with pytest.raises(ValueError, match="C_2 parity check matrix must be binary"):
+        CSSCode(steane_h, steane_h * 3)
+    with pytest.raises(ValueError, match="dual code must be a subspace"):
+        CSSCode(steane_h, np.array([[1, 0, 0, 0, 0, 0, 0]]))
+    with pytest.raises(InvalidCodeError):
+        CSSCode(np.array([[1, 1, 1, 1]]), np.array([[1, 1, 1, 1]]))
+
+
+def test_css_code_mid_size_vs_oracle():
+    # random dual pair, n = 96: H2 = first rows of nullspace(H1); capped tables (reference cannot finish)
+    rng = np.random.default_rng(96)
+    h1 = rng.integers(0, 2, (48, 96))
+    while bin_matrix.rank(h1) < 48:
+        h1 = rng.integers(0, 2, (48, 96))
+    h2 = bin_matrix.nullspace(h1)[:47]
+    code = CSSCode(h1, h2, max_table_weight=1)
+    want = cpu_ref.CSSCode(h1, h2, max_table_weight=1)
+    assert np.array_equal(code.parity_check_c1, want.parity_check_c1)
+    assert np.array_equal(code.parity_check_c2, want.parity_check_c2)
+    assert (code.t, code.k) == (want.t, want.k)
+    assert np.array_equal(code.z_operator_matrix(), want.z_operator_matrix())
+    assert np.array_equal(code.x_operator_matrix(), want.x_operator_matrix())
+    assert code.stabilisers() == want.stabiliser_labels()
+    assert list(code._c2_syndromes.keys()) == [int(k) for k in want._c2_syndromes.keys()]
+
+
+# ---- Monte-Carlo -------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [7, 64, 70, 200, 4096])
+def test_sampler_vs_oracle(n, ctx):
+    count, lde = 300, max(1, _native.words_for(n))
+    for (px, py, pz) in ((0.01, 0.01, 0.01), (0.2, 0.1, 0.3), (0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 0.5, 0.5)):
+        ex_buf, ez_buf = ctx.alloc(count * lde * 8), ctx.alloc(count * lde * 8)
+        ctx.sample_errors_dev(n, 99, 1000, count, px, py, pz, ex_buf, ez_buf, lde)
+        ex, ez = ex_buf.download((count, lde), "<u8"), ez_buf.download((count, lde), "<u8")
+        want_x, want_z = c_oracle.sample_errors(n, 99, 1000, count, px, py, pz)
+        assert np.array_equal(ex, want_x) and np.array_equal(ez, want_z), (n, px, py, pz)
+        ex_buf.free()
+        ez_buf.free()
+
+
+def test_monte_carlo_steane_config2(steane_h):
+    # BASELINE.json configs[1]: Steane, 10^6 random Pauli errors, bit-exact vs CPU
+    code = CSSCode(steane_h, steane_h)
+    h1, h2 = c_oracle.pack_rows(code.parity_check_c1), c_oracle.pack_rows(code.parity_check_c2)
+    for (px, py, pz) in ((0.01 / 3, 0.01 / 3, 0.01 / 3), (0.25, 0.25, 0.25)):
+        got = code.monte_carlo(10**6, px, py, pz, seed=0xC55C0DE)
+        hz, hx = c_oracle.mc(h1, 3, h2, 3, 7, 0xC55C0DE, 0, 10**6, px, py, pz, 0)
+        assert got['mode'] == 'full'
+        assert np.array_equal(got['hist_z'], hz) and np.array_equal(got['hist_x'], hx)
+
+
+def test_monte_carlo_rm15(rm15):
+    code = CSSCode(*rm15)
+    h1, h2 = c_oracle.pack_rows(code.parity_check_c1), c_oracle.pack_rows(code.parity_check_c2)
+    got = code.monte_carlo(300000, 0.03, 0.01, 0.02, seed=15, first_sample=12345)
+    hz, hx = c_oracle.mc(h1, 4, h2, 10, 15, 15, 12345, 300000, 0.03, 0.01, 0.02, 0)
+    assert got['hist_z'].size == 16 and got['hist_x'].size == 1024
+    assert np.array_equal(got['hist_z'], hz) and np.array_equal(got['hist_x'], hx)
+    # weight mode and shard-independence: two halves add up to the whole
+    whole = code.monte_carlo(100000, 0.03, 0.01, 0.02, seed=15, mode='weight')
+    a = code.monte_carlo(40000, 0.03, 0.01, 0.02, seed=15, mode='weight')
+    b = code.monte_carlo(60000, 0.03, 0.01, 0.02, seed=15, first_sample=40000, mode='weight')
+    assert np.array_equal(whole['hist_z'], a['hist_z'] + b['hist_z'])
+    assert np.array_equal(whole['hist_x'], a['hist_x'] + b['hist_x'])
+
+
+def test_monte_carlo_n4096_weight_histograms(ctx):
+    # BASELINE.json configs[4] at reduced sample count: dense random 2048/2047 x 4096 checks
+    rng = np.random.default_rng(4096)
+    h1 = _native.pack_rows(rng.integers(0, 2, (2048, 4096)))
+    h2 = _native.pack_rows(rng.integers(0, 2, (2047, 4096)))
+    c1, c2 = ctx.check_create(h1, 2048, 4096), ctx.check_create(h2, 2047, 4096)
+    count = 6000
+    hz, hx = ctx.mc_run(c1, c2, 0xC55C0DE, 10**6, count, 0.01 / 3, 0.01 / 3, 0.01 / 3, _native.HIST_WEIGHT)
+    wz, wx = c_oracle.mc(h1, 2048, h2, 2047, 4096, 0xC55C0DE, 10**6, count, 0.01 / 3, 0.01 / 3, 0.01 / 3, 1)
+    assert np.array_equal(hz, wz) and np.array_equal(hx, wx)
+    assert int(hz.sum()) == count and int(hx.sum()) == count

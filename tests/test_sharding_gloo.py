@@ -1,0 +1,84 @@
+"""
+The N > 1 path on CPU: world_size-2 torch.distributed (gloo) processes each take their shard of the global
+sample range and all-reduce the histograms; the result must equal the unsharded histogram.  The GPU kernel
+is replaced by the C oracle here (run_sharded's local_fn hook) -- what is under test is the sharding
+arithmetic and the collective, which are the same code on RCCL.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_exactly():
+    from quantum_css_codes_amd.montecarlo import shard_range
+    for (first, count, world) in ((0, 10, 3), (5, 100, 8), (7, 3, 4), (0, 0, 2), (11, 10**8, 8)):
+        pos, total = first, 0
+        for rank in range(world):
+            start, mine = shard_range(first, count, rank, world)
+            assert start == pos and mine >= 0
+            pos += mine
+            total += mine
+        assert total == count
+    with pytest.raises(ValueError):
+        shard_range(0, 10, 2, 2)
+
+
+def test_pick_mode():
+    from quantum_css_codes_amd.montecarlo import pick_mode
+    assert pick_mode(3, 3) == 'full' and pick_mode(2048, 2047) == 'weight' and pick_mode(3, 3, 'weight') == 'weight'
+    with pytest.raises(ValueError):
+        pick_mode(30, 3, 'full')
+    with pytest.raises(ValueError):
+        pick_mode(3, 3, 'other')
+
+
+class _Code(object):
+    def __init__(self, h1, h2):
+        self.parity_check_c1, self.parity_check_c2 = h1, h2
+        self.r_1, self.r_2, self.n = h1.shape[0], h2.shape[0], h1.shape[1]
+
+
+def _oracle_local(code, num_samples, p_x, p_y, p_z, seed=0, first_sample=0, mode=None):
+    from oracle import c_oracle
+    from quantum_css_codes_amd.montecarlo import pick_mode
+    mode = pick_mode(code.r_1, code.r_2, mode)
+    hz, hx = c_oracle.mc(c_oracle.pack_rows(code.parity_check_c1), code.r_1, c_oracle.pack_rows(code.parity_check_c2),
+                         code.r_2, code.n, seed, first_sample, num_samples, p_x, p_y, p_z, 0 if mode == 'full' else 1)
+    return {'hist_z': hz, 'hist_x': hx, 'mode': mode}
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from quantum_css_codes_amd import montecarlo
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(1)
+    code = _Code(rng.integers(0, 2, (5, 70)), rng.integers(0, 2, (66, 70)))
+    res = montecarlo.run_sharded(code, 5001, 0.05, 0.02, 0.03, seed=9, first_sample=100, mode='weight',
+                                 local_fn=_oracle_local)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), hist_z=res['hist_z'], hist_x=res['hist_x'],
+             shard=np.array(res['shard']))
+    dist.destroy_process_group()
+
+
+def test_two_rank_histogram_allreduce(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    rng = np.random.default_rng(1)
+    code = _Code(rng.integers(0, 2, (5, 70)), rng.integers(0, 2, (66, 70)))
+    whole = _oracle_local(code, 5001, 0.05, 0.02, 0.03, seed=9, first_sample=100, mode='weight')
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    assert list(r0["shard"]) == [100, 2501] and list(r1["shard"]) == [2601, 2500]
+    for r in (r0, r1):                                    # every rank holds the global histogram
+        assert np.array_equal(r["hist_z"], whole['hist_z']) and np.array_equal(r["hist_x"], whole['hist_x'])
+    assert int(whole['hist_z'].sum()) == 5001
