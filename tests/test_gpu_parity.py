@@ -135,7 +135,7 @@ def test_normalize_golden(golden):
         css_code.normalize_parity_check(np.zeros((3, 5), dtype=np.int64), 3)
 
 
-@pytest.mark.parametrize("case", [(40, 100, 0, 11), (40, 100, 60, 12), (130, 300, 64, 13), (1030, 1200, 100, 14)])
+@pytest.mark.parametrize("case", [(40, 100, 0, 11), (40, 110, 60, 12), (130, 300, 64, 13), (1030, 1200, 100, 14)])
 def test_normalize_random_vs_oracle(case, ctx):
     r, n, off, seed = case
     rng = np.random.default_rng(seed)
