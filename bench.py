@@ -18,7 +18,7 @@ One step = one pass of the hot path over that batch: s_z = H1 . e_z and s_x = H2
 (RCCL) inside the timed region.  value = N * K * batch / max-over-ranks time.
 
 The JSON line also carries
-  roofline      dominant kernel (syndrome_tables_kernel) against the HBM roofline: algorithmic bytes per
+  roofline      dominant kernel (syndrome_tiled_kernel) against the HBM roofline: algorithmic bytes per
                 launch = batch * (n/8 read + r/8 written) (1536 B per sample over the two
                 launches) / its mean launch time, measured live with HIP events on the kernel's stream.
   cpu_baseline  the reference's NumPy path (oracle/cpu_ref.py restatement of css_code.py:728) timed on this
@@ -110,18 +110,19 @@ def main():
     chk1, chk2 = ctx.check_create(h1, R1, N_QUBITS), ctx.check_create(h2, R2, N_QUBITS)
 
     batch = 1 << args.batch_log2
-    lde, ls1, ls2 = N_QUBITS // 64, _native.words_for(R1), _native.words_for(R2)
-    ex, ez = ctx.alloc(batch * lde * 8), ctx.alloc(batch * lde * 8)
+    lde, ls1, ls2 = _native.tiled_ld(N_QUBITS), _native.words_for(R1), _native.words_for(R2)
+    tiled = _native.LAYOUT_TILED          # device-native error layout (include/gf2hip.h), written by the sampler
+    ex, ez = ctx.alloc(_native.tiled_words(N_QUBITS, batch) * 8), ctx.alloc(_native.tiled_words(N_QUBITS, batch) * 8)
     s1, s2 = ctx.alloc(batch * ls1 * 8), ctx.alloc(batch * ls2 * 8)
     hz, hx = ctx.alloc((R1 + 1) * 8), ctx.alloc((R2 + 1) * 8)
     # this rank's shard of the global sample stream (sample i is a function of (seed, i) only)
     first = rank * batch
-    ctx.sample_errors_dev(N_QUBITS, SEED, first, batch, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, ex, ez, lde)
+    ctx.sample_errors_dev(N_QUBITS, SEED, first, batch, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, ex, ez, lde, tiled)
     ctx.sync()
 
     def step():
-        ctx.syndrome_dev(chk1, ez, batch, lde, s1, ls1)
-        ctx.syndrome_dev(chk2, ex, batch, lde, s2, ls2)
+        ctx.syndrome_dev(chk1, ez, batch, lde, s1, ls1, tiled)
+        ctx.syndrome_dev(chk2, ex, batch, lde, s2, ls2, tiled)
         ctx.histogram_dev(s1, batch, ls1, R1, _native.HIST_WEIGHT, hz, R1 + 1)
         ctx.histogram_dev(s2, batch, ls2, R2, _native.HIST_WEIGHT, hx, R2 + 1)
 
@@ -189,7 +190,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("syndrome_tables_kernel_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("syndrome_tiled_kernel_bytes_per_launch")
         out = {
             "metric": "syndromes/sec (n=4096 CSS)", "value": value, "unit": "syndromes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,7 +200,7 @@ def main():
                                    "standard form), depolarising p=0.01, errors resident in HBM",
                        "samples_per_gpu_per_step": batch, "global_samples_per_step": batch * world,
                        "parallelism": "sample-range shards, 1 histogram all-reduce"},
-            "roofline": {"bound": "hbm", "kernel": "syndrome_tables_kernel", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "syndrome_tiled_kernel", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_launch_s * 1e3,
                          "launches": syn_launches},

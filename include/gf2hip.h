@@ -41,6 +41,13 @@ extern "C" {
 #define GF2_LAYOUT_SAMPLE_MAJOR 0  /* E: B rows of lde words (one error per row); S: B rows of lds words */
 #define GF2_LAYOUT_BIT_SLICED   1  /* E: n rows of ceil(B/64) words (word b of row q = qubit q of samples
                                       64b..64b+63); S: r rows likewise.  Requires n <= 64 and r <= 64. */
+#define GF2_LAYOUT_TILED        2  /* Device-native error layout of the large-n syndrome kernel.  Samples are
+                                      grouped in tiles of 64; with ldt = gf2_tiled_ld(n) (even) words per sample,
+                                      word w of sample b sits at word offset
+                                          (b>>6)*64*ldt + (w>>1)*128 + (b&63)*2 + (w&1)
+                                      so the 64 lanes of a wavefront read one 16-byte piece each from 1 KiB of
+                                      contiguous memory.  The buffer holds ceil(B/64) whole tiles
+                                      (gf2_tiled_words).  S stays sample-major. */
 
 #define GF2_HIST_FULL    0     /* bins indexed by vec_to_int(syndrome) (bin_matrix.py:36-43), 2^r bins  */
 #define GF2_HIST_WEIGHT  1     /* bins indexed by the syndrome's Hamming weight, r+1 bins               */
@@ -137,13 +144,22 @@ int gf2_row_weights(gf2_ctx* ctx, const uint64_t* a, int64_t m, int64_t n, int64
 int gf2_check_create(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, int64_t ld, gf2_check** check_out);
 int gf2_check_destroy(gf2_ctx* ctx, gf2_check* check);
 
+/* Tiled layout helpers: words per sample (even, >= ceil(n/64)) and words of a buffer for `batch` samples. */
+int64_t gf2_tiled_ld(int64_t n);
+int64_t gf2_tiled_words(int64_t n, int64_t batch);
+/* Sample-major (batch x lde) -> tiled, both on the device; asynchronous. */
+int gf2_retile_dev(gf2_ctx* ctx, const uint64_t* e_dev, int64_t batch, int64_t lde, int64_t n, uint64_t* tiled_dev);
+
 /* Host buffers, synchronous. */
 int gf2_syndrome_batch(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, int64_t ldh,
                        const uint64_t* e, int64_t batch, int64_t lde, int layout,
                        uint64_t* s_out, int64_t lds);
 
 /* Device buffers, asynchronous on the context's stream.
- * Sample-major: e_dev is batch x lde, s_dev is batch x lds (lds >= ceil(r/64)).
+ * Sample-major: e_dev is batch x lde, s_dev is batch x lds (lds >= ceil(r/64)).  For n > 64 the errors are
+ *               first re-tiled into context workspace (one extra streaming pass); keep resident data in
+ *               GF2_LAYOUT_TILED to avoid it.
+ * Tiled:        e_dev as described at GF2_LAYOUT_TILED (lde ignored); s_dev is batch x lds.
  * Bit-sliced:   e_dev is n x lde with lde >= ceil(batch/64); s_dev is r x lds, lds >= ceil(batch/64). */
 int gf2_syndrome_dev(gf2_ctx* ctx, const gf2_check* check, const uint64_t* e_dev, int64_t batch, int64_t lde,
                      int layout, uint64_t* s_dev, int64_t lds);
@@ -158,10 +174,11 @@ int gf2_histogram_dev(gf2_ctx* ctx, const uint64_t* s_dev, int64_t batch, int64_
  * generator is specified in DESIGN.md ("Sampler") and restated in oracle/.  X errors are caught by
  * parity_check_c2, Z errors by parity_check_c1 (css_code.py:457-470). */
 
-/* Writes packed errors for samples first_sample .. first_sample+count-1 (sample-major, count x lde). */
+/* Writes packed errors for samples first_sample .. first_sample+count-1.  layout GF2_LAYOUT_SAMPLE_MAJOR:
+ * count x lde; GF2_LAYOUT_TILED: gf2_tiled_words(n, count) words (lde ignored; pad samples are zero). */
 int gf2_sample_errors_dev(gf2_ctx* ctx, int64_t n, uint64_t seed, int64_t first_sample, int64_t count,
                           double p_x, double p_y, double p_z,
-                          uint64_t* ex_dev, uint64_t* ez_dev, int64_t lde);
+                          uint64_t* ex_dev, uint64_t* ez_dev, int64_t lde, int layout);
 
 /* Full pipeline: sample -> syndromes -> histograms, chunked through device workspace owned by ctx.
  * hist_z (from H1 . e_z) and hist_x (from H2 . e_x) are host uint64 arrays, overwritten. */

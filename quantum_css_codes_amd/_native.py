@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgf2hip.so")
 
 GF2_OK, GF2_E_ARG, GF2_E_COLUMNS, GF2_E_DEPENDENT, GF2_E_HIP, GF2_E_NOMEM = 0, -1, -2, -3, -4, -5
-LAYOUT_SAMPLE_MAJOR, LAYOUT_BIT_SLICED = 0, 1
+LAYOUT_SAMPLE_MAJOR, LAYOUT_BIT_SLICED, LAYOUT_TILED = 0, 1, 2
 HIST_FULL, HIST_WEIGHT = 0, 1
 K_SYNDROME, K_HIST, K_SAMPLER, K_ELIM = 0, 1, 2, 3
 
@@ -71,11 +71,14 @@ SIGNATURES = {
     "gf2_syndrome_dev": [_p, _p, _p, _c_i64, _c_i64, ctypes.c_int, _p, _c_i64],
     "gf2_histogram_dev": [_p, _p, _c_i64, _c_i64, _c_i64, ctypes.c_int, _p, _c_i64],
     "gf2_sample_errors_dev": [_p, _c_i64, _c_u64, _c_i64, _c_i64, ctypes.c_double, ctypes.c_double,
-                              ctypes.c_double, _p, _p, _c_i64],
+                              ctypes.c_double, _p, _p, _c_i64, ctypes.c_int],
+    "gf2_tiled_ld": [_c_i64],
+    "gf2_tiled_words": [_c_i64, _c_i64],
+    "gf2_retile_dev": [_p, _p, _c_i64, _c_i64, _c_i64, _p],
     "gf2_mc_run": [_p, _p, _p, _c_u64, _c_i64, _c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                    ctypes.c_int, _p, _c_i64, _p, _c_i64],
 }
-_RESTYPES = {"gf2_last_error": ctypes.c_char_p}
+_RESTYPES = {"gf2_last_error": ctypes.c_char_p, "gf2_tiled_ld": _c_i64, "gf2_tiled_words": _c_i64}
 
 _lib = None
 _lib_lock = threading.Lock()
@@ -143,6 +146,34 @@ def unpack_rows(words, n, dtype="int"):
         return np.zeros((m, n), dtype=dtype)
     bits = np.unpackbits(words.view(np.uint8).reshape(m, -1), axis=1, bitorder="little")
     return bits[:, :n].astype(dtype)
+
+
+def tiled_ld(n):
+    return int(lib().gf2_tiled_ld(int(n)))
+
+
+def tiled_words(n, batch):
+    return int(lib().gf2_tiled_words(int(n), int(batch)))
+
+
+def tile_rows(packed, n):
+    """Host model of GF2_LAYOUT_TILED: sample-major packed rows (B x ld) -> flat tiled words."""
+    packed = np.ascontiguousarray(packed, dtype="<u8")
+    batch, ld = packed.shape
+    ldt = tiled_ld(n)
+    tiles = max(1, (batch + 63) // 64)
+    full = np.zeros((tiles * 64, ldt), dtype="<u8")
+    full[:batch, :min(ld, ldt)] = packed[:, :min(ld, ldt)]
+    # (tile, lane, pair, half) -> (tile, pair, lane, half)
+    return np.ascontiguousarray(full.reshape(tiles, 64, ldt // 2, 2).transpose(0, 2, 1, 3)).reshape(-1)
+
+
+def untile_rows(flat, n, batch):
+    flat = np.ascontiguousarray(flat, dtype="<u8")
+    ldt = tiled_ld(n)
+    tiles = flat.size // (64 * ldt)
+    rows = flat.reshape(tiles, ldt // 2, 64, 2).transpose(0, 2, 1, 3).reshape(tiles * 64, ldt)
+    return np.ascontiguousarray(rows[:batch])
 
 
 def _ptr(arr):
@@ -338,9 +369,13 @@ class Context(object):
     def histogram_dev(self, s_buf, batch, lds, r, mode, hist_buf, nbins):
         check(lib().gf2_histogram_dev(self.handle, s_buf.ptr, batch, lds, r, mode, hist_buf.ptr, nbins))
 
-    def sample_errors_dev(self, n, seed, first, count, p_x, p_y, p_z, ex_buf, ez_buf, lde):
+    def sample_errors_dev(self, n, seed, first, count, p_x, p_y, p_z, ex_buf, ez_buf, lde,
+                          layout=LAYOUT_SAMPLE_MAJOR):
         check(lib().gf2_sample_errors_dev(self.handle, n, seed & 0xFFFFFFFFFFFFFFFF, first, count, p_x, p_y, p_z,
-                                          ex_buf.ptr, ez_buf.ptr, lde))
+                                          ex_buf.ptr, ez_buf.ptr, lde, layout))
+
+    def retile_dev(self, e_buf, batch, lde, n, tiled_buf):
+        check(lib().gf2_retile_dev(self.handle, e_buf.ptr, batch, lde, n, tiled_buf.ptr))
 
     def mc_run(self, chk1, chk2, seed, first, count, p_x, p_y, p_z, mode):
         """Returns (hist_z, hist_x) as uint64 arrays."""

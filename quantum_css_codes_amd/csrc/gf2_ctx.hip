@@ -64,7 +64,8 @@ int gf2_ctx_destroy(gf2_ctx* ctx) {
     if (!ctx) return GF2_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->ws) (void)hipFree(ctx->ws);
+    for (int k = 0; k < 2; ++k)
+        if (ctx->ws[k]) (void)hipFree(ctx->ws[k]);
     for (int i = 0; i < gf2_ctx::kProfSlots; ++i) {
         (void)hipEventDestroy(ctx->prof_ev[i][0]);
         (void)hipEventDestroy(ctx->prof_ev[i][1]);
@@ -224,16 +225,16 @@ int gf2_ctx_activate(gf2_ctx* ctx) {
     return GF2_OK;
 }
 
-int gf2_ws_reserve(gf2_ctx* ctx, size_t bytes) {
-    if (ctx->ws_bytes >= bytes) return GF2_OK;
+int gf2_ws_reserve(gf2_ctx* ctx, int slot, size_t bytes) {
+    if (ctx->ws_bytes[slot] >= bytes) return GF2_OK;
     GF2_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->ws) GF2_HIP(hipFree(ctx->ws));
-    ctx->ws = nullptr;
-    ctx->ws_bytes = 0;
-    hipError_t err = hipMalloc(&ctx->ws, bytes);
+    if (ctx->ws[slot]) GF2_HIP(hipFree(ctx->ws[slot]));
+    ctx->ws[slot] = nullptr;
+    ctx->ws_bytes[slot] = 0;
+    hipError_t err = hipMalloc(&ctx->ws[slot], bytes);
     if (err == hipErrorOutOfMemory) GF2_FAIL(GF2_E_NOMEM, "workspace of %zu bytes: out of device memory", bytes);
     GF2_HIP(err);
-    ctx->ws_bytes = bytes;
+    ctx->ws_bytes[slot] = bytes;
     return GF2_OK;
 }
 

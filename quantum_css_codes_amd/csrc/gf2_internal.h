@@ -50,29 +50,37 @@ struct gf2_ctx {
     hipEvent_t prof_ev[kProfSlots][2];
     int prof_family[kProfSlots];
     int prof_used;
-    // Monte-Carlo workspace (grown on demand)
-    void* ws;
-    size_t ws_bytes;
+    // workspaces grown on demand: slot 0 = Monte-Carlo pipeline, slot 1 = re-tiling of sample-major errors
+    void* ws[2];
+    size_t ws_bytes[2];
 };
 
 int gf2_ctx_activate(gf2_ctx* ctx);
-int gf2_ws_reserve(gf2_ctx* ctx, size_t bytes);
+int gf2_ws_reserve(gf2_ctx* ctx, int slot, size_t bytes);
 // Profiling brackets around one kernel launch of `family` (no-ops unless enabled).
 int gf2_prof_begin(gf2_ctx* ctx, int family);
 int gf2_prof_end(gf2_ctx* ctx);
 int gf2_prof_drain(gf2_ctx* ctx);
 
 // ---- prepared parity check -------------------------------------------------------------------------
-// Rows are grouped in slabs of 64 (one output word per slab); columns in groups of 4.  tables_dev holds,
-// for slab s and column group g, the 16 XOR-combinations of the slab's four column words:
-//     tables[(s * groups + g) * 16 + v]  bit i  =  XOR_{c : v bit c} H[64 s + i][4 g + c]
+// Rows are grouped in slabs of 64 (one output word per slab); columns in pairs of 128 (one 16-byte piece of
+// the tiled error layout), each pair in 32 groups of 4.  For slab s only its "active" pairs are tabulated
+// (pair_list / npairs); tables_dev holds for the t-th active pair of slab s, group j and nibble value v
+//     tables[((s * max_pairs + t) * 32 + j) * 16 + v]  bit i  =  XOR_{c : v bit c} H[64 s + i][128 q + 4 j + c]
+// with the columns of an identity block H[:, ident_off : ident_off + r] == I left out (taken from the error
+// word directly by the kernel).
 struct gf2_check {
     int64_t r, n, ld;
-    int64_t slabs;       // ceil(r / 64)
-    int64_t groups;      // ceil(n / 4), padded to a multiple of 32 (one uint4 of error bits = 32 groups)
-    uint64_t* h_dev;     // r x ld packed rows
+    int64_t slabs;        // ceil(r / 64)
+    int64_t ldt;          // words per sample in the tiled layout (even)
+    int64_t ident_off;    // -1: none
+    int64_t max_pairs;    // stride of pair_list / tables per slab
+    int small;            // n <= 64 and r <= 64: streaming kernels, rows_small
+    uint64_t* h_dev;      // r x ld packed rows
     uint64_t* tables_dev;
-    uint64_t rows_small[64];   // host copy of the rows when n <= 64 and r <= 64
+    int32_t* pair_list_dev;
+    int32_t* npairs_dev;
+    uint64_t rows_small[64];
 };
 
 static inline int64_t gf2_words(int64_t bits) { return (bits + 63) >> 6; }

@@ -49,16 +49,25 @@ __device__ static inline void sample_word(u64 seed, u64 sample, u64 w, u64 valid
     *ez = (any_err & ~has_x) | is_y;
 }
 
-// One lane per (sample, word); consecutive lanes write consecutive words of a row.
+// One lane per output word.  Sample-major: idx = i * lde + w.  Tiled: idx is the tiled word offset
+// (i>>6)*64*ldt + (w>>1)*128 + (i&63)*2 + (w&1).  Either way consecutive lanes write consecutive words.
+template <bool TILED>
 __global__ __launch_bounds__(256) void sampler_kernel(u64 seed, int64_t first_sample, int64_t count, int64_t n,
-                                                      int64_t words, int64_t lde, PauliThresholds th,
+                                                      int64_t words, int64_t lde, int64_t total, PauliThresholds th,
                                                       uint64_t* __restrict__ ex, uint64_t* __restrict__ ez) {
-    const int64_t total = count * lde;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        const int64_t i = idx / lde, w = idx - i * lde;
+        int64_t i, w;
+        if (TILED) {
+            const int64_t tile = idx / (64 * lde), rem = idx - tile * 64 * lde;
+            i = tile * 64 + ((rem & 127) >> 1);
+            w = (rem >> 7) * 2 + (rem & 1);
+        } else {
+            i = idx / lde;
+            w = idx - i * lde;
+        }
         u64 x = 0, z = 0;
-        if (w < words) {
+        if (i < count && w < words) {
             const int64_t left = n - w * 64;
             const u64 valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
             sample_word(seed, (u64)(first_sample + i), (u64)w, valid, th, &x, &z);
@@ -81,8 +90,11 @@ static int make_thresholds(double p_x, double p_y, double p_z, PauliThresholds* 
 extern "C" {
 
 int gf2_sample_errors_dev(gf2_ctx* ctx, int64_t n, uint64_t seed, int64_t first_sample, int64_t count, double p_x,
-                          double p_y, double p_z, uint64_t* ex_dev, uint64_t* ez_dev, int64_t lde) {
+                          double p_y, double p_z, uint64_t* ex_dev, uint64_t* ez_dev, int64_t lde, int layout) {
     if (!ctx) GF2_FAIL(GF2_E_ARG, "gf2_sample_errors_dev: null context");
+    if (layout != GF2_LAYOUT_SAMPLE_MAJOR && layout != GF2_LAYOUT_TILED)
+        GF2_FAIL(GF2_E_ARG, "gf2_sample_errors_dev: layout must be sample-major or tiled");
+    if (layout == GF2_LAYOUT_TILED) lde = gf2_tiled_ld(n);
     if (n < 0 || count < 0 || first_sample < 0 || lde < gf2_words(n) || lde < 1)
         GF2_FAIL(GF2_E_ARG, "gf2_sample_errors_dev: bad shape");
     PauliThresholds th;
@@ -90,11 +102,16 @@ int gf2_sample_errors_dev(gf2_ctx* ctx, int64_t n, uint64_t seed, int64_t first_
     if (count == 0) return GF2_OK;
     if (!ex_dev || !ez_dev) GF2_FAIL(GF2_E_ARG, "gf2_sample_errors_dev: null buffer");
     GF2_TRY(gf2_ctx_activate(ctx));
-    int64_t blocks = gf2_cdiv(count * lde, 256);
+    const int64_t total = layout == GF2_LAYOUT_TILED ? gf2_tiled_words(n, count) : count * lde;
+    int64_t blocks = gf2_cdiv(total, 256);
     if (blocks > 16384) blocks = 16384;
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_SAMPLER));
-    hipLaunchKernelGGL(sampler_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (u64)seed, first_sample, count,
-                       n, gf2_words(n), lde, th, ex_dev, ez_dev);
+    if (layout == GF2_LAYOUT_TILED)
+        hipLaunchKernelGGL(sampler_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (u64)seed, first_sample,
+                           count, n, gf2_words(n), lde, total, th, ex_dev, ez_dev);
+    else
+        hipLaunchKernelGGL(sampler_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (u64)seed, first_sample,
+                           count, n, gf2_words(n), lde, total, th, ex_dev, ez_dev);
     GF2_TRY(gf2_prof_end(ctx));
     GF2_HIP(hipGetLastError());
     return GF2_OK;
@@ -117,20 +134,25 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
     GF2_TRY(make_thresholds(p_x, p_y, p_z, &th));
     GF2_TRY(gf2_ctx_activate(ctx));
 
-    const int64_t lde = gf2_words(n) > 0 ? gf2_words(n) : 1;
+    const bool tiled = !c1->small || !c2->small;     // large checks read the tiled layout directly
+    if (tiled && (c1->small || c2->small))
+        GF2_FAIL(GF2_E_ARG, "gf2_mc_run: one check is small (<= 64 x 64) and the other is not; unsupported");
+    const int layout = tiled ? GF2_LAYOUT_TILED : GF2_LAYOUT_SAMPLE_MAJOR;
+    const int64_t lde = tiled ? gf2_tiled_ld(n) : (gf2_words(n) > 0 ? gf2_words(n) : 1);
     const int64_t ls1 = c1->slabs > 0 ? c1->slabs : 1, ls2 = c2->slabs > 0 ? c2->slabs : 1;
     // chunk sized to about 256 MiB of error words
     int64_t chunk = (int64_t)(256ll << 20) / (2 * lde * 8);
     if (chunk > (1ll << 22)) chunk = 1ll << 22;
     if (chunk < 4096) chunk = 4096;
     if (chunk > count) chunk = count > 0 ? count : 1;
+    chunk = gf2_cdiv(chunk, 64) * 64;
     const size_t e_bytes = (size_t)chunk * lde * 8;
     const size_t s1_bytes = (size_t)chunk * ls1 * 8, s2_bytes = (size_t)chunk * ls2 * 8;
     const size_t hz_bytes = (size_t)nbins_z * 8, hx_bytes = (size_t)nbins_x * 8;
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t total = 2 * align(e_bytes) + align(s1_bytes) + align(s2_bytes) + align(hz_bytes) + align(hx_bytes);
-    GF2_TRY(gf2_ws_reserve(ctx, total));
-    char* p = (char*)ctx->ws;
+    GF2_TRY(gf2_ws_reserve(ctx, 0, total));
+    char* p = (char*)ctx->ws[0];
     uint64_t* ex = (uint64_t*)p; p += align(e_bytes);
     uint64_t* ez = (uint64_t*)p; p += align(e_bytes);
     uint64_t* s1 = (uint64_t*)p; p += align(s1_bytes);
@@ -141,9 +163,9 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
     GF2_TRY(gf2_dev_zero(ctx, hx, hx_bytes));
     for (int64_t done = 0; done < count; done += chunk) {
         const int64_t now = count - done < chunk ? count - done : chunk;
-        GF2_TRY(gf2_sample_errors_dev(ctx, n, seed, first_sample + done, now, p_x, p_y, p_z, ex, ez, lde));
-        if (c1->r > 0) GF2_TRY(gf2_syndrome_dev(ctx, c1, ez, now, lde, GF2_LAYOUT_SAMPLE_MAJOR, s1, ls1));
-        if (c2->r > 0) GF2_TRY(gf2_syndrome_dev(ctx, c2, ex, now, lde, GF2_LAYOUT_SAMPLE_MAJOR, s2, ls2));
+        GF2_TRY(gf2_sample_errors_dev(ctx, n, seed, first_sample + done, now, p_x, p_y, p_z, ex, ez, lde, layout));
+        if (c1->r > 0) GF2_TRY(gf2_syndrome_dev(ctx, c1, ez, now, lde, layout, s1, ls1));
+        if (c2->r > 0) GF2_TRY(gf2_syndrome_dev(ctx, c2, ex, now, lde, layout, s2, ls2));
         if (c1->r == 0) GF2_TRY(gf2_dev_zero(ctx, s1, (size_t)now * ls1 * 8));
         if (c2->r == 0) GF2_TRY(gf2_dev_zero(ctx, s2, (size_t)now * ls2 * 8));
         GF2_TRY(gf2_histogram_dev(ctx, s1, now, ls1, c1->r, mode, hz, nbins_z));

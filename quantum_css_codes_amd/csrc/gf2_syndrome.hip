@@ -1,14 +1,23 @@
 // Syndrome extraction S = E . H^T over GF(2) on packed words, and syndrome histograms (gfx950).
 //
 // Replaces np.mod(np.matmul(parity_check, e), 2) of css_code.py:728 (and the commutation check of
-// css_code.py:47) for a whole batch of errors.  Three kernels:
+// css_code.py:47) for a whole batch of errors.
 //
-//   * syndrome_tables_kernel   Method-of-Four-Russians tables in LDS.  A workgroup owns one slab of 64
-//                              parity-check rows: for every group of 4 columns the 16 XOR-combinations
-//                              of the slab's column words (16 x 8 B per group, 128 KiB at n = 4096).
-//                              A lane owns a sample; each nibble of its error word selects one table
-//                              entry (ds_read_b64).  The 16 entries of a group span 32 distinct banks
-//                              and equal addresses broadcast, so the reads are conflict-free.
+//   * syndrome_tiled_kernel    Method-of-Four-Russians tables in LDS.  A workgroup owns one slab of 64
+//                              parity-check rows and a chunk of samples.  For every group of 4 columns the
+//                              slab's table holds the 16 XOR-combinations of its four column words
+//                              (16 x 8 B); a lane owns a sample and each nibble of its error word selects
+//                              one entry with a ds_read_b64.  The 16 entries of a group span 32 distinct
+//                              banks and equal addresses broadcast, so the reads are conflict-free.
+//                              Errors arrive in the tiled layout (gf2hip.h): a wavefront reads one 16-byte
+//                              piece per lane from 1 KiB of contiguous memory.
+//                              Only "active" 128-column pairs of a slab are tabulated: pairs whose columns are
+//                              all zero in the slab are skipped, and the columns of an identity block
+//                              H[:, off:off+r] = I (the reference's standard forms, css_code.py:51-61) are
+//                              taken straight from the error word instead of through the table.
+//                              Tables are staged at LDS offset 0 in chunks of at most 16 pairs (64 KiB), so a
+//                              lookup address is nibble*8 plus an instruction immediate; two workgroups share a CU.
+//   * retile_kernel            sample-major -> tiled, through LDS (coalesced both ways).
 //   * syndrome_small_kernel    n <= 64, r <= 64, sample-major: one lane per sample, rows in SGPRs,
 //                              parity by AND + popcount.  Pure streaming.
 //   * syndrome_sliced_kernel   n <= 64, r <= 64, bit-sliced: one lane per 64 samples, S[i] = XOR of the
@@ -16,33 +25,50 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "gf2_internal.h"
 
 // ---- table construction ---------------------------------------------------------------------------------
 
-// grid (slabs, ceil(groups / 64)), block 64.  Lane i of the wave holds row 64*slab+i.
-__global__ void build_tables_kernel(const uint64_t* __restrict__ h, int64_t r, int64_t ld, int64_t groups,
-                                    u64* __restrict__ tables) {
+// grid (slabs, max_pairs), block 64.  Lane i holds row 64*slab+i.  Entry layout per (slab, t):
+//   tables[((slab * max_pairs + t) * 32 + j) * 16 + v],  j = group within the pair, v = nibble value.
+__global__ void build_tables_kernel(const uint64_t* __restrict__ h, int64_t r, int64_t ld, int64_t ident_off,
+                                    const int32_t* __restrict__ pair_list, const int32_t* __restrict__ npairs,
+                                    int64_t max_pairs, u64* __restrict__ tables) {
     const int lane = threadIdx.x;
-    const int64_t slab = blockIdx.x;
+    const int64_t slab = blockIdx.x, t = blockIdx.y;
     const int64_t row = slab * 64 + lane;
-    const int64_t g0 = (int64_t)blockIdx.y * 64;
-    for (int gi = 0; gi < 64; ++gi) {
-        const int64_t g = g0 + gi;
-        if (g >= groups) break;
-        const int64_t word = g >> 4;
+    u64* out = tables + (slab * max_pairs + t) * 512;
+    if (t >= npairs[slab]) {
+        for (int i = lane; i < 512; i += 64) out[i] = 0;
+        return;
+    }
+    const int64_t q = pair_list[slab * max_pairs + t];
+    for (int half = 0; half < 2; ++half) {
+        const int64_t word = 2 * q + half;
         u64 w = 0;
         if (row < r && word < ld) w = h[row * ld + word];
-        const int shift = (int)(g & 15) * 4;
-        u64 col[4];
+        if (ident_off >= 0) {                                   // drop the identity block's columns
+            const int64_t lo = ident_off - word * 64, hi = ident_off + r - word * 64;
+            if (hi > 0 && lo < 64) {
+                u64 m = ~0ull;
+                if (lo > 0) m &= ~0ull << lo;
+                if (hi < 64) m &= ~(~0ull << hi);
+                w &= ~m;
+            }
+        }
+        for (int g = 0; g < 16; ++g) {
+            u64 col[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) col[c] = __ballot((w >> (shift + c)) & 1ull);
-        if (lane < 16) {
-            u64 acc = 0;
+            for (int c = 0; c < 4; ++c) col[c] = __ballot((w >> (4 * g + c)) & 1ull);
+            if (lane < 16) {
+                u64 acc = 0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if ((lane >> c) & 1) acc ^= col[c];
-            tables[(slab * groups + g) * 16 + lane] = acc;
+                for (int c = 0; c < 4; ++c)
+                    if ((lane >> c) & 1) acc ^= col[c];
+                out[(half * 16 + g) * 16 + lane] = acc;
+            }
         }
     }
 }
@@ -50,58 +76,167 @@ __global__ void build_tables_kernel(const uint64_t* __restrict__ h, int64_t r, i
 // ---- Four-Russians syndrome kernel ------------------------------------------------------------------------
 
 #define SYN_THREADS 1024
-#define SYN_SPT 4                                  // samples per thread
-#define SYN_BLOCK_SAMPLES (SYN_THREADS * SYN_SPT)
-#define SYN_MAX_GROUPS 1024                         // 1024 groups x 128 B = 128 KiB of LDS per column pass
+#define SYN_WAVES (SYN_THREADS / 64)
+#define SYN_TPW 4                                   // tiles (of 64 samples) per wave
+#define SYN_BLOCK_TILES (SYN_WAVES * SYN_TPW)       // 64 tiles = 4096 samples per workgroup
+#define SYN_CHUNK_PAIRS 19                          // 19 pairs x 4 KiB = 76 KiB of LDS per staging, 2 workgroups/CU
 
-// Blocks are dealt round-robin over the 8 XCDs, so blocks b and b+8 share an L2.  Give the blocks of one
-// XCD the same sample chunk and different slabs: the chunk's errors are then fetched from HBM once per
-// XCD and served from its L2 to the other slabs.
-__global__ __launch_bounds__(SYN_THREADS) void syndrome_tables_kernel(
-    const u64* __restrict__ tables, int64_t groups, int64_t slabs, const uint64_t* __restrict__ e,
-    int64_t batch, int64_t lde, int64_t e_words, uint64_t* __restrict__ s, int64_t lds_out, int64_t chunks) {
-    extern __shared__ __attribute__((aligned(16))) u64 tab[];
+typedef const __attribute__((address_space(3))) u64* lds_u64_ptr;
+
+// The kernel has no static LDS, so its dynamic LDS starts at LDS address 0 and a table entry is addressed by
+// its plain byte offset: nibble*8 in a VGPR plus an instruction immediate (at most 65535; pairs 16.. add 64 KiB
+// to the VGPR instead).
+template <int OFFSET>
+__device__ __forceinline__ u64 lds_entry(unsigned int nib8) {
+    if (OFFSET < 65536 - 8) return *(lds_u64_ptr)(uintptr_t)(nib8 + (unsigned)OFFSET);
+    return *(lds_u64_ptr)(uintptr_t)((nib8 | 0x10000u) + (unsigned)(OFFSET - 65536));
+}
+
+// (byte B of x) & mask in one VALU op (SDWA byte select).
+template <int B>
+__device__ __forceinline__ unsigned int byte_and(unsigned int x, unsigned int mask) {
+    unsigned int out;
+    if (B == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(out) : "v"(x), "v"(mask));
+    if (B == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(out) : "v"(x), "v"(mask));
+    if (B == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(out) : "v"(x), "v"(mask));
+    if (B == 3) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(out) : "v"(x), "v"(mask));
+    return out;
+}
+
+// 8 table reads for the 8 nibbles of one dword; BASE = byte offset of the dword's first group.
+template <int BASE>
+__device__ __forceinline__ u64 lookup_dword(const unsigned int d, u64 a, unsigned int mask78) {
+    const unsigned int lo = d << 3, hi = d >> 1;                // nibble*8 sits in bits 3..6 of each byte
+    a ^= lds_entry<BASE + 0 * 128>(byte_and<0>(lo, mask78));
+    a ^= lds_entry<BASE + 1 * 128>(byte_and<0>(hi, mask78));
+    a ^= lds_entry<BASE + 2 * 128>(byte_and<1>(lo, mask78));
+    a ^= lds_entry<BASE + 3 * 128>(byte_and<1>(hi, mask78));
+    a ^= lds_entry<BASE + 4 * 128>(byte_and<2>(lo, mask78));
+    a ^= lds_entry<BASE + 5 * 128>(byte_and<2>(hi, mask78));
+    a ^= lds_entry<BASE + 6 * 128>(byte_and<3>(lo, mask78));
+    a ^= lds_entry<BASE + 7 * 128>(byte_and<3>(hi, mask78));
+    return a;
+}
+
+// 32 table reads for the 32 nibbles of one 16-byte error piece; BASE = byte offset of the pair's tables.
+template <int BASE>
+__device__ __forceinline__ u64 lookup_piece(const uint4 v, u64 a, unsigned int mask78) {
+    a = lookup_dword<BASE + 0 * 1024>(v.x, a, mask78);
+    a = lookup_dword<BASE + 1 * 1024>(v.y, a, mask78);
+    a = lookup_dword<BASE + 2 * 1024>(v.z, a, mask78);
+    a = lookup_dword<BASE + 3 * 1024>(v.w, a, mask78);
+    return a;
+}
+
+// Pairs t = 0 .. np-1 of the staged chunk, fully unrolled so every table offset is an immediate.  The piece
+// of pair t+1 is requested before the 32 lookups of pair t (explicit one-deep prefetch; the scheduling barrier
+// keeps the compiler from hoisting all 19 loads and spilling).
+template <int T>
+struct PairUnroll {
+    static __device__ __forceinline__ void run(const uint4* __restrict__ tile, int lane, const int32_t* __restrict__ pairs,
+                                               int np, const uint4 cur, u64& a, unsigned int mask78) {
+        constexpr int t = SYN_CHUNK_PAIRS - T;
+        uint4 next = cur;
+        if (t + 1 < np) next = tile[(int64_t)pairs[t + 1] * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+        a = lookup_piece<t * 4096>(cur, a, mask78);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t + 1 < np) PairUnroll<T - 1>::run(tile, lane, pairs, np, next, a, mask78);
+    }
+};
+template <>
+struct PairUnroll<0> {
+    static __device__ __forceinline__ void run(const uint4*, int, const int32_t*, int, const uint4, u64&, unsigned int) {}
+};
+
+// Blocks are dealt round-robin over the 8 XCDs, so blocks b and b+8 share an L2.  The blocks of one XCD get
+// the same sample chunk and different slabs: the chunk's errors come from HBM once per XCD and are served
+// from its L2 to the other slabs.
+__global__ __launch_bounds__(SYN_THREADS, 8) void syndrome_tiled_kernel(
+    const u64* __restrict__ tables, const int32_t* __restrict__ pair_list, const int32_t* __restrict__ npairs,
+    int64_t max_pairs, int64_t slabs, int64_t r, int64_t ident_off, const uint64_t* __restrict__ e, int64_t batch,
+    int64_t ldt, uint64_t* __restrict__ s, int64_t lds_out, int64_t chunks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char tab[];
     const int64_t b = blockIdx.x;
     const int64_t xcd = b & 7, q = b >> 3;
     const int64_t slab = q % slabs;
     const int64_t chunk = (q / slabs) * 8 + xcd;
     if (chunk >= chunks) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: tile addresses stay in SGPRs
+    const int64_t tiles = (batch + 63) >> 6;
+    const int64_t tile0 = chunk * SYN_BLOCK_TILES + wave;
+    const int np_total = npairs[slab];
+    const int32_t* pairs = pair_list + slab * max_pairs;
+    unsigned int mask78 = 0x78u;
+    asm volatile("" : "+v"(mask78));                            // keep the mask in a VGPR for the SDWA operand
 
-    const int64_t first = chunk * SYN_BLOCK_SAMPLES + threadIdx.x;
-    u64 acc[SYN_SPT];
-#pragma unroll
-    for (int k = 0; k < SYN_SPT; ++k) acc[k] = 0;
+    // Rows 64*slab.. of an identity block correspond to error bits ident_off + 64*slab ..
+    const int64_t ibit = ident_off + slab * 64;
+    const int64_t iw0 = ibit >> 6;
+    const int ish = (int)(ibit & 63);
+    const int64_t irows = r - slab * 64;
+    const u64 imask = irows < 64 ? ~(~0ull << irows) : ~0ull;
 
-    for (int64_t g0 = 0; g0 < groups; g0 += SYN_MAX_GROUPS) {
-        const int64_t gn = (groups - g0 < SYN_MAX_GROUPS) ? groups - g0 : SYN_MAX_GROUPS;
-        if (g0) __syncthreads();
-        {   // stage this slab's tables for column groups g0 .. g0+gn-1 (16-byte copies, coalesced)
-            const uint4* src = reinterpret_cast<const uint4*>(tables + (slab * groups + g0) * 16);
+    int p0 = 0;
+    do {                                                        // one pass per staging of at most 19 pairs
+        const int np = np_total - p0 < SYN_CHUNK_PAIRS ? np_total - p0 : SYN_CHUNK_PAIRS;
+        if (p0) __syncthreads();
+        {   // stage the tables of pairs p0 .. p0+np-1 at LDS offset 0 (16-byte copies, coalesced)
+            const uint4* src = reinterpret_cast<const uint4*>(tables + (slab * max_pairs + p0) * 512);
             uint4* dst = reinterpret_cast<uint4*>(tab);
-            for (int64_t i = threadIdx.x; i < gn * 8; i += SYN_THREADS) dst[i] = src[i];
+            for (int i = threadIdx.x; i < np * 256; i += SYN_THREADS) dst[i] = src[i];
         }
         __syncthreads();
-        const int64_t w0 = g0 >> 4;                       // first error word of this pass
-        const int64_t wn = (gn + 15) >> 4;
-#pragma unroll
-        for (int k = 0; k < SYN_SPT; ++k) {
-            const int64_t sample = first + (int64_t)k * SYN_THREADS;
-            if (sample >= batch) continue;
-            const uint64_t* erow = e + sample * lde;
-            u64 a = acc[k];
-            for (int64_t w = 0; w < wn; ++w) {
-                const u64 v = (w0 + w < e_words) ? erow[w0 + w] : 0ull;
-                const u64* t = tab + w * 256;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) a ^= t[j * 16 + ((v >> (4 * j)) & 15ull)];
+#pragma unroll 1
+        for (int k = 0; k < SYN_TPW; ++k) {
+            const int64_t tile = tile0 + (int64_t)k * SYN_WAVES;
+            if (tile >= tiles) break;
+            const int64_t sample = tile * 64 + lane;
+            const uint64_t* tbase = e + tile * 64 * ldt;
+            u64 a = 0;
+            if (p0) {
+                if (sample < batch) a = s[sample * lds_out + slab];
+            } else if (ident_off >= 0) {
+                const uint64_t* lp = tbase + lane * 2;
+                a = lp[(iw0 >> 1) * 128 + (iw0 & 1)] >> ish;
+                if (ish && iw0 + 1 < ldt) a |= lp[((iw0 + 1) >> 1) * 128 + ((iw0 + 1) & 1)] << (64 - ish);
+                a &= imask;
             }
-            acc[k] = a;
+            if (np > 0) {
+                const uint4* tptr = reinterpret_cast<const uint4*>(tbase);
+                const uint4 first = tptr[(int64_t)pairs[p0] * 64 + lane];
+                PairUnroll<SYN_CHUNK_PAIRS>::run(tptr, lane, pairs + p0, np, first, a, mask78);
+            }
+            if (sample < batch) s[sample * lds_out + slab] = a;
         }
-    }
-#pragma unroll
-    for (int k = 0; k < SYN_SPT; ++k) {
-        const int64_t sample = first + (int64_t)k * SYN_THREADS;
-        if (sample < batch) s[sample * lds_out + slab] = acc[k];
+        p0 += SYN_CHUNK_PAIRS;
+    } while (p0 < np_total);
+}
+
+// ---- sample-major -> tiled ----------------------------------------------------------------------------------
+
+// grid (tiles), block 256.  Word w of sample b goes to (b>>6)*64*ldt + (w>>1)*128 + (b&63)*2 + (w&1).
+__global__ __launch_bounds__(256) void retile_kernel(const uint64_t* __restrict__ src, int64_t batch, int64_t lde,
+                                                     int64_t words, int64_t ldt, uint64_t* __restrict__ dst) {
+    __shared__ u64 buf[64 * 65];
+    const int64_t tile = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t w0 = 0; w0 < ldt; w0 += 64) {
+        if (w0) __syncthreads();
+        for (int sidx = wave; sidx < 64; sidx += 4) {
+            const int64_t sample = tile * 64 + sidx;
+            const int64_t w = w0 + lane;
+            buf[sidx * 65 + lane] = (sample < batch && w < words) ? src[sample * lde + w] : 0ull;
+        }
+        __syncthreads();
+        const int64_t pairs_here = (ldt - w0 < 64 ? ldt - w0 : 64) >> 1;
+        for (int64_t qi = wave; qi < pairs_here; qi += 4) {
+            ulonglong2 v;
+            v.x = buf[lane * 65 + 2 * qi];
+            v.y = buf[lane * 65 + 2 * qi + 1];
+            reinterpret_cast<ulonglong2*>(dst + tile * 64 * ldt + ((w0 >> 1) + qi) * 128)[lane] = v;
+        }
     }
 }
 
@@ -182,7 +317,42 @@ __global__ __launch_bounds__(256) void histogram_kernel(const uint64_t* __restri
 
 // ---- host side -------------------------------------------------------------------------------------------
 
+static inline int host_bit(const uint64_t* row, int64_t j) { return (int)((row[j >> 6] >> (j & 63)) & 1ull); }
+
+// Offset of an identity block H[:, off:off+r] == I, or -1.  Candidates are the set bits of row 0 whose column
+// is a unit vector; each survivor is verified in full.
+static int64_t find_identity_block(const uint64_t* h, int64_t r, int64_t n, int64_t ld) {
+    if (r == 0 || r > n) return -1;
+    for (int64_t c = 0; c + r <= n; ++c) {
+        if (!host_bit(h, c)) continue;
+        bool ok = true;
+        for (int64_t i = 0; i < r && ok; ++i)                           // diagonal set, column c clear below row 0
+            ok = host_bit(h + i * ld, c + i) && (i == 0 || !host_bit(h + i * ld, c));
+        for (int64_t i = 0; i < r && ok; ++i) {                         // row i restricted to the block == unit vector
+            const uint64_t* row = h + i * ld;
+            for (int64_t w = c >> 6; w <= (c + r - 1) >> 6 && ok; ++w) {
+                u64 m = ~0ull;
+                const int64_t lo = c - w * 64, hi = c + r - w * 64;
+                if (lo > 0) m &= ~0ull << lo;
+                if (hi < 64) m &= ~(~0ull << hi);
+                const int64_t d = c + i - w * 64;
+                const u64 want = (d >= 0 && d < 64) ? (1ull << d) : 0ull;
+                ok = (row[w] & m) == want;
+            }
+        }
+        if (ok) return c;
+    }
+    return -1;
+}
+
 extern "C" {
+
+int64_t gf2_tiled_ld(int64_t n) {
+    const int64_t w = gf2_words(n) > 0 ? gf2_words(n) : 1;
+    return (w + 1) & ~(int64_t)1;
+}
+
+int64_t gf2_tiled_words(int64_t n, int64_t batch) { return gf2_cdiv(batch > 0 ? batch : 1, 64) * 64 * gf2_tiled_ld(n); }
 
 int gf2_check_create(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, int64_t ld, gf2_check** check_out) {
     if (!ctx || !check_out) GF2_FAIL(GF2_E_ARG, "gf2_check_create: null argument");
@@ -196,24 +366,60 @@ int gf2_check_create(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, int6
     ck->n = n;
     ck->ld = ld > 0 ? ld : 1;
     ck->slabs = gf2_cdiv(r, 64);
-    ck->groups = gf2_cdiv(gf2_cdiv(n, 4), 16) * 16;         // whole error words
-    if (ck->groups == 0) ck->groups = 16;
-    if (n <= 64 && r <= 64)
+    ck->ldt = gf2_tiled_ld(n);
+    ck->ident_off = -1;
+    ck->small = n <= 64 && r <= 64;
+    if (ck->small && n > 0)
         for (int64_t i = 0; i < r; ++i) ck->rows_small[i] = h[i * ld];
     int rc = GF2_OK;
     const size_t hbytes = (size_t)(r > 0 ? r : 1) * ck->ld * 8;
-    const size_t tbytes = (size_t)(ck->slabs > 0 ? ck->slabs : 1) * ck->groups * 16 * 8;
     if ((rc = gf2_dev_alloc(ctx, hbytes, (void**)&ck->h_dev)) != GF2_OK) goto fail;
-    if ((rc = gf2_dev_alloc(ctx, tbytes, (void**)&ck->tables_dev)) != GF2_OK) goto fail;
-    if (r > 0) {
-        if (ld == ck->ld) {
-            if ((rc = gf2_h2d(ctx, ck->h_dev, h, (size_t)r * ld * 8)) != GF2_OK) goto fail;
-        } else {
-            if ((rc = gf2_dev_zero(ctx, ck->h_dev, hbytes)) != GF2_OK) goto fail;
+    if (r > 0 && n > 0 && (rc = gf2_h2d(ctx, ck->h_dev, h, (size_t)r * ld * 8)) != GF2_OK) goto fail;
+
+    if (!ck->small && r > 0 && n > 0) {
+        ck->ident_off = find_identity_block(h, r, n, ld);
+        // per-slab list of 128-column pairs with a non-zero column outside the identity block
+        const int64_t pairs_total = ck->ldt / 2;
+        std::vector<std::vector<int32_t>> lists((size_t)ck->slabs);
+        int64_t max_pairs = 1;
+        for (int64_t s = 0; s < ck->slabs; ++s) {
+            for (int64_t q = 0; q < pairs_total; ++q) {
+                u64 any = 0;
+                for (int half = 0; half < 2; ++half) {
+                    const int64_t w = 2 * q + half;
+                    if (w >= ld) continue;
+                    u64 colmask = 0;
+                    for (int64_t i = s * 64; i < r && i < s * 64 + 64; ++i) colmask |= h[i * ld + w];
+                    if (ck->ident_off >= 0) {
+                        const int64_t lo = ck->ident_off - w * 64, hi = ck->ident_off + r - w * 64;
+                        if (hi > 0 && lo < 64) {
+                            u64 m = ~0ull;
+                            if (lo > 0) m &= ~0ull << lo;
+                            if (hi < 64) m &= ~(~0ull << hi);
+                            colmask &= ~m;
+                        }
+                    }
+                    any |= colmask;
+                }
+                if (any) lists[(size_t)s].push_back((int32_t)q);
+            }
+            if ((int64_t)lists[(size_t)s].size() > max_pairs) max_pairs = (int64_t)lists[(size_t)s].size();
         }
-        dim3 grid((unsigned)ck->slabs, (unsigned)gf2_cdiv(ck->groups, 64));
-        hipLaunchKernelGGL(build_tables_kernel, grid, dim3(64), 0, ctx->stream, ck->h_dev, r, ck->ld, ck->groups,
-                           (u64*)ck->tables_dev);
+        ck->max_pairs = max_pairs;
+        std::vector<int32_t> flat((size_t)(ck->slabs * max_pairs), 0), counts((size_t)ck->slabs, 0);
+        for (int64_t s = 0; s < ck->slabs; ++s) {
+            counts[(size_t)s] = (int32_t)lists[(size_t)s].size();
+            for (size_t t = 0; t < lists[(size_t)s].size(); ++t) flat[(size_t)(s * max_pairs) + t] = lists[(size_t)s][t];
+        }
+        const size_t tbytes = (size_t)ck->slabs * max_pairs * 512 * 8;
+        if ((rc = gf2_dev_alloc(ctx, flat.size() * 4, (void**)&ck->pair_list_dev)) != GF2_OK) goto fail;
+        if ((rc = gf2_dev_alloc(ctx, counts.size() * 4, (void**)&ck->npairs_dev)) != GF2_OK) goto fail;
+        if ((rc = gf2_dev_alloc(ctx, tbytes, (void**)&ck->tables_dev)) != GF2_OK) goto fail;
+        if ((rc = gf2_h2d(ctx, ck->pair_list_dev, flat.data(), flat.size() * 4)) != GF2_OK) goto fail;
+        if ((rc = gf2_h2d(ctx, ck->npairs_dev, counts.data(), counts.size() * 4)) != GF2_OK) goto fail;
+        dim3 grid((unsigned)ck->slabs, (unsigned)max_pairs);
+        hipLaunchKernelGGL(build_tables_kernel, grid, dim3(64), 0, ctx->stream, ck->h_dev, r, ck->ld, ck->ident_off,
+                           ck->pair_list_dev, ck->npairs_dev, max_pairs, (u64*)ck->tables_dev);
         hipError_t err = hipGetLastError();
         if (err == hipSuccess) err = hipStreamSynchronize(ctx->stream);
         if (err != hipSuccess) {
@@ -227,6 +433,8 @@ int gf2_check_create(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, int6
 fail:
     if (ck->h_dev) (void)hipFree(ck->h_dev);
     if (ck->tables_dev) (void)hipFree(ck->tables_dev);
+    if (ck->pair_list_dev) (void)hipFree(ck->pair_list_dev);
+    if (ck->npairs_dev) (void)hipFree(ck->npairs_dev);
     free(ck);
     return rc;
 }
@@ -236,7 +444,47 @@ int gf2_check_destroy(gf2_ctx* ctx, gf2_check* check) {
     if (!check) return GF2_OK;
     GF2_TRY(gf2_dev_free(ctx, check->h_dev));
     GF2_TRY(gf2_dev_free(ctx, check->tables_dev));
+    GF2_TRY(gf2_dev_free(ctx, check->pair_list_dev));
+    GF2_TRY(gf2_dev_free(ctx, check->npairs_dev));
     free(check);
+    return GF2_OK;
+}
+
+int gf2_retile_dev(gf2_ctx* ctx, const uint64_t* e_dev, int64_t batch, int64_t lde, int64_t n, uint64_t* tiled_dev) {
+    if (!ctx) GF2_FAIL(GF2_E_ARG, "gf2_retile_dev: null context");
+    if (batch < 0 || n < 0 || lde < gf2_words(n) || lde < 1) GF2_FAIL(GF2_E_ARG, "gf2_retile_dev: bad shape");
+    if (batch == 0) return GF2_OK;
+    if (!e_dev || !tiled_dev) GF2_FAIL(GF2_E_ARG, "gf2_retile_dev: null buffer");
+    GF2_TRY(gf2_ctx_activate(ctx));
+    const int64_t tiles = gf2_cdiv(batch, 64);
+    if (tiles > 0x7fffffffLL) GF2_FAIL(GF2_E_ARG, "gf2_retile_dev: batch too large");
+    hipLaunchKernelGGL(retile_kernel, dim3((unsigned)tiles), dim3(256), 0, ctx->stream, e_dev, batch, lde, gf2_words(n),
+                       gf2_tiled_ld(n), tiled_dev);
+    GF2_HIP(hipGetLastError());
+    return GF2_OK;
+}
+
+static int launch_tiled(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_tiled, int64_t batch, uint64_t* s_dev,
+                        int64_t lds) {
+    const int64_t tiles = gf2_cdiv(batch, 64);
+    const int64_t chunks = gf2_cdiv(tiles, SYN_BLOCK_TILES);
+    const int64_t chunks8 = gf2_cdiv(chunks, 8) * 8;
+    const int64_t blocks = chunks8 * ck->slabs;
+    if (blocks > 0x7fffffffLL) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: batch too large for one launch");
+    const int64_t stage_pairs = ck->max_pairs < SYN_CHUNK_PAIRS ? ck->max_pairs : SYN_CHUNK_PAIRS;
+    const size_t shmem = (size_t)stage_pairs * 4096;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GF2_HIP(hipFuncSetAttribute((const void*)syndrome_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    SYN_CHUNK_PAIRS * 4096));
+        attr_set = true;
+    }
+    GF2_TRY(gf2_prof_begin(ctx, GF2_K_SYNDROME));
+    hipLaunchKernelGGL(syndrome_tiled_kernel, dim3((unsigned)blocks), dim3(SYN_THREADS), shmem, ctx->stream,
+                       (const u64*)ck->tables_dev, ck->pair_list_dev, ck->npairs_dev, ck->max_pairs, ck->slabs, ck->r,
+                       ck->ident_off, e_tiled, batch, ck->ldt, s_dev, lds, chunks);
+    GF2_TRY(gf2_prof_end(ctx));
+    GF2_HIP(hipGetLastError());
     return GF2_OK;
 }
 
@@ -247,10 +495,9 @@ int gf2_syndrome_dev(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, i
     if (batch == 0 || ck->r == 0) return GF2_OK;
     if (!e_dev || !s_dev) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: null buffer");
     GF2_TRY(gf2_ctx_activate(ctx));
-    const bool small = ck->n <= 64 && ck->r <= 64;
 
     if (layout == GF2_LAYOUT_BIT_SLICED) {
-        if (!small) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: bit-sliced layout needs n <= 64 and r <= 64");
+        if (!ck->small) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: bit-sliced layout needs n <= 64 and r <= 64");
         const int64_t words = gf2_words(batch);
         if (lde < words || lds < words) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: bit-sliced strides too small");
         SmallRows rows;
@@ -272,11 +519,16 @@ int gf2_syndrome_dev(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, i
         GF2_HIP(hipGetLastError());
         return GF2_OK;
     }
-    if (layout != GF2_LAYOUT_SAMPLE_MAJOR) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: unknown layout %d", layout);
-    if (lde < gf2_words(ck->n) || lde < 1) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: lde too small");
     if (lds < ck->slabs) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: lds too small");
 
-    if (small) {
+    if (layout == GF2_LAYOUT_TILED) {
+        if (ck->small) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: the tiled layout is for n > 64 or r > 64");
+        return launch_tiled(ctx, ck, e_dev, batch, s_dev, lds);
+    }
+    if (layout != GF2_LAYOUT_SAMPLE_MAJOR) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: unknown layout %d", layout);
+    if (lde < gf2_words(ck->n) || lde < 1) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: lde too small");
+
+    if (ck->small) {
         SmallRows rows;
         memcpy(rows.row, ck->rows_small, sizeof(rows.row));
         int64_t blocks = gf2_cdiv(batch, 256);
@@ -288,26 +540,11 @@ int gf2_syndrome_dev(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, i
         GF2_HIP(hipGetLastError());
         return GF2_OK;
     }
-
-    const int64_t chunks = gf2_cdiv(batch, SYN_BLOCK_SAMPLES);
-    const int64_t chunks8 = gf2_cdiv(chunks, 8) * 8;
-    const int64_t blocks = chunks8 * ck->slabs;
-    if (blocks > 0x7fffffffLL) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: batch too large for one launch");
-    const int64_t pass_groups = ck->groups < SYN_MAX_GROUPS ? ck->groups : SYN_MAX_GROUPS;
-    const size_t shmem = (size_t)pass_groups * 16 * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        GF2_HIP(hipFuncSetAttribute((const void*)syndrome_tables_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    SYN_MAX_GROUPS * 16 * 8));
-        attr_set = true;
-    }
-    GF2_TRY(gf2_prof_begin(ctx, GF2_K_SYNDROME));
-    hipLaunchKernelGGL(syndrome_tables_kernel, dim3((unsigned)blocks), dim3(SYN_THREADS), shmem, ctx->stream,
-                       (const u64*)ck->tables_dev, ck->groups, ck->slabs, e_dev, batch, lde, gf2_words(ck->n), s_dev,
-                       lds, chunks);
-    GF2_TRY(gf2_prof_end(ctx));
-    GF2_HIP(hipGetLastError());
-    return GF2_OK;
+    // sample-major input for the table kernel: one streaming pass into the tiled layout first
+    const size_t tbytes = (size_t)gf2_tiled_words(ck->n, batch) * 8;
+    GF2_TRY(gf2_ws_reserve(ctx, 1, tbytes));
+    GF2_TRY(gf2_retile_dev(ctx, e_dev, batch, lde, ck->n, (uint64_t*)ctx->ws[1]));
+    return launch_tiled(ctx, ck, (const uint64_t*)ctx->ws[1], batch, s_dev, lds);
 }
 
 int gf2_syndrome_batch(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, int64_t ldh, const uint64_t* e,
@@ -316,21 +553,24 @@ int gf2_syndrome_batch(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, in
     if (batch < 0 || r < 0 || n < 0) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: negative size");
     if (batch == 0 || r == 0) return GF2_OK;
     if (!e || !s_out) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: null buffer");
-    int64_t e_rows, s_rows;
+    int64_t e_words, s_rows;
     if (layout == GF2_LAYOUT_BIT_SLICED) {
-        e_rows = n;
+        e_words = n * lde;
         s_rows = r;
-    } else {
-        e_rows = batch;
+    } else if (layout == GF2_LAYOUT_TILED) {
+        e_words = gf2_tiled_words(n, batch);
         s_rows = batch;
-        if (lds < gf2_cdiv(r, 64)) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: lds too small");
+    } else {
+        e_words = batch * lde;
+        s_rows = batch;
     }
+    if (layout != GF2_LAYOUT_BIT_SLICED && lds < gf2_cdiv(r, 64)) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: lds too small");
     gf2_check* ck = nullptr;
     uint64_t *e_dev = nullptr, *s_dev = nullptr;
     int rc = gf2_check_create(ctx, h, r, n, ldh, &ck);
-    if (rc == GF2_OK) rc = gf2_dev_alloc(ctx, (size_t)e_rows * lde * 8, (void**)&e_dev);
+    if (rc == GF2_OK) rc = gf2_dev_alloc(ctx, (size_t)e_words * 8, (void**)&e_dev);
     if (rc == GF2_OK) rc = gf2_dev_alloc(ctx, (size_t)s_rows * lds * 8, (void**)&s_dev);
-    if (rc == GF2_OK) rc = gf2_h2d(ctx, e_dev, e, (size_t)e_rows * lde * 8);
+    if (rc == GF2_OK) rc = gf2_h2d(ctx, e_dev, e, (size_t)e_words * 8);
     if (rc == GF2_OK) rc = gf2_dev_zero(ctx, s_dev, (size_t)s_rows * lds * 8);
     if (rc == GF2_OK) rc = gf2_syndrome_dev(ctx, ck, e_dev, batch, lde, layout, s_dev, lds);
     if (rc == GF2_OK) rc = gf2_d2h(ctx, s_out, s_dev, (size_t)s_rows * lds * 8);

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def header_functions():
     text = open(os.path.join(ROOT, "include", "gf2hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    decls = re.findall(r"\b(?:int|const char\*)\s+(gf2_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S)
+    decls = re.findall(r"\b(?:int64_t|int|const char\*)\s+(gf2_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S)
     return {name: [a.strip() for a in args.split(",")] if args.strip() != "void" else [] for name, args in decls}
 
 

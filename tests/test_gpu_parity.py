@@ -361,3 +361,45 @@ def test_monte_carlo_n4096_weight_histograms(ctx):
     wz, wx = c_oracle.mc(h1, 2048, h2, 2047, 4096, 0xC55C0DE, 10**6, count, 0.01 / 3, 0.01 / 3, 0.01 / 3, 1)
     assert np.array_equal(hz, wz) and np.array_equal(hx, wx)
     assert int(hz.sum()) == count and int(hx.sum()) == count
+
+
+# ---- tiled device layout -----------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [(70, 1), (130, 64), (200, 65), (4096, 300), (4100, 130)])
+def test_retile_and_tiled_sampler(shape, ctx):
+    n, batch = shape
+    rng = np.random.default_rng(n + batch)
+    lde = _native.words_for(n)
+    e = _native.pack_rows(rng.integers(0, 2, (batch, n)))
+    src = ctx.alloc(e.nbytes).upload(e)
+    words = _native.tiled_words(n, batch)
+    dst = ctx.alloc(words * 8).zero()
+    ctx.retile_dev(src, batch, lde, n, dst)
+    got = dst.download((words,), "<u8")
+    assert np.array_equal(got, _native.tile_rows(e, n))
+    assert np.array_equal(_native.untile_rows(got, n, batch)[:, :lde], e)
+    # the sampler writes the same samples in either layout
+    ex_t, ez_t = ctx.alloc(words * 8), ctx.alloc(words * 8)
+    ctx.sample_errors_dev(n, 5, 77, batch, 0.05, 0.02, 0.03, ex_t, ez_t, 0, _native.LAYOUT_TILED)
+    want_x, want_z = c_oracle.sample_errors(n, 5, 77, batch, 0.05, 0.02, 0.03)
+    assert np.array_equal(ex_t.download((words,), "<u8"), _native.tile_rows(want_x, n))
+    assert np.array_equal(ez_t.download((words,), "<u8"), _native.tile_rows(want_z, n))
+
+
+@pytest.mark.parametrize("case", [(100, 300, 0, 500), (100, 300, 100, 130), (64, 200, 17, 64), (130, 4096, 64, 200),
+                                  (2047, 4096, 2048, 300), (1000, 2600, None, 100), (70, 9000, 128, 50)])
+def test_syndrome_identity_block_and_sparse_slabs(case, ctx):
+    # standard forms [.. I ..] (css_code.py:51-61) take the identity columns from the error word; slabs with
+    # all-zero column pairs skip them
+    r, n, ioff, batch = case
+    rng = np.random.default_rng(r + n)
+    hm = rng.integers(0, 2, (r, n))
+    if ioff is not None:
+        hm[:, ioff:ioff + r] = np.identity(r, dtype=int)
+    else:
+        hm[:, 512:1900] = 0                                  # zero column pairs in every slab
+        hm[64:128, :] = 0                                    # an all-zero slab
+    h = _native.pack_rows(hm)
+    e = _native.pack_rows(rng.integers(0, 2, (batch, n)))
+    got = ctx.syndrome_batch(h, r, n, e, batch)
+    assert np.array_equal(got, c_oracle.syndrome_batch(h, r, n, e, batch))
