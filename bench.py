@@ -88,6 +88,10 @@ def main():
     ap.add_argument("--batch-log2", type=int, default=20, help="samples per GPU per step (2^k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extras", action="store_true", help="also time RREF and the sampler-inclusive pipeline")
+    ap.add_argument("--algo", choices=("sparse", "dense"), default="sparse",
+                    help="sparse: one wavefront per sample XORs the check's column for each set error bit, weight "
+                         "histogram fused (work ~ error weight; the Monte-Carlo path at p=0.01).  dense: Four-Russians "
+                         "table kernel on tiled errors + histogram kernel (data-independent)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -110,21 +114,48 @@ def main():
     chk1, chk2 = ctx.check_create(h1, R1, N_QUBITS), ctx.check_create(h2, R2, N_QUBITS)
 
     batch = 1 << args.batch_log2
-    lde, ls1, ls2 = _native.tiled_ld(N_QUBITS), _native.words_for(R1), _native.words_for(R2)
-    tiled = _native.LAYOUT_TILED          # device-native error layout (include/gf2hip.h), written by the sampler
-    ex, ez = ctx.alloc(_native.tiled_words(N_QUBITS, batch) * 8), ctx.alloc(_native.tiled_words(N_QUBITS, batch) * 8)
-    s1, s2 = ctx.alloc(batch * ls1 * 8), ctx.alloc(batch * ls2 * 8)
+    ls1, ls2 = _native.words_for(R1), _native.words_for(R2)
     hz, hx = ctx.alloc((R1 + 1) * 8), ctx.alloc((R2 + 1) * 8)
     # this rank's shard of the global sample stream (sample i is a function of (seed, i) only)
     first = rank * batch
-    ctx.sample_errors_dev(N_QUBITS, SEED, first, batch, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, ex, ez, lde, tiled)
-    ctx.sync()
+    if args.algo == "sparse":
+        # sample-major packed errors resident in HBM; histogram-only output (no syndromes written)
+        lde = _native.words_for(N_QUBITS)
+        ex, ez = ctx.alloc(batch * lde * 8), ctx.alloc(batch * lde * 8)
+        s1 = s2 = None
+        ctx.sample_errors_dev(N_QUBITS, SEED, first, batch, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, ex, ez, lde)
+        kernel_name = "syndrome_sparse_kernel"
+        alg_bytes_per_sample = N_QUBITS / 8.0                       # SURVEY.md 8d read-only variant, per component
 
-    def step():
-        ctx.syndrome_dev(chk1, ez, batch, lde, s1, ls1, tiled)
-        ctx.syndrome_dev(chk2, ex, batch, lde, s2, ls2, tiled)
-        ctx.histogram_dev(s1, batch, ls1, R1, _native.HIST_WEIGHT, hz, R1 + 1)
-        ctx.histogram_dev(s2, batch, ls2, R2, _native.HIST_WEIGHT, hx, R2 + 1)
+        def step():
+            ctx.syndrome_sparse_dev(chk1, ez, batch, lde, None, 0, hz, R1 + 1)
+            ctx.syndrome_sparse_dev(chk2, ex, batch, lde, None, 0, hx, R2 + 1)
+
+        def prefix_syndromes(count):
+            a, b = ctx.alloc(count * ls1 * 8).zero(), ctx.alloc(count * ls2 * 8).zero()
+            ctx.syndrome_sparse_dev(chk1, ez, count, lde, a, ls1)
+            ctx.syndrome_sparse_dev(chk2, ex, count, lde, b, ls2)
+            return a.download((count, ls1), "<u8"), b.download((count, ls2), "<u8")
+    else:
+        lde = _native.tiled_ld(N_QUBITS)
+        tiled = _native.LAYOUT_TILED      # device-native error layout (include/gf2hip.h), written by the sampler
+        ex, ez = ctx.alloc(_native.tiled_words(N_QUBITS, batch) * 8), ctx.alloc(_native.tiled_words(N_QUBITS, batch) * 8)
+        s1, s2 = ctx.alloc(batch * ls1 * 8), ctx.alloc(batch * ls2 * 8)
+        ctx.sample_errors_dev(N_QUBITS, SEED, first, batch, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, ex, ez, lde, tiled)
+        kernel_name = "syndrome_tiled_kernel"
+        alg_bytes_per_sample = N_QUBITS / 8.0 + (R1 + R2) / 2.0 / 8.0   # packed error read + packed syndrome written
+
+        def step():
+            # tiled errors in, slab-major syndromes out (word s of sample b at s*batch + b)
+            ctx.syndrome_dev(chk1, ez, batch, lde, s1, batch, tiled)
+            ctx.syndrome_dev(chk2, ex, batch, lde, s2, batch, tiled)
+            ctx.histogram_dev(s1, batch, batch, R1, _native.HIST_WEIGHT, hz, R1 + 1, tiled)
+            ctx.histogram_dev(s2, batch, batch, R2, _native.HIST_WEIGHT, hx, R2 + 1, tiled)
+
+        def prefix_syndromes(count):
+            return (np.ascontiguousarray(s1.download((ls1, batch), "<u8")[:, :count].T),
+                    np.ascontiguousarray(s2.download((ls2, batch), "<u8")[:, :count].T))
+    ctx.sync()
 
     # ---- correctness of what is about to be timed: a prefix of the batch against the oracle ----------------
     hz.zero(), hx.zero()
@@ -134,8 +165,7 @@ def main():
         from oracle import c_oracle
         want_z, want_x = c_oracle.mc(h1, R1, h2, R2, N_QUBITS, SEED, first, 512, P_TOTAL / 3, P_TOTAL / 3,
                                      P_TOTAL / 3, 1)
-        got_s1 = s1.download((512, ls1), "<u8")
-        got_s2 = s2.download((512, ls2), "<u8")
+        got_s1, got_s2 = prefix_syndromes(512)
         assert np.array_equal(c_oracle.histogram(got_s1, 512, R1, 1, R1 + 1), want_z), "H1.e_z differs from the oracle"
         assert np.array_equal(c_oracle.histogram(got_s2, 512, R2, 1, R2 + 1), want_x), "H2.e_x differs from the oracle"
     single = hz.download((R1 + 1,), np.uint64)
@@ -184,13 +214,13 @@ def main():
     out = None
     if rank == 0:
         # dominant kernel: one launch handles `batch` samples of one Pauli component
-        alg_bytes = batch * (N_QUBITS / 8.0 + (R1 + R2) / 2.0 / 8.0)
+        alg_bytes = batch * alg_bytes_per_sample
         mean_launch_s = syn_ms / 1e3 / max(1, syn_launches)
         achieved = alg_bytes / mean_launch_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("syndrome_tiled_kernel_bytes_per_launch")
+            traffic = json.load(open(tpath)).get(kernel_name + "_bytes_per_launch")
         out = {
             "metric": "syndromes/sec (n=4096 CSS)", "value": value, "unit": "syndromes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -198,9 +228,9 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[4]: n=4096 CSS Monte-Carlo, random dual code (H1 2048x4096, H2 2047x4096, "
                                    "standard form), depolarising p=0.01, errors resident in HBM",
-                       "samples_per_gpu_per_step": batch, "global_samples_per_step": batch * world,
+                       "algo": args.algo, "samples_per_gpu_per_step": batch, "global_samples_per_step": batch * world,
                        "parallelism": "sample-range shards, 1 histogram all-reduce"},
-            "roofline": {"bound": "hbm", "kernel": "syndrome_tiled_kernel", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_launch_s * 1e3,
                          "launches": syn_launches},

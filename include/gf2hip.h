@@ -47,7 +47,9 @@ extern "C" {
                                           (b>>6)*64*ldt + (w>>1)*128 + (b&63)*2 + (w&1)
                                       so the 64 lanes of a wavefront read one 16-byte piece each from 1 KiB of
                                       contiguous memory.  The buffer holds ceil(B/64) whole tiles
-                                      (gf2_tiled_words).  S stays sample-major. */
+                                      (gf2_tiled_words).  Syndromes of tiled errors are SLAB-MAJOR: word s
+                                      (rows 64s..64s+63) of sample b at s*lds + b with lds >= B, so a wavefront
+                                      stores 512 contiguous bytes. */
 
 #define GF2_HIST_FULL    0     /* bins indexed by vec_to_int(syndrome) (bin_matrix.py:36-43), 2^r bins  */
 #define GF2_HIST_WEIGHT  1     /* bins indexed by the syndrome's Hamming weight, r+1 bins               */
@@ -159,14 +161,25 @@ int gf2_syndrome_batch(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, in
  * Sample-major: e_dev is batch x lde, s_dev is batch x lds (lds >= ceil(r/64)).  For n > 64 the errors are
  *               first re-tiled into context workspace (one extra streaming pass); keep resident data in
  *               GF2_LAYOUT_TILED to avoid it.
- * Tiled:        e_dev as described at GF2_LAYOUT_TILED (lde ignored); s_dev is batch x lds.
+ * Tiled:        e_dev as described at GF2_LAYOUT_TILED (lde ignored); s_dev is slab-major: ceil(r/64) rows
+ *               of lds >= batch words.
  * Bit-sliced:   e_dev is n x lde with lde >= ceil(batch/64); s_dev is r x lds, lds >= ceil(batch/64). */
 int gf2_syndrome_dev(gf2_ctx* ctx, const gf2_check* check, const uint64_t* e_dev, int64_t batch, int64_t lde,
                      int layout, uint64_t* s_dev, int64_t lds);
 
-/* Histogram of sample-major packed syndromes (device), accumulated into hist_dev (uint64 bins).
- * mode GF2_HIST_FULL needs r <= 24 and nbins == 2^r; GF2_HIST_WEIGHT needs nbins == r+1. */
-int gf2_histogram_dev(gf2_ctx* ctx, const uint64_t* s_dev, int64_t batch, int64_t lds, int64_t r,
+/* Sparse-error path: work proportional to the weight of each error (one wavefront per sample XORs the
+ * transposed check's column for every set bit).  Sample-major errors (batch x lde).  Produces the sample-major
+ * syndromes (s_dev, batch x lds; may be null) and/or accumulates the syndrome-weight histogram (hist_dev with
+ * r+1 uint64 bins; may be null) without materialising the syndromes.  Identical results to gf2_syndrome_dev;
+ * faster when errors are sparse (DESIGN.md gives the crossover).  Fails for small checks (n, r <= 64) and r > 8192. */
+int gf2_syndrome_sparse_dev(gf2_ctx* ctx, const gf2_check* check, const uint64_t* e_dev, int64_t batch, int64_t lde,
+                            uint64_t* s_dev, int64_t lds, uint64_t* hist_dev, int64_t nbins);
+
+/* Histogram of packed syndromes (device), accumulated into hist_dev (uint64 bins).  layout
+ * GF2_LAYOUT_SAMPLE_MAJOR: s_dev is batch x lds; GF2_LAYOUT_TILED: slab-major as written by gf2_syndrome_dev for
+ * tiled errors (lds >= batch).  mode GF2_HIST_FULL needs r <= 24 and nbins == 2^r; GF2_HIST_WEIGHT needs
+ * nbins == r+1. */
+int gf2_histogram_dev(gf2_ctx* ctx, const uint64_t* s_dev, int64_t batch, int64_t lds, int layout, int64_t r,
                       int mode, uint64_t* hist_dev, int64_t nbins);
 
 /* ---- Monte-Carlo --------------------------------------------------------------------------------

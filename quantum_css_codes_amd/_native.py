@@ -69,7 +69,8 @@ SIGNATURES = {
     "gf2_check_destroy": [_p, _p],
     "gf2_syndrome_batch": [_p, _p, _c_i64, _c_i64, _c_i64, _p, _c_i64, _c_i64, ctypes.c_int, _p, _c_i64],
     "gf2_syndrome_dev": [_p, _p, _p, _c_i64, _c_i64, ctypes.c_int, _p, _c_i64],
-    "gf2_histogram_dev": [_p, _p, _c_i64, _c_i64, _c_i64, ctypes.c_int, _p, _c_i64],
+    "gf2_syndrome_sparse_dev": [_p, _p, _p, _c_i64, _c_i64, _p, _c_i64, _p, _c_i64],
+    "gf2_histogram_dev": [_p, _p, _c_i64, _c_i64, ctypes.c_int, _c_i64, ctypes.c_int, _p, _c_i64],
     "gf2_sample_errors_dev": [_p, _c_i64, _c_u64, _c_i64, _c_i64, ctypes.c_double, ctypes.c_double,
                               ctypes.c_double, _p, _p, _c_i64, ctypes.c_int],
     "gf2_tiled_ld": [_c_i64],
@@ -366,8 +367,14 @@ class Context(object):
     def syndrome_dev(self, chk, e_buf, batch, lde, s_buf, lds, layout=LAYOUT_SAMPLE_MAJOR):
         check(lib().gf2_syndrome_dev(self.handle, chk.handle, e_buf.ptr, batch, lde, layout, s_buf.ptr, lds))
 
-    def histogram_dev(self, s_buf, batch, lds, r, mode, hist_buf, nbins):
-        check(lib().gf2_histogram_dev(self.handle, s_buf.ptr, batch, lds, r, mode, hist_buf.ptr, nbins))
+    def syndrome_sparse_dev(self, chk, e_buf, batch, lde, s_buf=None, lds=0, hist_buf=None, nbins=0):
+        """Sparse-error kernel: sample-major errors; writes syndromes and/or accumulates the weight histogram."""
+        check(lib().gf2_syndrome_sparse_dev(self.handle, chk.handle, e_buf.ptr, batch, lde,
+                                            s_buf.ptr if s_buf is not None else None, lds,
+                                            hist_buf.ptr if hist_buf is not None else None, nbins))
+
+    def histogram_dev(self, s_buf, batch, lds, r, mode, hist_buf, nbins, layout=LAYOUT_SAMPLE_MAJOR):
+        check(lib().gf2_histogram_dev(self.handle, s_buf.ptr, batch, lds, layout, r, mode, hist_buf.ptr, nbins))
 
     def sample_errors_dev(self, n, seed, first, count, p_x, p_y, p_z, ex_buf, ez_buf, lde,
                           layout=LAYOUT_SAMPLE_MAJOR):

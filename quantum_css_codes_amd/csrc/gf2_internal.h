@@ -80,8 +80,14 @@ struct gf2_check {
     uint64_t* tables_dev;
     int32_t* pair_list_dev;
     int32_t* npairs_dev;
+    // transposed check for the sparse-error kernel: (n + 1) columns of 64 * ht_k dwords (column n is zero, the
+    // identity block's columns are zero); null when unsupported (small check, r > 8192)
+    uint32_t* ht_dev;
+    int ht_k;
     uint64_t rows_small[64];
 };
+
+int gf2_build_columns(gf2_ctx* ctx, gf2_check* ck);
 
 static inline int64_t gf2_words(int64_t bits) { return (bits + 63) >> 6; }
 static inline int64_t gf2_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -5,6 +5,7 @@
 // in oracle/cpu_ref.py (plain evaluation) and oracle/gf2_oracle.c; this file is the lazy evaluation of
 // the same definition.  Sample i is a pure function of (seed, i), so any sharding of the index range over
 // GPUs gives the same histograms.
+#include <stdlib.h>
 #include <string.h>
 
 #include "gf2_internal.h"
@@ -134,12 +135,40 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
     GF2_TRY(make_thresholds(p_x, p_y, p_z, &th));
     GF2_TRY(gf2_ctx_activate(ctx));
 
+    // Sparse-error pipeline: when few bits are set per error the column kernel wins: sampler writes
+    // sample-major errors, the sparse kernel accumulates the weight histograms directly, no syndromes stored.
+    const double dens = (p_x + p_y > p_z + p_y ? p_x + p_y : p_z + p_y) * (double)n;
+    if (mode == GF2_HIST_WEIGHT && c1->ht_dev && c2->ht_dev && dens <= 160.0 && getenv("GF2_MC_DENSE") == nullptr) {
+        const int64_t lde_s = gf2_words(n);
+        int64_t chunk_s = (int64_t)(256ll << 20) / (2 * lde_s * 8);
+        if (chunk_s > count) chunk_s = count > 0 ? count : 1;
+        auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t eb = (size_t)chunk_s * lde_s * 8, hzb = (size_t)nbins_z * 8, hxb = (size_t)nbins_x * 8;
+        GF2_TRY(gf2_ws_reserve(ctx, 0, 2 * al(eb) + al(hzb) + al(hxb)));
+        char* q = (char*)ctx->ws[0];
+        uint64_t* sx = (uint64_t*)q; q += al(eb);
+        uint64_t* sz = (uint64_t*)q; q += al(eb);
+        uint64_t* dz = (uint64_t*)q; q += al(hzb);
+        uint64_t* dx = (uint64_t*)q;
+        GF2_TRY(gf2_dev_zero(ctx, dz, hzb));
+        GF2_TRY(gf2_dev_zero(ctx, dx, hxb));
+        for (int64_t done = 0; done < count; done += chunk_s) {
+            const int64_t now = count - done < chunk_s ? count - done : chunk_s;
+            GF2_TRY(gf2_sample_errors_dev(ctx, n, seed, first_sample + done, now, p_x, p_y, p_z, sx, sz, lde_s,
+                                          GF2_LAYOUT_SAMPLE_MAJOR));
+            GF2_TRY(gf2_syndrome_sparse_dev(ctx, c1, sz, now, lde_s, nullptr, 0, dz, nbins_z));
+            GF2_TRY(gf2_syndrome_sparse_dev(ctx, c2, sx, now, lde_s, nullptr, 0, dx, nbins_x));
+        }
+        GF2_TRY(gf2_d2h(ctx, hist_z, dz, hzb));
+        GF2_TRY(gf2_d2h(ctx, hist_x, dx, hxb));
+        return GF2_OK;
+    }
     const bool tiled = !c1->small || !c2->small;     // large checks read the tiled layout directly
     if (tiled && (c1->small || c2->small))
         GF2_FAIL(GF2_E_ARG, "gf2_mc_run: one check is small (<= 64 x 64) and the other is not; unsupported");
     const int layout = tiled ? GF2_LAYOUT_TILED : GF2_LAYOUT_SAMPLE_MAJOR;
     const int64_t lde = tiled ? gf2_tiled_ld(n) : (gf2_words(n) > 0 ? gf2_words(n) : 1);
-    const int64_t ls1 = c1->slabs > 0 ? c1->slabs : 1, ls2 = c2->slabs > 0 ? c2->slabs : 1;
+    const int64_t sl1 = c1->slabs > 0 ? c1->slabs : 1, sl2 = c2->slabs > 0 ? c2->slabs : 1;
     // chunk sized to about 256 MiB of error words
     int64_t chunk = (int64_t)(256ll << 20) / (2 * lde * 8);
     if (chunk > (1ll << 22)) chunk = 1ll << 22;
@@ -147,7 +176,9 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
     if (chunk > count) chunk = count > 0 ? count : 1;
     chunk = gf2_cdiv(chunk, 64) * 64;
     const size_t e_bytes = (size_t)chunk * lde * 8;
-    const size_t s1_bytes = (size_t)chunk * ls1 * 8, s2_bytes = (size_t)chunk * ls2 * 8;
+    const size_t s1_bytes = (size_t)chunk * sl1 * 8, s2_bytes = (size_t)chunk * sl2 * 8;
+    // sample-major: chunk rows of `slabs` words; tiled: `slabs` rows of `chunk` words (slab-major)
+    const int64_t ls1 = tiled ? chunk : sl1, ls2 = tiled ? chunk : sl2;
     const size_t hz_bytes = (size_t)nbins_z * 8, hx_bytes = (size_t)nbins_x * 8;
     auto align = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t total = 2 * align(e_bytes) + align(s1_bytes) + align(s2_bytes) + align(hz_bytes) + align(hx_bytes);
@@ -166,10 +197,10 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
         GF2_TRY(gf2_sample_errors_dev(ctx, n, seed, first_sample + done, now, p_x, p_y, p_z, ex, ez, lde, layout));
         if (c1->r > 0) GF2_TRY(gf2_syndrome_dev(ctx, c1, ez, now, lde, layout, s1, ls1));
         if (c2->r > 0) GF2_TRY(gf2_syndrome_dev(ctx, c2, ex, now, lde, layout, s2, ls2));
-        if (c1->r == 0) GF2_TRY(gf2_dev_zero(ctx, s1, (size_t)now * ls1 * 8));
-        if (c2->r == 0) GF2_TRY(gf2_dev_zero(ctx, s2, (size_t)now * ls2 * 8));
-        GF2_TRY(gf2_histogram_dev(ctx, s1, now, ls1, c1->r, mode, hz, nbins_z));
-        GF2_TRY(gf2_histogram_dev(ctx, s2, now, ls2, c2->r, mode, hx, nbins_x));
+        if (c1->r == 0) GF2_TRY(gf2_dev_zero(ctx, s1, s1_bytes));
+        if (c2->r == 0) GF2_TRY(gf2_dev_zero(ctx, s2, s2_bytes));
+        GF2_TRY(gf2_histogram_dev(ctx, s1, now, ls1, layout, c1->r, mode, hz, nbins_z));
+        GF2_TRY(gf2_histogram_dev(ctx, s2, now, ls2, layout, c2->r, mode, hx, nbins_x));
     }
     GF2_TRY(gf2_d2h(ctx, hist_z, hz, hz_bytes));
     GF2_TRY(gf2_d2h(ctx, hist_x, hx, hx_bytes));

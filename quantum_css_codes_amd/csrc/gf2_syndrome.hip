@@ -155,7 +155,7 @@ struct PairUnroll<0> {
 __global__ __launch_bounds__(SYN_THREADS, 8) void syndrome_tiled_kernel(
     const u64* __restrict__ tables, const int32_t* __restrict__ pair_list, const int32_t* __restrict__ npairs,
     int64_t max_pairs, int64_t slabs, int64_t r, int64_t ident_off, const uint64_t* __restrict__ e, int64_t batch,
-    int64_t ldt, uint64_t* __restrict__ s, int64_t lds_out, int64_t chunks) {
+    int64_t ldt, uint64_t* __restrict__ s, int64_t sstride, int64_t chunks) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tab[];
     const int64_t b = blockIdx.x;
     const int64_t xcd = b & 7, q = b >> 3;
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(SYN_THREADS, 8) void syndrome_tiled_kernel(
             const uint64_t* tbase = e + tile * 64 * ldt;
             u64 a = 0;
             if (p0) {
-                if (sample < batch) a = s[sample * lds_out + slab];
+                if (sample < batch) a = s[slab * sstride + sample];
             } else if (ident_off >= 0) {
                 const uint64_t* lp = tbase + lane * 2;
                 a = lp[(iw0 >> 1) * 128 + (iw0 & 1)] >> ish;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(SYN_THREADS, 8) void syndrome_tiled_kernel(
                 const uint4 first = tptr[(int64_t)pairs[p0] * 64 + lane];
                 PairUnroll<SYN_CHUNK_PAIRS>::run(tptr, lane, pairs + p0, np, first, a, mask78);
             }
-            if (sample < batch) s[sample * lds_out + slab] = a;
+            if (sample < batch) s[slab * sstride + sample] = a;      // slab-major: 512 B per wavefront store
         }
         p0 += SYN_CHUNK_PAIRS;
     } while (p0 < np_total);
@@ -236,6 +236,28 @@ __global__ __launch_bounds__(256) void retile_kernel(const uint64_t* __restrict_
             v.x = buf[lane * 65 + 2 * qi];
             v.y = buf[lane * 65 + 2 * qi + 1];
             reinterpret_cast<ulonglong2*>(dst + tile * 64 * ldt + ((w0 >> 1) + qi) * 128)[lane] = v;
+        }
+    }
+}
+
+// Slab-major syndromes (word s of sample b at in[s * in_stride + b]) -> sample-major (out[b * lds_out + s]).
+// grid (ceil(batch / 64)), block 256; through LDS so that both sides are coalesced.
+__global__ __launch_bounds__(256) void slab_to_sample_kernel(const uint64_t* __restrict__ in, int64_t in_stride,
+                                                             int64_t batch, int64_t slabs, uint64_t* __restrict__ out,
+                                                             int64_t lds_out) {
+    __shared__ u64 buf[64 * 65];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b0 = (int64_t)blockIdx.x * 64;
+    for (int64_t s0 = 0; s0 < slabs; s0 += 64) {
+        if (s0) __syncthreads();
+        for (int si = wave; si < 64; si += 4) {
+            const int64_t slab = s0 + si, sample = b0 + lane;
+            buf[si * 65 + lane] = (slab < slabs && sample < batch) ? in[slab * in_stride + sample] : 0ull;
+        }
+        __syncthreads();
+        for (int bi = wave; bi < 64; bi += 4) {
+            const int64_t sample = b0 + bi, slab = s0 + lane;
+            if (sample < batch && slab < slabs) out[sample * lds_out + slab] = buf[lane * 65 + bi];
         }
     }
 }
@@ -284,8 +306,10 @@ __global__ __launch_bounds__(256) void syndrome_sliced_kernel(SmallRows rows, in
 
 // mode 0: key = big-endian integer of the r syndrome bits (row 0 most significant, bin_matrix.py:36-43);
 // mode 1: key = Hamming weight.  Bins privatised in LDS when they fit, one global atomic per bin and block.
+// slab_major: word w of sample i at s[w * lds_in + i] (lane-coalesced), else at s[i * lds_in + w].
 __global__ __launch_bounds__(256) void histogram_kernel(const uint64_t* __restrict__ s, int64_t batch, int64_t lds_in,
-                                                        int r, int mode, u64* __restrict__ hist, int64_t nbins) {
+                                                        int r, int mode, int slab_major, u64* __restrict__ hist,
+                                                        int64_t nbins) {
     __shared__ unsigned int bins[HIST_LDS_BINS];
     const bool priv = nbins <= HIST_LDS_BINS;
     if (priv) {
@@ -295,13 +319,14 @@ __global__ __launch_bounds__(256) void histogram_kernel(const uint64_t* __restri
     const int words = (r + 63) >> 6;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < batch; i += stride) {
-        const uint64_t* row = s + i * lds_in;
+        const uint64_t* row = slab_major ? s + i : s + i * lds_in;
+        const int64_t step = slab_major ? lds_in : 1;
         u64 key;
         if (mode == GF2_HIST_FULL) {
             key = r ? (__brevll(row[0]) >> (64 - r)) : 0ull;
         } else {
             key = 0;
-            for (int w = 0; w < words; ++w) key += __popcll(row[w]);
+            for (int w = 0; w < words; ++w) key += __popcll(row[w * step]);
         }
         if (priv)
             atomicAdd(&bins[key], 1u);
@@ -428,9 +453,11 @@ int gf2_check_create(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, int6
             goto fail;
         }
     }
+    if ((rc = gf2_build_columns(ctx, ck)) != GF2_OK) goto fail;
     *check_out = ck;
     return GF2_OK;
 fail:
+    if (ck->ht_dev) (void)hipFree(ck->ht_dev);
     if (ck->h_dev) (void)hipFree(ck->h_dev);
     if (ck->tables_dev) (void)hipFree(ck->tables_dev);
     if (ck->pair_list_dev) (void)hipFree(ck->pair_list_dev);
@@ -446,6 +473,7 @@ int gf2_check_destroy(gf2_ctx* ctx, gf2_check* check) {
     GF2_TRY(gf2_dev_free(ctx, check->tables_dev));
     GF2_TRY(gf2_dev_free(ctx, check->pair_list_dev));
     GF2_TRY(gf2_dev_free(ctx, check->npairs_dev));
+    GF2_TRY(gf2_dev_free(ctx, check->ht_dev));
     free(check);
     return GF2_OK;
 }
@@ -464,8 +492,9 @@ int gf2_retile_dev(gf2_ctx* ctx, const uint64_t* e_dev, int64_t batch, int64_t l
     return GF2_OK;
 }
 
+// Writes slab-major syndromes: word s of sample b at s_dev[s * sstride + b].
 static int launch_tiled(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_tiled, int64_t batch, uint64_t* s_dev,
-                        int64_t lds) {
+                        int64_t sstride) {
     const int64_t tiles = gf2_cdiv(batch, 64);
     const int64_t chunks = gf2_cdiv(tiles, SYN_BLOCK_TILES);
     const int64_t chunks8 = gf2_cdiv(chunks, 8) * 8;
@@ -482,7 +511,7 @@ static int launch_tiled(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_til
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_SYNDROME));
     hipLaunchKernelGGL(syndrome_tiled_kernel, dim3((unsigned)blocks), dim3(SYN_THREADS), shmem, ctx->stream,
                        (const u64*)ck->tables_dev, ck->pair_list_dev, ck->npairs_dev, ck->max_pairs, ck->slabs, ck->r,
-                       ck->ident_off, e_tiled, batch, ck->ldt, s_dev, lds, chunks);
+                       ck->ident_off, e_tiled, batch, ck->ldt, s_dev, sstride, chunks);
     GF2_TRY(gf2_prof_end(ctx));
     GF2_HIP(hipGetLastError());
     return GF2_OK;
@@ -519,13 +548,13 @@ int gf2_syndrome_dev(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, i
         GF2_HIP(hipGetLastError());
         return GF2_OK;
     }
-    if (lds < ck->slabs) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: lds too small");
-
     if (layout == GF2_LAYOUT_TILED) {
         if (ck->small) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: the tiled layout is for n > 64 or r > 64");
+        if (lds < batch) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: slab-major output needs lds >= batch");
         return launch_tiled(ctx, ck, e_dev, batch, s_dev, lds);
     }
     if (layout != GF2_LAYOUT_SAMPLE_MAJOR) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: unknown layout %d", layout);
+    if (lds < ck->slabs) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: lds too small");
     if (lde < gf2_words(ck->n) || lde < 1) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: lde too small");
 
     if (ck->small) {
@@ -540,11 +569,19 @@ int gf2_syndrome_dev(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, i
         GF2_HIP(hipGetLastError());
         return GF2_OK;
     }
-    // sample-major input for the table kernel: one streaming pass into the tiled layout first
-    const size_t tbytes = (size_t)gf2_tiled_words(ck->n, batch) * 8;
-    GF2_TRY(gf2_ws_reserve(ctx, 1, tbytes));
-    GF2_TRY(gf2_retile_dev(ctx, e_dev, batch, lde, ck->n, (uint64_t*)ctx->ws[1]));
-    return launch_tiled(ctx, ck, (const uint64_t*)ctx->ws[1], batch, s_dev, lds);
+    // sample-major in and out around the table kernel: one streaming pass into the tiled layout first, and the
+    // slab-major result transposed back at the end
+    const size_t tbytes = ((size_t)gf2_tiled_words(ck->n, batch) * 8 + 255) & ~(size_t)255;
+    const int64_t sstride = gf2_cdiv(batch, 64) * 64;
+    GF2_TRY(gf2_ws_reserve(ctx, 1, tbytes + (size_t)ck->slabs * sstride * 8));
+    uint64_t* tiled = (uint64_t*)ctx->ws[1];
+    uint64_t* slabbed = (uint64_t*)((char*)ctx->ws[1] + tbytes);
+    GF2_TRY(gf2_retile_dev(ctx, e_dev, batch, lde, ck->n, tiled));
+    GF2_TRY(launch_tiled(ctx, ck, tiled, batch, slabbed, sstride));
+    hipLaunchKernelGGL(slab_to_sample_kernel, dim3((unsigned)gf2_cdiv(batch, 64)), dim3(256), 0, ctx->stream, slabbed,
+                       sstride, batch, ck->slabs, s_dev, lds);
+    GF2_HIP(hipGetLastError());
+    return GF2_OK;
 }
 
 int gf2_syndrome_batch(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, int64_t ldh, const uint64_t* e,
@@ -559,12 +596,12 @@ int gf2_syndrome_batch(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, in
         s_rows = r;
     } else if (layout == GF2_LAYOUT_TILED) {
         e_words = gf2_tiled_words(n, batch);
-        s_rows = batch;
+        s_rows = gf2_cdiv(r, 64);                          // slab-major output: ceil(r/64) rows of lds >= batch words
     } else {
         e_words = batch * lde;
         s_rows = batch;
     }
-    if (layout != GF2_LAYOUT_BIT_SLICED && lds < gf2_cdiv(r, 64)) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: lds too small");
+    if (layout == GF2_LAYOUT_SAMPLE_MAJOR && lds < gf2_cdiv(r, 64)) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: lds too small");
     gf2_check* ck = nullptr;
     uint64_t *e_dev = nullptr, *s_dev = nullptr;
     int rc = gf2_check_create(ctx, h, r, n, ldh, &ck);
@@ -587,7 +624,7 @@ int gf2_matmul_abt(gf2_ctx* ctx, const uint64_t* a, int64_t ra, int64_t lda, con
     return gf2_syndrome_batch(ctx, b, rb, n, ldb, a, ra, lda, GF2_LAYOUT_SAMPLE_MAJOR, c, ldc);
 }
 
-int gf2_histogram_dev(gf2_ctx* ctx, const uint64_t* s_dev, int64_t batch, int64_t lds, int64_t r, int mode,
+int gf2_histogram_dev(gf2_ctx* ctx, const uint64_t* s_dev, int64_t batch, int64_t lds, int layout, int64_t r, int mode,
                       uint64_t* hist_dev, int64_t nbins) {
     if (!ctx || !hist_dev) GF2_FAIL(GF2_E_ARG, "gf2_histogram_dev: null argument");
     if (batch < 0 || r < 0) GF2_FAIL(GF2_E_ARG, "gf2_histogram_dev: negative size");
@@ -600,14 +637,18 @@ int gf2_histogram_dev(gf2_ctx* ctx, const uint64_t* s_dev, int64_t batch, int64_
         GF2_FAIL(GF2_E_ARG, "gf2_histogram_dev: unknown mode %d", mode);
     }
     if (batch == 0) return GF2_OK;
-    if (!s_dev || lds < gf2_cdiv(r, 64) || lds < 1) GF2_FAIL(GF2_E_ARG, "gf2_histogram_dev: bad syndrome buffer");
+    if (layout != GF2_LAYOUT_SAMPLE_MAJOR && layout != GF2_LAYOUT_TILED)
+        GF2_FAIL(GF2_E_ARG, "gf2_histogram_dev: layout must be sample-major or tiled (slab-major)");
+    const bool slab_major = layout == GF2_LAYOUT_TILED;
+    if (!s_dev || lds < 1 || (slab_major ? lds < batch : lds < gf2_cdiv(r, 64)))
+        GF2_FAIL(GF2_E_ARG, "gf2_histogram_dev: bad syndrome buffer");
     GF2_TRY(gf2_ctx_activate(ctx));
     int64_t blocks = gf2_cdiv(batch, 256 * 8);
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_HIST));
     hipLaunchKernelGGL(histogram_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, s_dev, batch, lds, (int)r,
-                       mode, (u64*)hist_dev, nbins);
+                       mode, slab_major ? 1 : 0, (u64*)hist_dev, nbins);
     GF2_TRY(gf2_prof_end(ctx));
     GF2_HIP(hipGetLastError());
     return GF2_OK;

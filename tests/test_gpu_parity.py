@@ -403,3 +403,76 @@ def test_syndrome_identity_block_and_sparse_slabs(case, ctx):
     e = _native.pack_rows(rng.integers(0, 2, (batch, n)))
     got = ctx.syndrome_batch(h, r, n, e, batch)
     assert np.array_equal(got, c_oracle.syndrome_batch(h, r, n, e, batch))
+
+
+def test_tiled_device_path_slab_major_output(ctx):
+    # device-native layouts end to end: tiled errors in, slab-major syndromes out, histogram of the slab-major buffer
+    r, n, batch = 200, 1000, 777
+    rng = np.random.default_rng(8)
+    h = _native.pack_rows(rng.integers(0, 2, (r, n)))
+    e = _native.pack_rows(rng.integers(0, 2, (batch, n)))
+    chk = ctx.check_create(h, r, n)
+    e_buf = ctx.alloc(_native.tiled_words(n, batch) * 8).upload(_native.tile_rows(e, n))
+    stride = 832                                           # >= batch
+    s_buf = ctx.alloc(chk.slabs * stride * 8).zero()
+    ctx.syndrome_dev(chk, e_buf, batch, 0, s_buf, stride, _native.LAYOUT_TILED)
+    got = s_buf.download((chk.slabs, stride), "<u8")[:, :batch].T
+    want = c_oracle.syndrome_batch(h, r, n, e, batch)
+    assert np.array_equal(got, want)
+    hist = ctx.alloc((r + 1) * 8).zero()
+    ctx.histogram_dev(s_buf, batch, stride, r, _native.HIST_WEIGHT, hist, r + 1, _native.LAYOUT_TILED)
+    assert np.array_equal(hist.download((r + 1,), np.uint64), c_oracle.histogram(want, batch, r, 1, r + 1))
+
+
+# ---- sparse-error kernel -------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("case", [(100, 300, None, 200, 0.02), (100, 300, 100, 130, 0.05), (64, 200, 17, 64, 0.5),
+                                  (2048, 4096, 0, 300, 0.007), (2047, 4096, 2048, 300, 0.007), (2047, 4096, 2048, 40, 0.5),
+                                  (3000, 5000, None, 70, 0.01), (3000, 9000, 6000, 70, 0.01), (70, 9000, 128, 50, 0.2),
+                                  (5000, 6000, 1000, 20, 0.02), (65, 65, 0, 10, 0.3)])
+def test_syndrome_sparse_kernel(case, ctx):
+    r, n, ioff, batch, density = case
+    rng = np.random.default_rng(r * 3 + n)
+    hm = rng.integers(0, 2, (r, n))
+    if ioff is not None:
+        hm[:, ioff:ioff + r] = np.identity(r, dtype=int)
+    em = (rng.random((batch, n)) < density).astype(np.uint8)
+    em[0] = 0                                               # an error-free sample
+    if batch > 3:
+        em[3] = 1                                           # and a full-weight one (exceeds the list capacity)
+    h, e = _native.pack_rows(hm), _native.pack_rows(em)
+    chk = ctx.check_create(h, r, n)
+    lde, lds = e.shape[1], _native.words_for(r)
+    e_buf = ctx.alloc(e.nbytes).upload(e)
+    s_buf = ctx.alloc(batch * lds * 8).zero()
+    hist = ctx.alloc((r + 1) * 8).zero()
+    ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, s_buf, lds, hist, r + 1)
+    want = c_oracle.syndrome_batch(h, r, n, e, batch)
+    assert np.array_equal(s_buf.download((batch, lds), "<u8"), want)
+    assert np.array_equal(hist.download((r + 1,), np.uint64), c_oracle.histogram(want, batch, r, 1, r + 1))
+    # histogram-only and syndromes-only variants
+    hist2 = ctx.alloc((r + 1) * 8).zero()
+    ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist2, r + 1)
+    assert np.array_equal(hist2.download((r + 1,), np.uint64), c_oracle.histogram(want, batch, r, 1, r + 1))
+    s2 = ctx.alloc(batch * lds * 8).zero()
+    ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, s2, lds)
+    assert np.array_equal(s2.download((batch, lds), "<u8"), want)
+    # the dense table kernel gives the same answer
+    assert np.array_equal(ctx.syndrome_batch(h, r, n, e, batch), want)
+
+
+def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, monkeypatch):
+    rng = np.random.default_rng(11)
+    hm1, hm2 = rng.integers(0, 2, (2048, 4096)), rng.integers(0, 2, (2047, 4096))
+    hm1[:, :2048] = np.identity(2048, dtype=int)
+    hm2[:, 2048:4095] = np.identity(2047, dtype=int)
+    h1, h2 = _native.pack_rows(hm1), _native.pack_rows(hm2)
+    c1, c2 = ctx.check_create(h1, 2048, 4096), ctx.check_create(h2, 2047, 4096)
+    args = (0xABC, 5 * 10**6, 20000, 0.004, 0.003, 0.002, _native.HIST_WEIGHT)
+    sparse = ctx.mc_run(c1, c2, *args)
+    monkeypatch.setenv("GF2_MC_DENSE", "1")
+    dense = ctx.mc_run(c1, c2, *args)
+    monkeypatch.delenv("GF2_MC_DENSE")
+    want = c_oracle.mc(h1, 2048, h2, 2047, 4096, 0xABC, 5 * 10**6, 20000, 0.004, 0.003, 0.002, 1)
+    for got in (sparse, dense):
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
