@@ -14,8 +14,11 @@
 //   5. the syndrome row is stored (256 B contiguous, sample-major) and/or its weight goes to the histogram.
 //
 // Work is proportional to the error weight; the transposed check (1 MiB at 2048 x 4096, half of it never touched
-// in standard form) stays in L2.  The dense Four-Russians kernel (gf2_syndrome.hip) remains the data-independent
-// path; DESIGN.md gives the crossover.
+// in standard form) stays in L2.  The kernel is bound by L2 gather bandwidth: about 14 random 256-byte column
+// reads per sample and component at the benchmark's p = 0.01 (measured ~50-70 GB/s per CU, the chip's ceiling for
+// L2-resident row gathers).  A 16-lanes-per-sample variant (4 samples per wavefront, 1 KiB per wavefront load,
+// 2.3 instead of 5 instructions per column) measured the same time, which is how the bound was identified.
+// The dense Four-Russians kernel (gf2_syndrome.hip) remains the data-independent path; DESIGN.md gives the crossover.
 #include "gf2_internal.h"
 
 #define SPARSE_LIST_CAP 512
