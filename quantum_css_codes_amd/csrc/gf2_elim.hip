@@ -144,6 +144,210 @@ __global__ __launch_bounds__(ELIM_THREADS) void eliminate_kernel(u64* __restrict
     }
 }
 
+// ---- blocked RREF -----------------------------------------------------------------------------------------------------
+//
+// The reduced row echelon form is unique, so the elimination may pick any pivot row and move rows whenever it
+// likes.  rref_blocked_kernel keeps every row in place and works in panels of 64 columns:
+//
+//   1. panel analysis (registers; one barrier per column).  A lane owns rows tid, tid+1024, .. and holds their
+//      panel words.  For each column: every wavefront proposes an unused row with the bit set (__ballot), the first
+//      proposal wins, and every lane clears the bit in its rows with the winner's panel word, recording the
+//      operation in the row's 64-bit coefficient c_i.  With P_p the pivot row's value when chosen,
+//      P = V . OLDPIV (V unit lower triangular, from the coefficients the pivot rows had when chosen) and
+//      new_i = old_i ^ (c_i . V) . OLDPIV, where OLDPIV are the chosen rows as they stand at the start of the panel.
+//   2. d_i = c_i . V through byte tables of V.
+//   3. trailing update A[i] ^= d_i . OLDPIV, Method of Four Russians: per chunk of W words the 8 x 256 XOR
+//      combinations of the pivot rows go to LDS and every row does 8 lookups.  Chunks left of the panel are skipped
+//      while no pivot-free column has been seen there (they cannot change).
+//   4. after the last panel the pivot rows are gathered into rows 0..rank-1 (gather_rows_kernel) and the rest zeroed.
+//
+// One workgroup per matrix; a batch of matrices is one workgroup each.
+#define RB_THREADS 1024
+
+template <int RPT, int W>
+__global__ __launch_bounds__(RB_THREADS) void rref_blocked_kernel(u64* __restrict__ base, int64_t m, int64_t n, int64_t ld,
+                                                                 int64_t* __restrict__ pivots_base, int64_t cap,
+                                                                 int64_t* __restrict__ rank_base,
+                                                                 int32_t* __restrict__ pivrow_base) {
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    const int64_t m_pad = (m + 1) & ~(int64_t)1;
+    u64* T = smem;                                 // 2048 * W   (also VT: 8 x 256 words, before T is built)
+    u64* dl = T + 2048 * W;                        // m_pad
+    u64* snap = dl + m_pad;                        // 64 * W
+    u64* V = snap + 64 * W;                        // 64
+    u64* csel = V + 64;                            // 64
+    u64* slot_w = csel + 64;                       // 2 x 16
+    int* slot_row = reinterpret_cast<int*>(slot_w + 32);      // 2 x 16 ints
+    int* prow_l = slot_row + 32;                   // 64 ints
+
+    u64* a = base + (int64_t)blockIdx.x * m * ld;
+    int64_t* pivots = pivots_base ? pivots_base + (int64_t)blockIdx.x * cap : nullptr;
+    int32_t* pivrow = pivrow_base + (int64_t)blockIdx.x * cap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    unsigned int usedmask = 0;                     // bit k: owned row tid + 1024 k is a pivot row already
+    int64_t rank = 0;
+    int64_t first_free = n;                        // first column seen without a pivot
+
+    for (int64_t pw = 0; pw < ld && rank < m && pw * 64 < n; ++pw) {
+        // ---- 1. panel analysis ---------------------------------------------------------------------------------------
+        u64 w[RPT], c[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int64_t row = tid + (int64_t)RB_THREADS * k;
+            w[k] = row < m ? a[row * ld + pw] : 0ull;
+            c[k] = 0;
+        }
+        int t = 0;
+        for (int b = 0; b < 64; ++b) {
+            const int64_t col = pw * 64 + b;
+            if (col >= n || rank + t >= m) break;
+            const int par = b & 1;
+            int kc = -1;
+            u64 wc = 0;
+#pragma unroll
+            for (int k = RPT - 1; k >= 0; --k)
+                if (!((usedmask >> k) & 1u) && ((w[k] >> b) & 1ull)) {
+                    kc = k;
+                    wc = w[k];
+                }
+            const u64 bal = __ballot(kc >= 0);
+            if (bal) {
+                if (lane == __ffsll((long long)bal) - 1) {
+                    slot_row[par * 16 + wave] = tid + RB_THREADS * kc;
+                    slot_w[par * 16 + wave] = wc;
+                }
+            } else if (lane == 0) {
+                slot_row[par * 16 + wave] = -1;
+            }
+            __syncthreads();
+            const u64 valid = __ballot(slot_row[par * 16 + (lane & 15)] >= 0) & 0xFFFFull;
+            if (!valid) {
+                if (col < first_free) first_free = col;
+                continue;
+            }
+            const int wsel = __ffsll((long long)valid) - 1;
+            const int prow = slot_row[par * 16 + wsel];
+            const u64 pword = slot_w[par * 16 + wsel];
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int row = tid + RB_THREADS * k;
+                if (row == prow) {
+                    csel[t] = c[k];
+                    usedmask |= 1u << k;
+                } else if ((w[k] >> b) & 1ull) {
+                    w[k] ^= pword;
+                    c[k] |= 1ull << t;
+                }
+            }
+            if (tid == 0) {
+                prow_l[t] = prow;
+                pivrow[rank + t] = prow;
+                if (pivots) pivots[rank + t] = col;
+            }
+            t += 1;
+        }
+        __syncthreads();
+        if (t == 0) continue;
+
+        // ---- 2. V (forward substitution in one wavefront), its byte tables, d_i = c_i . V ---------------------------------
+        if (wave == 0) {
+            u64 v = lane < t ? 1ull << lane : 0ull;
+            const u64 cs = lane < t ? csel[lane] : 0ull;
+            for (int q = 0; q < t; ++q) {
+                const u64 vq = ((u64)(unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), q) << 32) |
+                               (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, q);
+                if ((cs >> q) & 1ull) v ^= vq;
+            }
+            V[lane] = v;
+        }
+        __syncthreads();
+        for (int idx = tid; idx < 2048; idx += RB_THREADS) {
+            const int g = idx >> 8, vv = idx & 255;
+            u64 x = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if ((vv >> k) & 1) x ^= V[8 * g + k];
+            T[idx] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int64_t row = tid + (int64_t)RB_THREADS * k;
+            if (row < m) {
+                u64 d = 0;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) d ^= T[g * 256 + (int)((c[k] >> (8 * g)) & 255ull)];
+                dl[row] = d;
+            }
+        }
+        __syncthreads();
+
+        // ---- 3. trailing update, chunk by chunk --------------------------------------------------------------------------
+        const int groups = (t + 7) >> 3;
+        const int64_t untouched = first_free < pw * 64 ? first_free : pw * 64;   // columns below this cannot change
+        for (int64_t cw0 = 0; cw0 < ld; cw0 += W) {
+            if ((cw0 + W) * 64 <= untouched) continue;
+            const int wc_n = ld - cw0 < W ? (int)(ld - cw0) : W;
+            for (int idx = tid; idx < t * W; idx += RB_THREADS) {
+                const int q = idx / W, wd = idx % W;
+                snap[idx] = wd < wc_n ? a[(int64_t)prow_l[q] * ld + cw0 + wd] : 0ull;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < groups * 256 * W; idx += RB_THREADS) {
+                const int wd = idx % W, vv = (idx / W) & 255, g = idx / (256 * W);
+                u64 x = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (((vv >> k) & 1) && 8 * g + k < t) x ^= snap[(8 * g + k) * W + wd];
+                T[idx] = x;
+            }
+            __syncthreads();
+            {   // all loads first (independent, in flight together), then the lookups, then the stores
+                constexpr int ITEMS = RPT * W;
+                u64 x[ITEMS], dd[ITEMS];
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it) {
+                    const int64_t idx = tid + (int64_t)RB_THREADS * it;
+                    const int64_t row = idx / W;
+                    const int wd = (int)(idx % W);
+                    const bool live = row < m && wd < wc_n;
+                    dd[it] = live ? dl[row] : 0ull;
+                    x[it] = dd[it] ? a[row * ld + cw0 + wd] : 0ull;
+                }
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it) {
+                    const int wd = (int)((tid + (int64_t)RB_THREADS * it) % W);
+                    for (int g = 0; g < groups; ++g)
+                        x[it] ^= T[(g * 256 + (int)((dd[it] >> (8 * g)) & 255ull)) * W + wd];
+                }
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it) {
+                    const int64_t idx = tid + (int64_t)RB_THREADS * it;
+                    if (dd[it]) a[(idx / W) * ld + cw0 + (idx % W)] = x[it];
+                }
+            }
+            __syncthreads();
+        }
+        rank += t;
+    }
+    if (tid == 0) rank_base[blockIdx.x] = rank;
+}
+
+// out row k (k < rank) = in row pivrow[k]; rows >= rank are zero.  grid (m, batch), block 64.
+__global__ void gather_rows_kernel(const u64* __restrict__ in, u64* __restrict__ out, const int32_t* __restrict__ pivrow,
+                                   const int64_t* __restrict__ rank, int64_t m, int64_t ld, int64_t cap) {
+    const int64_t k = blockIdx.x, mat = blockIdx.y;
+    const u64* src = in + mat * m * ld;
+    u64* dst = out + mat * m * ld + k * ld;
+    if (k < rank[mat]) {
+        const u64* row = src + (int64_t)pivrow[mat * cap + k] * ld;
+        for (int64_t wd = threadIdx.x; wd < ld; wd += 64) dst[wd] = row[wd];
+    } else {
+        for (int64_t wd = threadIdx.x; wd < ld; wd += 64) dst[wd] = 0ull;
+    }
+}
+
 __global__ void swap_columns_kernel(u64* __restrict__ a, int64_t m, int64_t ld, int64_t i, int64_t j) {
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= m) return;
@@ -217,6 +421,48 @@ static int launch_eliminate(gf2_ctx* ctx, int mode, u64* a_dev, int64_t batch, i
 
 extern "C" {
 
+// Blocked path: m <= 8192.  Needs workspace for the row gather (a copy of the batch) and the pivot-row lists.
+static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld,
+                               int64_t* pivots_dev, int64_t cap, int64_t* rank_dev) {
+    const int rpt = (int)gf2_cdiv(m, RB_THREADS);
+    const int64_t m_pad = (m + 1) & ~(int64_t)1;
+    const size_t abytes = (size_t)batch * m * ld * 8;
+    const size_t pbytes = ((size_t)batch * cap * 4 + 255) & ~(size_t)255;
+    GF2_TRY(gf2_ws_reserve(ctx, 1, pbytes + abytes));
+    int32_t* pivrow = (int32_t*)ctx->ws[1];
+    u64* tmp = (u64*)((char*)ctx->ws[1] + pbytes);
+    const int w = m <= 2048 ? 8 : 4;
+    const size_t shmem = ((size_t)2048 * w + m_pad + 64 * w + 64 + 64 + 32) * 8 + (32 + 64) * 4;
+    GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
+#define GF2_RB_LAUNCH(RPT, WW)                                                                                           \
+    do {                                                                                                                 \
+        static bool attr_done = false;                                                                                   \
+        if (!attr_done) {                                                                                                \
+            GF2_HIP(hipFuncSetAttribute((const void*)rref_blocked_kernel<RPT, WW>,                                        \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
+            attr_done = true;                                                                                            \
+        }                                                                                                                \
+        hipLaunchKernelGGL((rref_blocked_kernel<RPT, WW>), dim3((unsigned)batch), dim3(RB_THREADS), shmem, ctx->stream,   \
+                           a_dev, m, n, ld, pivots_dev, cap, rank_dev, pivrow);                                           \
+    } while (0)
+    if (rpt <= 1)
+        GF2_RB_LAUNCH(1, 8);
+    else if (rpt <= 2)
+        GF2_RB_LAUNCH(2, 8);
+    else if (rpt <= 4)
+        GF2_RB_LAUNCH(4, 4);
+    else
+        GF2_RB_LAUNCH(8, 4);
+#undef GF2_RB_LAUNCH
+    GF2_HIP(hipGetLastError());
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)m, (unsigned)batch), dim3(64), 0, ctx->stream, (const u64*)a_dev,
+                       tmp, pivrow, rank_dev, m, ld, cap);
+    GF2_HIP(hipGetLastError());
+    GF2_HIP(hipMemcpyAsync(a_dev, tmp, abytes, hipMemcpyDeviceToDevice, ctx->stream));
+    GF2_TRY(gf2_prof_end(ctx));
+    return GF2_OK;
+}
+
 int gf2_rref_batch_dev(gf2_ctx* ctx, uint64_t* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld,
                        int64_t* pivots_dev, int64_t* rank_dev) {
     if (!ctx) GF2_FAIL(GF2_E_ARG, "gf2_rref_batch_dev: null context");
@@ -227,6 +473,8 @@ int gf2_rref_batch_dev(gf2_ctx* ctx, uint64_t* a_dev, int64_t batch, int64_t m, 
     if (m == 0 || n == 0) return gf2_dev_zero(ctx, rank_dev, (size_t)batch * 8);
     if (!a_dev) GF2_FAIL(GF2_E_ARG, "gf2_rref_batch_dev: null matrix");
     const int64_t cap = m < n ? m : n;
+    if (m <= 8 * RB_THREADS && batch <= 65535 && m <= 0x7fffffff && getenv("GF2_RREF_SEQUENTIAL") == nullptr)
+        return launch_rref_blocked(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
     return launch_eliminate(ctx, ELIM_RREF, (u64*)a_dev, batch, m, n, ld, 0, pivots_dev, cap, rank_dev, nullptr, nullptr,
                             nullptr);
 }
