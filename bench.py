@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """
-bench.py -- syndromes/s of the n = 4096 CSS Monte-Carlo hot path on N x MI355X (BASELINE.json metric).
+bench.py -- syndromes/s of the n = 4096 CSS Monte-Carlo hot path on N x MI355X (BASELINE.json metric), with the
+GF(2) RREF GB/s beside it.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -12,17 +13,25 @@ CSSCode exactly as css_code.py:51-61 does -- and depolarising errors (p = 0.01) 
 sampler, pre-materialised in HBM before the timed region (2^20 samples per GPU, 1 GiB of packed errors:
 larger than the 256 MiB Infinity Cache, so every step streams from HBM).
 
-One step = one pass of the hot path over that batch: s_z = H1 . e_z and s_x = H2 . e_x for every sample
-(two launches of the dominant kernel) plus the two weight histograms.  Per-GPU work is fixed as N grows
-("weak"); ranks never exchange data on the path; the histograms are summed once with one all-reduce
-(RCCL) inside the timed region.  value = N * K * batch / max-over-ranks time.
+One step = one pass of the hot path over that batch: s_z = H1 . e_z and s_x = H2 . e_x for every sample and
+the two syndrome-weight histograms.  Two implementations, same results bit for bit:
+  --algo sparse (default)  one wavefront per sample XORs the transposed check's column for every set error
+                           bit; the weight histogram is fused, no syndromes are written.  Work ~ error weight
+                           (about 27 set bits per component at p = 0.01).
+  --algo dense             Four-Russians table kernel on tiled errors, slab-major syndromes written, then the
+                           histogram kernel.  Data-independent.
+Per-GPU work is fixed as N grows ("weak"); ranks never exchange data on the path; the histograms are summed
+once with one all-reduce (RCCL) inside the timed region.  value = N * K * batch / max-over-ranks time.
 
 The JSON line also carries
-  roofline      dominant kernel (syndrome_tiled_kernel) against the HBM roofline: algorithmic bytes per
-                launch = batch * (n/8 read + r/8 written) (1536 B per sample over the two
-                launches) / its mean launch time, measured live with HIP events on the kernel's stream.
+  roofline      the dominant kernel against the HBM roofline: algorithmic bytes per launch (SURVEY.md 8d:
+                n/8 read [+ r/8 written when syndromes are stored] per sample and component) / its mean launch
+                time, measured live with HIP events on the kernel's stream; traffic = PMC HBM bytes per launch
+                from the committed rocprofv3 passes (profiles/traffic.json).
   cpu_baseline  the reference's NumPy path (oracle/cpu_ref.py restatement of css_code.py:728) timed on this
                 host, 1 core, on a bounded sample of the same workload.
+  secondary     (rank 0, N = 1) the other syndrome kernel on the same workload, and RREF GB/s
+                (2 * m * ceil(n/64) * 8 bytes / time) for one and for 256 resident 2048 x 4096 matrices.
 """
 import argparse
 import json
@@ -43,7 +52,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def build_code():
-    """Config 4 of BASELINE.json on the GPU: returns packed standard-form H1, H2 (uint64 words)."""
+    """Config 4 of BASELINE.json on the GPU: returns the code and packed standard-form H1, H2 (uint64 words)."""
     from quantum_css_codes_amd import _native, bin_matrix
     from quantum_css_codes_amd.css_code import CSSCode
     seed = 4096
@@ -58,16 +67,16 @@ def build_code():
     return code, _native.pack_rows(code.parity_check_c1), _native.pack_rows(code.parity_check_c2)
 
 
-def cpu_baseline(code, seconds_target=12.0):
+def cpu_baseline(code, seconds_target=20.0, sample=2048):
     """Reference-style CPU path: np.mod(np.matmul(H, e), 2) per error vector on dense int64 arrays
     (css_code.py:728), both Pauli components, single thread.  Bounded sample, extrapolated rate."""
     from oracle import cpu_ref, c_oracle
     h1 = np.array(code.parity_check_c1, dtype='int')
     h2 = np.array(code.parity_check_c2, dtype='int')
-    ex, ez = c_oracle.sample_errors(N_QUBITS, SEED, 0, 512, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3)
+    ex, ez = c_oracle.sample_errors(N_QUBITS, SEED, 0, sample, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3)
     ex, ez = c_oracle.unpack_rows(ex, N_QUBITS), c_oracle.unpack_rows(ez, N_QUBITS)
     done, t0 = 0, time.perf_counter()
-    while done < 512:
+    while done < sample:
         cpu_ref.syndrome_product(h1, ez[done])
         cpu_ref.syndrome_product(h2, ex[done])
         done += 1
@@ -80,182 +89,115 @@ def cpu_baseline(code, seconds_target=12.0):
                       % (done, dt, os.cpu_count())}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-log2", type=int, default=20, help="samples per GPU per step (2^k)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extras", action="store_true", help="also time RREF and the sampler-inclusive pipeline")
-    ap.add_argument("--algo", choices=("sparse", "dense"), default="sparse",
-                    help="sparse: one wavefront per sample XORs the check's column for each set error bit, weight "
-                         "histogram fused (work ~ error weight; the Monte-Carlo path at p=0.01).  dense: Four-Russians "
-                         "table kernel on tiled errors + histogram kernel (data-independent)")
-    args = ap.parse_args()
+class Path(object):
+    """Resident buffers and the step function of one implementation of the hot path."""
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
-    os.environ.setdefault("GF2_DEVICE", str(local_rank))
+    def __init__(self, ctx, algo, chk1, chk2, batch, first):
+        from quantum_css_codes_amd import _native
+        self.ctx, self.algo, self.batch = ctx, algo, batch
+        self.ls1, self.ls2 = _native.words_for(R1), _native.words_for(R2)
+        self.hz, self.hx = ctx.alloc((R1 + 1) * 8), ctx.alloc((R2 + 1) * 8)
+        p = P_TOTAL / 3
+        if algo == "sparse":
+            # sample-major packed errors resident in HBM; histogram-only output (no syndromes written)
+            lde = _native.words_for(N_QUBITS)
+            self.ex, self.ez = ctx.alloc(batch * lde * 8), ctx.alloc(batch * lde * 8)
+            ctx.sample_errors_dev(N_QUBITS, SEED, first, batch, p, p, p, self.ex, self.ez, lde)
+            self.kernel = "syndrome_sparse_kernel"
+            self.alg_bytes_per_sample = N_QUBITS / 8.0                   # SURVEY.md 8d read-only variant, per component
 
-    import torch
-    import torch.distributed as dist
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            def step():
+                ctx.syndrome_sparse_dev(chk1, self.ez, batch, lde, None, 0, self.hz, R1 + 1)
+                ctx.syndrome_sparse_dev(chk2, self.ex, batch, lde, None, 0, self.hx, R2 + 1)
 
-    from quantum_css_codes_amd import _native
-    ctx = _native.default_context()
-    code, h1, h2 = build_code()
-    chk1, chk2 = ctx.check_create(h1, R1, N_QUBITS), ctx.check_create(h2, R2, N_QUBITS)
+            def prefix(count):
+                a, b = ctx.alloc(count * self.ls1 * 8).zero(), ctx.alloc(count * self.ls2 * 8).zero()
+                ctx.syndrome_sparse_dev(chk1, self.ez, count, lde, a, self.ls1)
+                ctx.syndrome_sparse_dev(chk2, self.ex, count, lde, b, self.ls2)
+                out = a.download((count, self.ls1), "<u8"), b.download((count, self.ls2), "<u8")
+                a.free(), b.free()
+                return out
+        else:
+            lde = _native.tiled_ld(N_QUBITS)
+            tiled = _native.LAYOUT_TILED      # device-native error layout (include/gf2hip.h), written by the sampler
+            words = _native.tiled_words(N_QUBITS, batch)
+            self.ex, self.ez = ctx.alloc(words * 8), ctx.alloc(words * 8)
+            self.s1, self.s2 = ctx.alloc(batch * self.ls1 * 8), ctx.alloc(batch * self.ls2 * 8)
+            ctx.sample_errors_dev(N_QUBITS, SEED, first, batch, p, p, p, self.ex, self.ez, lde, tiled)
+            self.kernel = "syndrome_tiled_kernel"
+            self.alg_bytes_per_sample = N_QUBITS / 8.0 + (R1 + R2) / 2.0 / 8.0   # packed error read + syndrome written
 
-    batch = 1 << args.batch_log2
-    ls1, ls2 = _native.words_for(R1), _native.words_for(R2)
-    hz, hx = ctx.alloc((R1 + 1) * 8), ctx.alloc((R2 + 1) * 8)
-    # this rank's shard of the global sample stream (sample i is a function of (seed, i) only)
-    first = rank * batch
-    if args.algo == "sparse":
-        # sample-major packed errors resident in HBM; histogram-only output (no syndromes written)
-        lde = _native.words_for(N_QUBITS)
-        ex, ez = ctx.alloc(batch * lde * 8), ctx.alloc(batch * lde * 8)
-        s1 = s2 = None
-        ctx.sample_errors_dev(N_QUBITS, SEED, first, batch, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, ex, ez, lde)
-        kernel_name = "syndrome_sparse_kernel"
-        alg_bytes_per_sample = N_QUBITS / 8.0                       # SURVEY.md 8d read-only variant, per component
+            def step():
+                # tiled errors in, slab-major syndromes out (word s of sample b at s*batch + b)
+                ctx.syndrome_dev(chk1, self.ez, batch, lde, self.s1, batch, tiled)
+                ctx.syndrome_dev(chk2, self.ex, batch, lde, self.s2, batch, tiled)
+                ctx.histogram_dev(self.s1, batch, batch, R1, _native.HIST_WEIGHT, self.hz, R1 + 1, tiled)
+                ctx.histogram_dev(self.s2, batch, batch, R2, _native.HIST_WEIGHT, self.hx, R2 + 1, tiled)
 
-        def step():
-            ctx.syndrome_sparse_dev(chk1, ez, batch, lde, None, 0, hz, R1 + 1)
-            ctx.syndrome_sparse_dev(chk2, ex, batch, lde, None, 0, hx, R2 + 1)
+            def prefix(count):
+                return (np.ascontiguousarray(self.s1.download((self.ls1, batch), "<u8")[:, :count].T),
+                        np.ascontiguousarray(self.s2.download((self.ls2, batch), "<u8")[:, :count].T))
+        self.step, self.prefix = step, prefix
+        ctx.sync()
 
-        def prefix_syndromes(count):
-            a, b = ctx.alloc(count * ls1 * 8).zero(), ctx.alloc(count * ls2 * 8).zero()
-            ctx.syndrome_sparse_dev(chk1, ez, count, lde, a, ls1)
-            ctx.syndrome_sparse_dev(chk2, ex, count, lde, b, ls2)
-            return a.download((count, ls1), "<u8"), b.download((count, ls2), "<u8")
-    else:
-        lde = _native.tiled_ld(N_QUBITS)
-        tiled = _native.LAYOUT_TILED      # device-native error layout (include/gf2hip.h), written by the sampler
-        ex, ez = ctx.alloc(_native.tiled_words(N_QUBITS, batch) * 8), ctx.alloc(_native.tiled_words(N_QUBITS, batch) * 8)
-        s1, s2 = ctx.alloc(batch * ls1 * 8), ctx.alloc(batch * ls2 * 8)
-        ctx.sample_errors_dev(N_QUBITS, SEED, first, batch, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, ex, ez, lde, tiled)
-        kernel_name = "syndrome_tiled_kernel"
-        alg_bytes_per_sample = N_QUBITS / 8.0 + (R1 + R2) / 2.0 / 8.0   # packed error read + packed syndrome written
-
-        def step():
-            # tiled errors in, slab-major syndromes out (word s of sample b at s*batch + b)
-            ctx.syndrome_dev(chk1, ez, batch, lde, s1, batch, tiled)
-            ctx.syndrome_dev(chk2, ex, batch, lde, s2, batch, tiled)
-            ctx.histogram_dev(s1, batch, batch, R1, _native.HIST_WEIGHT, hz, R1 + 1, tiled)
-            ctx.histogram_dev(s2, batch, batch, R2, _native.HIST_WEIGHT, hx, R2 + 1, tiled)
-
-        def prefix_syndromes(count):
-            return (np.ascontiguousarray(s1.download((ls1, batch), "<u8")[:, :count].T),
-                    np.ascontiguousarray(s2.download((ls2, batch), "<u8")[:, :count].T))
-    ctx.sync()
-
-    # ---- correctness of what is about to be timed: a prefix of the batch against the oracle ----------------
-    hz.zero(), hx.zero()
-    step()
-    ctx.sync()
-    if rank == 0:
+    def check_against_oracle(self, h1, h2, first):
+        """A prefix of the resident batch through this path against the C oracle."""
         from oracle import c_oracle
-        want_z, want_x = c_oracle.mc(h1, R1, h2, R2, N_QUBITS, SEED, first, 512, P_TOTAL / 3, P_TOTAL / 3,
-                                     P_TOTAL / 3, 1)
-        got_s1, got_s2 = prefix_syndromes(512)
-        assert np.array_equal(c_oracle.histogram(got_s1, 512, R1, 1, R1 + 1), want_z), "H1.e_z differs from the oracle"
-        assert np.array_equal(c_oracle.histogram(got_s2, 512, R2, 1, R2 + 1), want_x), "H2.e_x differs from the oracle"
-    single = hz.download((R1 + 1,), np.uint64)
-    assert int(single.sum()) == batch
+        p = P_TOTAL / 3
+        self.hz.zero(), self.hx.zero()
+        self.step()
+        self.ctx.sync()
+        want_z, want_x = c_oracle.mc(h1, R1, h2, R2, N_QUBITS, SEED, first, 512, p, p, p, 1)
+        got1, got2 = self.prefix(512)
+        assert np.array_equal(c_oracle.histogram(got1, 512, R1, 1, R1 + 1), want_z), "H1.e_z differs from the oracle"
+        assert np.array_equal(c_oracle.histogram(got2, 512, R2, 1, R2 + 1), want_x), "H2.e_x differs from the oracle"
+        assert int(self.hz.download((R1 + 1,), np.uint64).sum()) == self.batch
 
-    for _ in range(args.warmup):
-        step()
+    def free(self):
+        for name in ("ex", "ez", "s1", "s2", "hz", "hx"):
+            buf = getattr(self, name, None)
+            if buf is not None:
+                buf.free()
+
+
+def timed(ctx, path, steps, warmup):
+    """Returns (stream ms, mean syndrome-kernel launch s, launches, histogram-kernel ms)."""
+    from quantum_css_codes_amd import _native
+    for _ in range(warmup):
+        path.step()
     ctx.sync()
-    hz.zero(), hx.zero()
+    path.hz.zero(), path.hx.zero()
     ctx.sync()
     ctx.profile(True)
     ctx.profile_reset()
-
-    def fence():
-        ctx.sync()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize() if torch.cuda.is_available() else None
-
-    fence()
-    t0 = time.perf_counter()
     ctx.timer_start()
-    for _ in range(args.steps):
-        step()
+    for _ in range(steps):
+        path.step()
     gpu_ms = ctx.timer_stop()
-    hist_z = hz.download((R1 + 1,), np.uint64)
-    hist_x = hx.download((R2 + 1,), np.uint64)
-    if world > 1:
-        from quantum_css_codes_amd.montecarlo import all_reduce_histograms
-        hist_z, hist_x = all_reduce_histograms([hist_z, hist_x])
-    fence()
-    elapsed = time.perf_counter() - t0
-
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert int(hist_z.sum()) == world * args.steps * batch and int(hist_x.sum()) == world * args.steps * batch
-
-    syn_ms, syn_launches = ctx.profile_get(_native.K_SYNDROME)
-    hist_ms, hist_launches = ctx.profile_get(_native.K_HIST)
+    syn_ms, syn_n = ctx.profile_get(_native.K_SYNDROME)
+    hist_ms, _ = ctx.profile_get(_native.K_HIST)
     ctx.profile(False)
-
-    total = world * args.steps * batch
-    value = total / elapsed
-    out = None
-    if rank == 0:
-        # dominant kernel: one launch handles `batch` samples of one Pauli component
-        alg_bytes = batch * alg_bytes_per_sample
-        mean_launch_s = syn_ms / 1e3 / max(1, syn_launches)
-        achieved = alg_bytes / mean_launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(kernel_name + "_bytes_per_launch")
-        out = {
-            "metric": "syndromes/sec (n=4096 CSS)", "value": value, "unit": "syndromes/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "configs[4]: n=4096 CSS Monte-Carlo, random dual code (H1 2048x4096, H2 2047x4096, "
-                                   "standard form), depolarising p=0.01, errors resident in HBM",
-                       "algo": args.algo, "samples_per_gpu_per_step": batch, "global_samples_per_step": batch * world,
-                       "parallelism": "sample-range shards, 1 histogram all-reduce"},
-            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": mean_launch_s * 1e3,
-                         "launches": syn_launches},
-            "kernel_ms": {"syndrome": syn_ms, "histogram": hist_ms, "stream_total": gpu_ms},
-        }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(code)
-        if args.extras:
-            out["extras"] = extras(ctx, h1)
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
-    return out
+    return gpu_ms, syn_ms / 1e3 / max(1, syn_n), syn_n, hist_ms
 
 
-def extras(ctx, h1):
-    """RREF GB/s (2 * m * ld * 8 bytes / time) on the resident 2048 x 4096 matrix, single and
-    batched, and the sampler-inclusive Monte-Carlo pipeline."""
+def roofline(path, mean_launch_s, launches):
+    alg_bytes = path.batch * path.alg_bytes_per_sample
+    achieved = alg_bytes / mean_launch_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and path.batch == 1 << 20:
+        traffic = json.load(open(tpath)).get(path.kernel + "_bytes_per_launch")
+    return {"bound": "hbm", "kernel": path.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+            "mean_launch_ms": mean_launch_s * 1e3, "launches": launches}
+
+
+def rref_numbers(ctx):
+    """RREF GB/s = 2 * m * ld * 8 bytes / time on resident random 2048 x 4096 matrices."""
     from quantum_css_codes_amd import _native
-    import ctypes
     res = {}
-    rng = np.random.default_rng(4096)
-    a = _native.pack_rows(rng.integers(0, 2, (R1, N_QUBITS)).astype(np.uint8))
-    for batch in (1, 64):
+    a = _native.pack_rows(np.random.default_rng(4096).integers(0, 2, (R1, N_QUBITS)).astype(np.uint8))
+    for batch in (1, 256):
         buf = ctx.alloc(batch * a.nbytes)
         piv, rk = ctx.alloc(batch * R1 * 8), ctx.alloc(batch * 8)
         best = None
@@ -267,10 +209,121 @@ def extras(ctx, h1):
                                                            piv.ptr, rk.ptr))
             ms = ctx.timer_stop()
             best = ms if best is None else min(best, ms)
-        res["rref_2048x4096_batch%d" % batch] = {"ms": best, "GB/s": batch * 2 * a.nbytes / best / 1e6,
-                                                 "frac_hbm": batch * 2 * a.nbytes / best / 1e6 / HBM_PEAK_GBS}
+        gbs = batch * 2 * a.nbytes / best / 1e6
+        res["2048x4096_x%d" % batch] = {"ms": best, "GB/s": gbs, "frac_hbm_peak": gbs / HBM_PEAK_GBS}
         buf.free(), piv.free(), rk.free()
     return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-log2", type=int, default=20, help="samples per GPU per step (2^k)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other syndrome kernel and the RREF timings")
+    ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
+                    help="gloo lets several ranks share one GPU to rehearse the multi-process path (histograms are "
+                         "then all-reduced on the host); the driver's runs use nccl = RCCL")
+    ap.add_argument("--algo", choices=("sparse", "dense"), default="sparse")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    device = local_rank % max(1, torch.cuda.device_count())
+    os.environ.setdefault("GF2_DEVICE", str(device))
+    if world > 1:
+        torch.cuda.set_device(device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    from quantum_css_codes_amd import _native
+    from quantum_css_codes_amd.montecarlo import all_reduce_histograms
+    ctx = _native.default_context()
+    code, h1, h2 = build_code()
+    chk1, chk2 = ctx.check_create(h1, R1, N_QUBITS), ctx.check_create(h2, R2, N_QUBITS)
+    batch = 1 << args.batch_log2
+    first = rank * batch               # this rank's shard of the global sample stream: sample i = f(seed, i)
+
+    path = Path(ctx, args.algo, chk1, chk2, batch, first)
+    if rank == 0:
+        path.check_against_oracle(h1, h2, first)        # correctness of what is about to be timed
+
+    def fence():
+        ctx.sync()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        path.step()
+    path.hz.zero(), path.hx.zero()
+    ctx.profile(True)
+    ctx.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    ctx.timer_start()
+    for _ in range(args.steps):
+        path.step()
+    gpu_ms = ctx.timer_stop()
+    hist_z = path.hz.download((R1 + 1,), np.uint64)
+    hist_x = path.hx.download((R2 + 1,), np.uint64)
+    if world > 1:
+        hist_z, hist_x = all_reduce_histograms([hist_z, hist_x])
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total = world * args.steps * batch
+    assert int(hist_z.sum()) == total and int(hist_x.sum()) == total
+    syn_ms, syn_n = ctx.profile_get(_native.K_SYNDROME)
+    hist_ms, _ = ctx.profile_get(_native.K_HIST)
+    ctx.profile(False)
+
+    if rank == 0:
+        out = {
+            "metric": "syndromes/sec (n=4096 CSS)", "value": total / elapsed, "unit": "syndromes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "configs[4]: n=4096 CSS Monte-Carlo, random dual code (H1 2048x4096, H2 2047x4096, "
+                                   "standard form), depolarising p=0.01, errors resident in HBM",
+                       "algo": args.algo, "samples_per_gpu_per_step": batch, "global_samples_per_step": batch * world,
+                       "parallelism": "sample-range shards, 1 histogram all-reduce"},
+            "roofline": roofline(path, syn_ms / 1e3 / max(1, syn_n), syn_n),
+            "kernel_ms": {"syndrome": syn_ms, "histogram": hist_ms, "stream_total": gpu_ms},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(code)
+        if world == 1 and not args.no_secondary:
+            single_z = (hist_z // np.uint64(args.steps)).astype(np.uint64)      # same batch every step
+            path.free()
+            other = Path(ctx, "dense" if args.algo == "sparse" else "sparse", chk1, chk2, batch, first)
+            other.check_against_oracle(h1, h2, first)
+            o_ms, o_launch, o_n, o_hist = timed(ctx, other, 10, 2)
+            other_z = other.hz.download((R1 + 1,), np.uint64)
+            assert np.array_equal(other_z, single_z * np.uint64(10)), "the two syndrome kernels disagree"
+            out["secondary"] = {
+                other.algo + "_kernel": {"value": 10 * batch / (o_ms / 1e3), "unit": "syndromes/s", "ms_per_step": o_ms / 10,
+                                         "roofline": roofline(other, o_launch, o_n), "histogram_ms_per_step": o_hist / 10},
+                "rref": rref_numbers(ctx)}
+            other.free()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
