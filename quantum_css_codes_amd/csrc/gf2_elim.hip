@@ -147,200 +147,349 @@ __global__ __launch_bounds__(ELIM_THREADS) void eliminate_kernel(u64* __restrict
 // ---- blocked RREF -----------------------------------------------------------------------------------------------------
 //
 // The reduced row echelon form is unique, so the elimination may pick any pivot row and move rows whenever it
-// likes.  rref_blocked_kernel keeps every row in place and works in panels of 64 columns:
+// likes.  Rows stay in place and the matrix is processed in panels of 64 columns, two kernels per panel:
 //
-//   1. panel analysis (registers; one barrier per column).  A lane owns rows tid, tid+1024, .. and holds their
-//      panel words.  For each column: every wavefront proposes an unused row with the bit set (__ballot), the first
-//      proposal wins, and every lane clears the bit in its rows with the winner's panel word, recording the
-//      operation in the row's 64-bit coefficient c_i.  With P_p the pivot row's value when chosen,
-//      P = V . OLDPIV (V unit lower triangular, from the coefficients the pivot rows had when chosen) and
-//      new_i = old_i ^ (c_i . V) . OLDPIV, where OLDPIV are the chosen rows as they stand at the start of the panel.
-//   2. d_i = c_i . V through byte tables of V.
-//   3. trailing update A[i] ^= d_i . OLDPIV, Method of Four Russians: per chunk of W words the 8 x 256 XOR
-//      combinations of the pivot rows go to LDS and every row does 8 lookups.  Chunks left of the panel are skipped
-//      while no pivot-free column has been seen there (they cannot change).
-//   4. after the last panel the pivot rows are gathered into rows 0..rank-1 (gather_rows_kernel) and the rest zeroed.
-//
-// One workgroup per matrix; a batch of matrices is one workgroup each.
+//   rref_panel_kernel (one workgroup per matrix)
+//     1. panel factorisation.  A lane owns rows tid, tid+1024, .. and holds their panel words w_i and 64-bit
+//        coefficients c_i.  Up to 128 unused rows with a bit in a still-unresolved panel column form a window in LDS;
+//        ONE wavefront runs Gauss-Jordan on the window with __ballot / readlane only (no barriers), choosing a pivot
+//        row per column and recording (bit, row, word-when-chosen, coefficients-when-chosen).  Every other row then
+//        replays those pivots on its own word in registers.  If a column found no pivot inside the window but rows
+//        outside it still carry the bit, another round follows; for random matrices one round resolves 64 columns.
+//        With P_p the pivot row's value when chosen, P = V . OLDPIV (V from the coefficients-when-chosen) and
+//        new_i = old_i ^ (c_i . V) . OLDPIV, where OLDPIV are the chosen rows as they stand at the start of the panel.
+//     2. d_i = c_i . V through byte tables of V (LDS); d_i and a snapshot of the OLDPIV rows go to global scratch.
+//   rref_update_kernel (grid: row blocks x 64-word column chunks x matrices -- the whole GPU)
+//     3. A[i] ^= d_i . OLDPIV, Method of Four Russians at full chunk width: for each group of 4 pivots the 16 XOR
+//        combinations of their rows sit in LDS (128 KiB); a wavefront owns a row, lane = word, d_i is scalar, so each
+//        of the 16 lookups is one v_add + one ds_read_b64 in which every lane reads the same entry (conflict-free),
+//        and the row is loaded and stored as 512 contiguous bytes.  Chunks left of the panel are skipped while no
+//        pivot-free column has been seen there (they cannot change).
+//   gather_rows_kernel: after the last panel the pivot rows are gathered into rows 0..rank-1, the rest zeroed.
 #define RB_THREADS 1024
+#define RB_WIN 128
 
-template <int RPT, int W>
-__global__ __launch_bounds__(RB_THREADS) void rref_blocked_kernel(u64* __restrict__ base, int64_t m, int64_t n, int64_t ld,
-                                                                 int64_t* __restrict__ pivots_base, int64_t cap,
-                                                                 int64_t* __restrict__ rank_base,
-                                                                 int32_t* __restrict__ pivrow_base) {
-    extern __shared__ __attribute__((aligned(16))) u64 smem[];
-    const int64_t m_pad = (m + 1) & ~(int64_t)1;
-    u64* T = smem;                                 // 2048 * W   (also VT: 8 x 256 words, before T is built)
-    u64* dl = T + 2048 * W;                        // m_pad
-    u64* snap = dl + m_pad;                        // 64 * W
-    u64* V = snap + 64 * W;                        // 64
-    u64* csel = V + 64;                            // 64
-    u64* slot_w = csel + 64;                       // 2 x 16
-    int* slot_row = reinterpret_cast<int*>(slot_w + 32);      // 2 x 16 ints
-    int* prow_l = slot_row + 32;                   // 64 ints
+struct RrefState {                                  // per matrix, in global scratch
+    int64_t rank;
+    int64_t first_free;                             // first column seen without a pivot
+    int64_t untouched;                              // columns below this cannot change in the current update
+    int32_t t;                                      // pivots of the current panel
+    int32_t pad;
+};
 
-    u64* a = base + (int64_t)blockIdx.x * m * ld;
-    int64_t* pivots = pivots_base ? pivots_base + (int64_t)blockIdx.x * cap : nullptr;
-    int32_t* pivrow = pivrow_base + (int64_t)blockIdx.x * cap;
+__device__ __forceinline__ u64 readlane64(u64 v, int src) {
+    return ((u64)(unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), src) << 32) |
+           (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, src);
+}
+
+template <int RPT>
+__global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict__ base, int64_t m, int64_t n, int64_t ld,
+                                                               int64_t pw, int64_t* __restrict__ pivots_base, int64_t cap,
+                                                               int32_t* __restrict__ pivrow_base, RrefState* __restrict__ states,
+                                                               unsigned char* __restrict__ used_base, u64* __restrict__ d_base,
+                                                               u64* __restrict__ snap_base) {
+    __shared__ u64 VT[2048];
+    __shared__ u64 V[64], csel[64], pword[64], win_w[RB_WIN], win_c[RB_WIN];
+    __shared__ int win_row[RB_WIN], win_piv[RB_WIN], pbit[64], prow_l[64], wave_tot[RB_THREADS / 64], misc[4];
+
+    const int64_t mat = blockIdx.x;
+    u64* a = base + mat * m * ld;
+    RrefState* st = states + mat;
+    unsigned char* used = used_base + mat * m;
+    u64* dout = d_base + mat * m;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t rank = st->rank;
+    int64_t first_free = st->first_free;
+    if (rank >= m || pw * 64 >= n) {                                   // nothing left to do for this matrix
+        if (tid == 0) st->t = 0;
+        return;
+    }
+    int64_t* pivots = pivots_base ? pivots_base + mat * cap : nullptr;
+    int32_t* pivrow = pivrow_base + mat * cap;
 
-    unsigned int usedmask = 0;                     // bit k: owned row tid + 1024 k is a pivot row already
-    int64_t rank = 0;
-    int64_t first_free = n;                        // first column seen without a pivot
-
-    for (int64_t pw = 0; pw < ld && rank < m && pw * 64 < n; ++pw) {
-        // ---- 1. panel analysis ---------------------------------------------------------------------------------------
-        u64 w[RPT], c[RPT];
+    // ---- 1. panel factorisation ------------------------------------------------------------------------------------------
+    u64 w[RPT], c[RPT];
+    int slot[RPT];
+    unsigned int usedmask = 0, usedmask0;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int64_t row = tid + (int64_t)RB_THREADS * k;
+        w[k] = row < m ? a[row * ld + pw] : 0ull;
+        c[k] = 0;
+        if (row < m && used[row]) usedmask |= 1u << k;
+    }
+    usedmask0 = usedmask;
+    const int64_t cols_here = n - pw * 64;
+    const u64 panel_cols = cols_here >= 64 ? ~0ull : ((1ull << cols_here) - 1ull);
+    u64 unresolved = panel_cols;
+    int t = 0;
+    while (unresolved && t < 64 && rank + t < m) {
+        // window: the first (up to) RB_WIN unused rows with a bit in an unresolved column
+        int cnt = 0;
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            const int64_t row = tid + (int64_t)RB_THREADS * k;
-            w[k] = row < m ? a[row * ld + pw] : 0ull;
-            c[k] = 0;
+            slot[k] = -1;
+            if (!((usedmask >> k) & 1u) && (w[k] & unresolved)) cnt += 1;
         }
-        int t = 0;
-        for (int b = 0; b < 64; ++b) {
-            const int64_t col = pw * 64 + b;
-            if (col >= n || rank + t >= m) break;
-            const int par = b & 1;
-            int kc = -1;
-            u64 wc = 0;
+        int incl = cnt;
 #pragma unroll
-            for (int k = RPT - 1; k >= 0; --k)
-                if (!((usedmask >> k) & 1u) && ((w[k] >> b) & 1ull)) {
-                    kc = k;
-                    wc = w[k];
-                }
-            const u64 bal = __ballot(kc >= 0);
-            if (bal) {
-                if (lane == __ffsll((long long)bal) - 1) {
-                    slot_row[par * 16 + wave] = tid + RB_THREADS * kc;
-                    slot_w[par * 16 + wave] = wc;
-                }
-            } else if (lane == 0) {
-                slot_row[par * 16 + wave] = -1;
-            }
-            __syncthreads();
-            const u64 valid = __ballot(slot_row[par * 16 + (lane & 15)] >= 0) & 0xFFFFull;
-            if (!valid) {
-                if (col < first_free) first_free = col;
-                continue;
-            }
-            const int wsel = __ffsll((long long)valid) - 1;
-            const int prow = slot_row[par * 16 + wsel];
-            const u64 pword = slot_w[par * 16 + wsel];
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int row = tid + RB_THREADS * k;
-                if (row == prow) {
-                    csel[t] = c[k];
-                    usedmask |= 1u << k;
-                } else if ((w[k] >> b) & 1ull) {
-                    w[k] ^= pword;
-                    c[k] |= 1ull << t;
-                }
-            }
-            if (tid == 0) {
-                prow_l[t] = prow;
-                pivrow[rank + t] = prow;
-                if (pivots) pivots[rank + t] = col;
-            }
-            t += 1;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off);
+            if (lane >= off) incl += up;
         }
+        if (lane == 63) wave_tot[wave] = incl;
         __syncthreads();
-        if (t == 0) continue;
-
-        // ---- 2. V (forward substitution in one wavefront), its byte tables, d_i = c_i . V ---------------------------------
+        int before = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < RB_THREADS / 64; ++i) {
+            const int v = wave_tot[i];
+            if (i < wave) before += v;
+            total += v;
+        }
+        if (total == 0) break;                                        // the unresolved columns have no pivot
+        int pos = before + incl - cnt;
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+            if (!((usedmask >> k) & 1u) && (w[k] & unresolved)) {
+                if (pos < RB_WIN) {
+                    slot[k] = pos;
+                    win_row[pos] = tid + RB_THREADS * k;
+                    win_w[pos] = w[k];
+                    win_c[pos] = c[k];
+                    win_piv[pos] = 0;
+                }
+                pos += 1;
+            }
+        __syncthreads();
+        const int nwin = total < RB_WIN ? total : RB_WIN;
         if (wave == 0) {
-            u64 v = lane < t ? 1ull << lane : 0ull;
-            const u64 cs = lane < t ? csel[lane] : 0ull;
-            for (int q = 0; q < t; ++q) {
-                const u64 vq = ((u64)(unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), q) << 32) |
-                               (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, q);
-                if ((cs >> q) & 1ull) v ^= vq;
+            // Gauss-Jordan on the window inside one wavefront: entries lane and lane + 64
+            u64 ew[2], ec[2];
+            int er[2];
+            bool ep[2] = {false, false};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int idx = lane + 64 * h;
+                const bool live = idx < nwin;
+                ew[h] = live ? win_w[idx] : 0ull;
+                ec[h] = live ? win_c[idx] : 0ull;
+                er[h] = live ? win_row[idx] : -1;
             }
-            V[lane] = v;
+            u64 newbits = 0;
+            int tt = t;
+            for (int b = 0; b < 64; ++b) {
+                if (!((unresolved >> b) & 1ull)) continue;
+                if (tt >= 64 || rank + tt >= m) break;
+                const u64 bal0 = __ballot(!ep[0] && ((ew[0] >> b) & 1ull));
+                const u64 bal1 = __ballot(!ep[1] && ((ew[1] >> b) & 1ull));
+                if (!(bal0 | bal1)) continue;
+                const int h = bal0 ? 0 : 1;
+                const int src = __ffsll((long long)(bal0 ? bal0 : bal1)) - 1;
+                const u64 pwd = readlane64(h ? ew[1] : ew[0], src);
+                const u64 pcs = readlane64(h ? ec[1] : ec[0], src);
+                const int prw = __builtin_amdgcn_readlane(h ? er[1] : er[0], src);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    if (hh == h && lane == src) {
+                        ep[hh] = true;
+                    } else if ((ew[hh] >> b) & 1ull) {
+                        ew[hh] ^= pwd;
+                        ec[hh] |= 1ull << tt;
+                    }
+                }
+                if (lane == 0) {
+                    pword[tt] = pwd;
+                    csel[tt] = pcs;
+                    pbit[tt] = b;
+                    prow_l[tt] = prw;
+                }
+                newbits |= 1ull << b;
+                tt += 1;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int idx = lane + 64 * h;
+                if (idx < nwin) {
+                    win_w[idx] = ew[h];
+                    win_c[idx] = ec[h];
+                    win_piv[idx] = ep[h] ? 1 : 0;
+                }
+            }
+            if (lane == 0) {
+                misc[0] = tt;
+                misc[1] = (int)(unsigned int)newbits;
+                misc[2] = (int)(unsigned int)(newbits >> 32);
+            }
         }
         __syncthreads();
-        for (int idx = tid; idx < 2048; idx += RB_THREADS) {
-            const int g = idx >> 8, vv = idx & 255;
+        const int t_new = misc[0];
+        const u64 newbits = ((u64)(unsigned int)misc[2] << 32) | (unsigned int)misc[1];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            if (slot[k] >= 0) {                                       // window rows: take the wavefront's result
+                w[k] = win_w[slot[k]];
+                c[k] = win_c[slot[k]];
+                if (win_piv[slot[k]]) usedmask |= 1u << k;
+            } else {                                                  // everyone else replays the new pivots
+#pragma unroll 4
+                for (int p = t; p < t_new; ++p) {
+                    const u64 hit = 0ull - ((w[k] >> pbit[p]) & 1ull);
+                    w[k] ^= pword[p] & hit;
+                    c[k] |= (1ull << p) & hit;
+                }
+            }
+        }
+        unresolved &= ~newbits;
+        t = t_new;
+        __syncthreads();                                              // window arrays are reused by the next round
+    }
+    if (unresolved) {                                                 // whatever is left has no pivot
+        const int64_t fc = pw * 64 + (__ffsll((long long)unresolved) - 1);
+        if (fc < first_free) first_free = fc;
+    }
+    if (tid == 0) {
+        st->t = t;
+        st->rank = rank + t;
+        st->untouched = st->first_free < pw * 64 ? st->first_free : pw * 64;   // first_free as it was BEFORE this panel
+        st->first_free = first_free;
+    }
+    if (t == 0) return;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+        if (((usedmask ^ usedmask0) >> k) & 1u) used[tid + RB_THREADS * k] = 1;
+    if (wave == 0 && lane < t) {
+        // global pivot lists in ascending column order (a later round may have resolved an earlier column): the
+        // position of a pivot is the number of resolved panel columns below its own
+        const u64 resolved = panel_cols & ~unresolved;
+        const int pos = __popcll(resolved & ((1ull << pbit[lane]) - 1ull));
+        pivrow[rank + pos] = prow_l[lane];
+        if (pivots) pivots[rank + pos] = pw * 64 + pbit[lane];
+    }
+    // snapshot of the pivot rows as they stand now (the update kernel overwrites them)
+    u64* snap = snap_base + mat * 64 * ld;
+    for (int64_t idx = tid; idx < (int64_t)t * ld; idx += RB_THREADS) {
+        const int p = (int)(idx / ld);
+        const int64_t wd = idx - (int64_t)p * ld;
+        snap[idx] = a[(int64_t)prow_l[p] * ld + wd];
+    }
+
+    // ---- 2. V (forward substitution in one wavefront), its byte tables, d_i = c_i . V ---------------------------------------
+    if (wave == 0) {
+        u64 v = lane < t ? 1ull << lane : 0ull;
+        const u64 cs = lane < t ? csel[lane] : 0ull;
+        for (int q = 0; q < t; ++q) {
+            const u64 vq = readlane64(v, q);
+            if ((cs >> q) & 1ull) v ^= vq;
+        }
+        V[lane] = v;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 2048; idx += RB_THREADS) {
+        const int g = idx >> 8, vv = idx & 255;
+        u64 x = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x ^= V[8 * g + k] & (0ull - (u64)((vv >> k) & 1));
+        VT[idx] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int64_t row = tid + (int64_t)RB_THREADS * k;
+        if (row < m) {
+            u64 d = 0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) d ^= VT[g * 256 + (int)((c[k] >> (8 * g)) & 255ull)];
+            dout[row] = d;
+        }
+    }
+}
+
+
+// grid (row blocks, column chunks of 64 words, matrices), block 1024, 128 KiB dynamic LDS.
+__global__ __launch_bounds__(RB_THREADS) void rref_update_kernel(u64* __restrict__ base, int64_t m, int64_t ld,
+                                                                int64_t rows_per_wg, const RrefState* __restrict__ states,
+                                                                const u64* __restrict__ d_base, const u64* __restrict__ snap_base) {
+    extern __shared__ __attribute__((aligned(16))) u64 T[];           // 16 groups x 16 entries x 64 words
+    const int64_t mat = blockIdx.z;
+    const RrefState st = states[mat];
+    const int t = st.t;
+    const int64_t cw0 = (int64_t)blockIdx.y * 64;
+    if (t == 0 || (cw0 + 64) * 64 <= st.untouched) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc_n = ld - cw0 < 64 ? (int)(ld - cw0) : 64;
+    const u64* snap = snap_base + mat * 64 * ld;
+    // single-pivot entries T[(g*16 + (1<<k)) * 64 + wd] = OLDPIV[4g+k][cw0+wd], then the combinations
+    {
+        u64 sv[4];                                                     // 64 x 64 words / 1024 lanes: 4 loads in flight
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + RB_THREADS * it, p = idx >> 6, wd = idx & 63;
+            sv[it] = (p < t && wd < wc_n) ? snap[(int64_t)p * ld + cw0 + wd] : 0ull;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tid + RB_THREADS * it, p = idx >> 6, wd = idx & 63;
+            T[((p >> 2) * 16 + (1 << (p & 3))) * 64 + wd] = sv[it];
+        }
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int idx = tid; idx < 16 * 16 * 64; idx += RB_THREADS) {
+        const int wd = idx & 63, vv = (idx >> 6) & 15, g = idx >> 10;
+        if (vv & (vv - 1)) {                                           // two or more pivots
             u64 x = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k)
-                if ((vv >> k) & 1) x ^= V[8 * g + k];
+            for (int k = 0; k < 4; ++k) x ^= T[(g * 16 + (1 << k)) * 64 + wd] & (0ull - (u64)((vv >> k) & 1));
             T[idx] = x;
+        } else if (vv == 0) {
+            T[idx] = 0;
         }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int64_t row = tid + (int64_t)RB_THREADS * k;
-            if (row < m) {
-                u64 d = 0;
-#pragma unroll
-                for (int g = 0; g < 8; ++g) d ^= T[g * 256 + (int)((c[k] >> (8 * g)) & 255ull)];
-                dl[row] = d;
-            }
-        }
-        __syncthreads();
-
-        // ---- 3. trailing update, chunk by chunk --------------------------------------------------------------------------
-        const int groups = (t + 7) >> 3;
-        const int64_t untouched = first_free < pw * 64 ? first_free : pw * 64;   // columns below this cannot change
-        for (int64_t cw0 = 0; cw0 < ld; cw0 += W) {
-            if ((cw0 + W) * 64 <= untouched) continue;
-            const int wc_n = ld - cw0 < W ? (int)(ld - cw0) : W;
-            for (int idx = tid; idx < t * W; idx += RB_THREADS) {
-                const int q = idx / W, wd = idx % W;
-                snap[idx] = wd < wc_n ? a[(int64_t)prow_l[q] * ld + cw0 + wd] : 0ull;
-            }
-            __syncthreads();
-            for (int idx = tid; idx < groups * 256 * W; idx += RB_THREADS) {
-                const int wd = idx % W, vv = (idx / W) & 255, g = idx / (256 * W);
-                u64 x = 0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (((vv >> k) & 1) && 8 * g + k < t) x ^= snap[(8 * g + k) * W + wd];
-                T[idx] = x;
-            }
-            __syncthreads();
-            {   // all loads first (independent, in flight together), then the lookups, then the stores
-                constexpr int ITEMS = RPT * W;
-                u64 x[ITEMS], dd[ITEMS];
-#pragma unroll
-                for (int it = 0; it < ITEMS; ++it) {
-                    const int64_t idx = tid + (int64_t)RB_THREADS * it;
-                    const int64_t row = idx / W;
-                    const int wd = (int)(idx % W);
-                    const bool live = row < m && wd < wc_n;
-                    dd[it] = live ? dl[row] : 0ull;
-                    x[it] = dd[it] ? a[row * ld + cw0 + wd] : 0ull;
-                }
-#pragma unroll
-                for (int it = 0; it < ITEMS; ++it) {
-                    const int wd = (int)((tid + (int64_t)RB_THREADS * it) % W);
-                    for (int g = 0; g < groups; ++g)
-                        x[it] ^= T[(g * 256 + (int)((dd[it] >> (8 * g)) & 255ull)) * W + wd];
-                }
-#pragma unroll
-                for (int it = 0; it < ITEMS; ++it) {
-                    const int64_t idx = tid + (int64_t)RB_THREADS * it;
-                    if (dd[it]) a[(idx / W) * ld + cw0 + (idx % W)] = x[it];
-                }
-            }
-            __syncthreads();
-        }
-        rank += t;
     }
-    if (tid == 0) rank_base[blockIdx.x] = rank;
+    __syncthreads();
+    u64* a = base + mat * m * ld;
+    const u64* dd = d_base + mat * m;
+    const bool word_live = lane < wc_n && (cw0 + lane + 1) * 64 > st.untouched;
+    // T is the kernel's only LDS, so it starts at LDS address 0: an entry is addressed as (lane*8 [+64 KiB]) +
+    // nibble*512 (scalar) + an immediate below 64 KiB
+    typedef const __attribute__((address_space(3))) u64* lds_u64_ptr;
+    const unsigned int lane8 = lane * 8u;
+    const int64_t row_end = ((int64_t)blockIdx.x + 1) * rows_per_wg < m ? ((int64_t)blockIdx.x + 1) * rows_per_wg : m;
+    constexpr int NW = RB_THREADS / 64;
+    for (int64_t r0 = (int64_t)blockIdx.x * rows_per_wg + wave; r0 < row_end; r0 += NW * 8) {
+        u64 x[8], d[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                                  // 8 rows' loads in flight
+            const int64_t row = r0 + (int64_t)u * NW;
+            d[u] = row < row_end ? readlane64(dd[row < row_end ? row : r0], 0) : 0ull;
+            x[u] = (d[u] && word_live) ? a[row * ld + cw0 + lane] : 0ull;
+        }
+#pragma unroll 1
+        for (int g = 0; g < 16; ++g) {                                 // groups outside, rows inside: 8 reads in flight
+            const unsigned int goff = (unsigned int)g * 8192u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const unsigned int soff = goff + (unsigned int)((d[u] >> (4 * g)) & 15ull) * 512u;   // scalar
+                x[u] ^= *(lds_u64_ptr)(uintptr_t)(lane8 + soff);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t row = r0 + (int64_t)u * NW;
+            if (d[u] && word_live) a[row * ld + cw0 + lane] = x[u];
+        }
+    }
 }
 
 // out row k (k < rank) = in row pivrow[k]; rows >= rank are zero.  grid (m, batch), block 64.
 __global__ void gather_rows_kernel(const u64* __restrict__ in, u64* __restrict__ out, const int32_t* __restrict__ pivrow,
-                                   const int64_t* __restrict__ rank, int64_t m, int64_t ld, int64_t cap) {
+                                   const RrefState* __restrict__ states, int64_t* __restrict__ rank_out, int64_t m,
+                                   int64_t ld, int64_t cap) {
     const int64_t k = blockIdx.x, mat = blockIdx.y;
     const u64* src = in + mat * m * ld;
     u64* dst = out + mat * m * ld + k * ld;
-    if (k < rank[mat]) {
+    const int64_t rank = states[mat].rank;
+    if (k == 0 && threadIdx.x == 0) rank_out[mat] = rank;
+    if (k < rank) {
         const u64* row = src + (int64_t)pivrow[mat * cap + k] * ld;
         for (int64_t wd = threadIdx.x; wd < ld; wd += 64) dst[wd] = row[wd];
     } else {
@@ -421,44 +570,61 @@ static int launch_eliminate(gf2_ctx* ctx, int mode, u64* a_dev, int64_t batch, i
 
 extern "C" {
 
-// Blocked path: m <= 8192.  Needs workspace for the row gather (a copy of the batch) and the pivot-row lists.
+// Blocked path: m <= 8192.  Workspace: a copy of the batch for the row gather, pivot-row lists, per-matrix state,
+// used flags, coefficients d and the snapshot of the pivot rows.
 static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld,
                                int64_t* pivots_dev, int64_t cap, int64_t* rank_dev) {
     const int rpt = (int)gf2_cdiv(m, RB_THREADS);
-    const int64_t m_pad = (m + 1) & ~(int64_t)1;
-    const size_t abytes = (size_t)batch * m * ld * 8;
-    const size_t pbytes = ((size_t)batch * cap * 4 + 255) & ~(size_t)255;
-    GF2_TRY(gf2_ws_reserve(ctx, 1, pbytes + abytes));
-    int32_t* pivrow = (int32_t*)ctx->ws[1];
-    u64* tmp = (u64*)((char*)ctx->ws[1] + pbytes);
-    const int w = m <= 2048 ? 8 : 4;
-    const size_t shmem = ((size_t)2048 * w + m_pad + 64 * w + 64 + 64 + 32) * 8 + (32 + 64) * 4;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t abytes = al((size_t)batch * m * ld * 8), pbytes = al((size_t)batch * cap * 4);
+    const size_t sbytes = al((size_t)batch * sizeof(RrefState)), ubytes = al((size_t)batch * m);
+    const size_t dbytes = al((size_t)batch * m * 8), nbytes = al((size_t)batch * 64 * ld * 8);
+    GF2_TRY(gf2_ws_reserve(ctx, 1, abytes + pbytes + sbytes + ubytes + dbytes + nbytes));
+    char* q = (char*)ctx->ws[1];
+    u64* tmp = (u64*)q; q += abytes;
+    int32_t* pivrow = (int32_t*)q; q += pbytes;
+    RrefState* states = (RrefState*)q; q += sbytes;
+    unsigned char* used = (unsigned char*)q; q += ubytes;
+    u64* dco = (u64*)q; q += dbytes;
+    u64* snap = (u64*)q;
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
-#define GF2_RB_LAUNCH(RPT, WW)                                                                                           \
-    do {                                                                                                                 \
-        static bool attr_done = false;                                                                                   \
-        if (!attr_done) {                                                                                                \
-            GF2_HIP(hipFuncSetAttribute((const void*)rref_blocked_kernel<RPT, WW>,                                        \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                         \
-            attr_done = true;                                                                                            \
-        }                                                                                                                \
-        hipLaunchKernelGGL((rref_blocked_kernel<RPT, WW>), dim3((unsigned)batch), dim3(RB_THREADS), shmem, ctx->stream,   \
-                           a_dev, m, n, ld, pivots_dev, cap, rank_dev, pivrow);                                           \
-    } while (0)
-    if (rpt <= 1)
-        GF2_RB_LAUNCH(1, 8);
-    else if (rpt <= 2)
-        GF2_RB_LAUNCH(2, 8);
-    else if (rpt <= 4)
-        GF2_RB_LAUNCH(4, 4);
-    else
-        GF2_RB_LAUNCH(8, 4);
-#undef GF2_RB_LAUNCH
+    GF2_HIP(hipMemsetAsync(states, 0, sbytes + ubytes, ctx->stream));          // rank = 0, used = 0 ...
+    {
+        std::vector<RrefState> init((size_t)batch);
+        for (auto& st : init) { st.rank = 0; st.first_free = n; st.untouched = 0; st.t = 0; st.pad = 0; }
+        GF2_HIP(hipMemcpyAsync(states, init.data(), (size_t)batch * sizeof(RrefState), hipMemcpyHostToDevice, ctx->stream));
+        GF2_HIP(hipStreamSynchronize(ctx->stream));                              // init lives on the host stack
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        GF2_HIP(hipFuncSetAttribute((const void*)rref_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_done = true;
+    }
+    const int64_t panels = gf2_words(n) < ld ? gf2_words(n) : ld;
+    // rows per update workgroup: a lone matrix wants many workgroups, a large batch wants the table build amortised
+    const int64_t rows_per_wg = batch * gf2_cdiv(ld, 64) >= 64 ? 512 : (batch * gf2_cdiv(ld, 64) >= 8 ? 256 : 128);
+    const dim3 ugrid((unsigned)gf2_cdiv(m, rows_per_wg), (unsigned)gf2_cdiv(ld, 64), (unsigned)batch);
+    for (int64_t pw = 0; pw < panels; ++pw) {
+#define GF2_RP_LAUNCH(RPT)                                                                                              \
+    hipLaunchKernelGGL((rref_panel_kernel<RPT>), dim3((unsigned)batch), dim3(RB_THREADS), 0, ctx->stream, a_dev, m, n, ld, \
+                       pw, pivots_dev, cap, pivrow, states, used, dco, snap)
+        if (rpt <= 1)
+            GF2_RP_LAUNCH(1);
+        else if (rpt <= 2)
+            GF2_RP_LAUNCH(2);
+        else if (rpt <= 4)
+            GF2_RP_LAUNCH(4);
+        else
+            GF2_RP_LAUNCH(8);
+#undef GF2_RP_LAUNCH
+        hipLaunchKernelGGL(rref_update_kernel, ugrid, dim3(RB_THREADS), 128 * 1024, ctx->stream, a_dev, m, ld, rows_per_wg, states, dco,
+                           snap);
+    }
     GF2_HIP(hipGetLastError());
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)m, (unsigned)batch), dim3(64), 0, ctx->stream, (const u64*)a_dev,
-                       tmp, pivrow, rank_dev, m, ld, cap);
+                       tmp, pivrow, states, rank_dev, m, ld, cap);
     GF2_HIP(hipGetLastError());
-    GF2_HIP(hipMemcpyAsync(a_dev, tmp, abytes, hipMemcpyDeviceToDevice, ctx->stream));
+    GF2_HIP(hipMemcpyAsync(a_dev, tmp, (size_t)batch * m * ld * 8, hipMemcpyDeviceToDevice, ctx->stream));
     GF2_TRY(gf2_prof_end(ctx));
     return GF2_OK;
 }
@@ -473,7 +639,7 @@ int gf2_rref_batch_dev(gf2_ctx* ctx, uint64_t* a_dev, int64_t batch, int64_t m, 
     if (m == 0 || n == 0) return gf2_dev_zero(ctx, rank_dev, (size_t)batch * 8);
     if (!a_dev) GF2_FAIL(GF2_E_ARG, "gf2_rref_batch_dev: null matrix");
     const int64_t cap = m < n ? m : n;
-    if (m <= 8 * RB_THREADS && batch <= 65535 && m <= 0x7fffffff && getenv("GF2_RREF_SEQUENTIAL") == nullptr)
+    if (m <= 8 * RB_THREADS && batch <= 65535 && getenv("GF2_RREF_SEQUENTIAL") == nullptr)
         return launch_rref_blocked(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
     return launch_eliminate(ctx, ELIM_RREF, (u64*)a_dev, batch, m, n, ld, 0, pivots_dev, cap, rank_dev, nullptr, nullptr,
                             nullptr);
