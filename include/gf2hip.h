@@ -200,6 +200,19 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* check_c1, const gf2_check* check_c
                double p_x, double p_y, double p_z, int mode,
                uint64_t* hist_z, int64_t nbins_z, uint64_t* hist_x, int64_t nbins_x);
 
+/* Table decode + logical-error tally [build-defined, SURVEY.md 8f item 1]: the classical content of
+ * quil_classical_correct (css_code.py:649-685) and noisy_measure (css_code.py:599-646) applied to sampled errors.
+ * Per sample: s_x = H2.e_x; if vec_to_int(s_x) is in the C2 syndrome table the correction is XOR-ed in, otherwise the
+ * error is left unchanged (css_code.py:655-657); the logical Z measurement flips iff z_operator . residual_x is odd
+ * (css_code.py:640-646).  Likewise for Z errors with H1, the C1 table and x_operator.  Small codes only (n <= 63,
+ * r_1, r_2 <= 20).  table_c1 / table_c2: 2^r_1 / 2^r_2 host words indexed by vec_to_int(syndrome): the packed
+ * correction, or ~0 where the table has no entry.  counts_out[5] = { logical X flips, logical Z flips, samples with
+ * either flip, samples whose X syndrome has no table entry, samples whose Z syndrome has no table entry }. */
+int gf2_mc_decode(gf2_ctx* ctx, const gf2_check* check_c1, const gf2_check* check_c2,
+                  const uint64_t* table_c1, const uint64_t* table_c2, uint64_t x_operator, uint64_t z_operator,
+                  uint64_t seed, int64_t first_sample, int64_t count, double p_x, double p_y, double p_z,
+                  uint64_t* counts_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,7 @@ def lib():
             "orc_syndrome_batch": [_p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64],
             "orc_histogram": [_p, _i64, _i64, _i64, ctypes.c_int, _p],
             "orc_sample_errors": [_i64, _u64, _i64, _i64, _dbl, _dbl, _dbl, _p, _p, _i64],
+            "orc_mc_decode": [_p, _i64, _p, _i64, _i64, _p, _p, _u64, _u64, _u64, _i64, _i64, _dbl, _dbl, _dbl, _p],
             "orc_mc": [_p, _i64, _i64, _p, _i64, _i64, _i64, _u64, _i64, _i64, _dbl, _dbl, _dbl, ctypes.c_int,
                        _p, _i64, _p, _i64],
         }
@@ -125,3 +126,15 @@ def mc(h1, r1, h2, r2, n, seed, first, count, p_x, p_y, p_z, mode):
     lib().orc_mc(_ptr(h1), r1, h1.shape[1], _ptr(h2), r2, h2.shape[1], n, seed & 0xFFFFFFFFFFFFFFFF, first, count,
                  p_x, p_y, p_z, mode, _ptr(hz), nz, _ptr(hx), nx)
     return hz, hx
+
+
+def mc_decode(h1, r1, h2, r2, n, t1, t2, xop, zop, seed, first, count, p_x, p_y, p_z):
+    """h1/h2: packed rows (one word each, n <= 63); t1/t2: dense tables (2^r words, ~0 = missing)."""
+    h1 = np.ascontiguousarray(np.asarray(h1, dtype="<u8").reshape(-1))
+    h2 = np.ascontiguousarray(np.asarray(h2, dtype="<u8").reshape(-1))
+    t1 = np.ascontiguousarray(t1, dtype=np.uint64)
+    t2 = np.ascontiguousarray(t2, dtype=np.uint64)
+    counts = np.zeros(5, dtype=np.uint64)
+    lib().orc_mc_decode(_ptr(h1), r1, _ptr(h2), r2, n, _ptr(t1), _ptr(t2), int(xop), int(zop), seed & 0xFFFFFFFFFFFFFFFF,
+                        first, count, p_x, p_y, p_z, _ptr(counts))
+    return counts

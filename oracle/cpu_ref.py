@@ -407,3 +407,31 @@ def monte_carlo_histograms(h_1, h_2, seed, first_sample, num_samples, p_x, p_y, 
             hist_z[int(s_z.sum())] += np.uint64(1)
             hist_x[int(s_x.sum())] += np.uint64(1)
     return hist_z, hist_x
+
+
+def decode_and_tally(code, seed, first_sample, num_samples, p_x, p_y, p_z):
+    """[build-defined, SURVEY.md 8f item 1]  Classical content of quil_classical_correct (css_code.py:649-685) and
+    noisy_measure (css_code.py:640-646) on sampled errors, one sample at a time with the reference's own data
+    structures: the syndrome tables are the dicts built by syndrome_table, keys by vec_to_int.  `code` is a CSSCode
+    of this module.  Returns [logical X flips, logical Z flips, either, X syndrome not in table, Z syndrome not in
+    table]."""
+    z_op = code.z_operator_matrix()[0]
+    x_op = code.x_operator_matrix()[0]
+    counts = [0, 0, 0, 0, 0]
+    for i in range(first_sample, first_sample + num_samples):
+        e_x, e_z = sample_pauli_error(seed, i, code.n, p_x, p_y, p_z)
+        flips = []
+        for err, check, table, op, miss_slot in ((e_x, code.parity_check_c2, code._c2_syndromes, z_op, 3),
+                                                 (e_z, code.parity_check_c1, code._c1_syndromes, x_op, 4)):
+            key = int(vec_to_int(syndrome_product(check, err)))
+            errors = np.zeros(code.n, dtype='int')             # the block's known-error register starts at zero
+            if key in table:
+                errors = np.mod(errors + table[key], 2)         # conditional_xor of the matching correction
+            else:
+                counts[miss_slot] += 1                          # no match: errors left unchanged
+            residual = np.mod(err + errors, 2)                  # codeword XOR errors, codeword = true codeword + err
+            flips.append(int(np.mod(np.dot(op, residual), 2)))
+        counts[0] += flips[0]
+        counts[1] += flips[1]
+        counts[2] += 1 if (flips[0] or flips[1]) else 0
+    return counts

@@ -233,3 +233,27 @@ int orc_mc(const u64* h1, int64_t r1, int64_t ld1, const u64* h2, int64_t r2, in
     free(s2);
     return 0;
 }
+
+/* [build-defined, SURVEY.md 8f item 1]  Table decode + logical tally for codes with n <= 63: tables are 2^r words
+ * indexed by the big-endian syndrome key (css_code.py:729), ~0 = no entry (css_code.py:655-657: error unchanged);
+ * logical flips per css_code.py:640-646.  counts[5] as in include/gf2hip.h, overwritten. */
+int orc_mc_decode(const u64* h1, int64_t r1, const u64* h2, int64_t r2, int64_t n, const u64* t1, const u64* t2, u64 xop,
+                  u64 zop, u64 seed, int64_t first, int64_t count, double p_x, double p_y, double p_z, u64* counts) {
+    for (int k = 0; k < 5; ++k) counts[k] = 0;
+    for (int64_t i = 0; i < count; ++i) {
+        u64 ex, ez;
+        orc_sample_errors(n, seed, first + i, 1, p_x, p_y, p_z, &ex, &ez, 1);
+        u64 kx = 0, kz = 0;
+        for (int64_t k = 0; k < r2; ++k) kx = (kx << 1) | (u64)(__builtin_popcountll(h2[k] & ex) & 1);
+        for (int64_t k = 0; k < r1; ++k) kz = (kz << 1) | (u64)(__builtin_popcountll(h1[k] & ez) & 1);
+        const int miss_x = t2[kx] == ~0ull, miss_z = t1[kz] == ~0ull;
+        const u64 res_x = miss_x ? ex : ex ^ t2[kx], res_z = miss_z ? ez : ez ^ t1[kz];
+        const int fx = __builtin_popcountll(zop & res_x) & 1, fz = __builtin_popcountll(xop & res_z) & 1;
+        counts[0] += (u64)fx;
+        counts[1] += (u64)fz;
+        counts[2] += (u64)(fx | fz);
+        counts[3] += (u64)miss_x;
+        counts[4] += (u64)miss_z;
+    }
+    return 0;
+}

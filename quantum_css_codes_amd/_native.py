@@ -76,6 +76,8 @@ SIGNATURES = {
     "gf2_tiled_ld": [_c_i64],
     "gf2_tiled_words": [_c_i64, _c_i64],
     "gf2_retile_dev": [_p, _p, _c_i64, _c_i64, _c_i64, _p],
+    "gf2_mc_decode": [_p, _p, _p, _p, _p, _c_u64, _c_u64, _c_u64, _c_i64, _c_i64, ctypes.c_double, ctypes.c_double,
+                      ctypes.c_double, _p],
     "gf2_mc_run": [_p, _p, _p, _c_u64, _c_i64, _c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                    ctypes.c_int, _p, _c_i64, _p, _c_i64],
 }
@@ -395,6 +397,16 @@ class Context(object):
         check(lib().gf2_mc_run(self.handle, chk1.handle, chk2.handle, seed & 0xFFFFFFFFFFFFFFFF, first, count,
                                p_x, p_y, p_z, mode, _ptr(hist_z), nz, _ptr(hist_x), nx))
         return hist_z, hist_x
+
+
+    def mc_decode(self, chk1, chk2, table_c1, table_c2, x_operator, z_operator, seed, first, count, p_x, p_y, p_z):
+        """Returns the five counts of gf2_mc_decode as a uint64 array."""
+        t1 = np.ascontiguousarray(table_c1, dtype=np.uint64)
+        t2 = np.ascontiguousarray(table_c2, dtype=np.uint64)
+        counts = np.zeros(5, dtype=np.uint64)
+        check(lib().gf2_mc_decode(self.handle, chk1.handle, chk2.handle, _ptr(t1), _ptr(t2), int(x_operator),
+                                  int(z_operator), seed & 0xFFFFFFFFFFFFFFFF, first, count, p_x, p_y, p_z, _ptr(counts)))
+        return counts
 
 
 _default = None

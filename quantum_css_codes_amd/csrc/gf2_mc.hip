@@ -78,6 +78,46 @@ __global__ __launch_bounds__(256) void sampler_kernel(u64 seed, int64_t first_sa
     }
 }
 
+// ---- table decode + logical-error tally (small codes) --------------------------------------------------------------
+struct DecodeRows {
+    u64 h1[20], h2[20];
+};
+
+// One lane per sample, everything in registers: sample -> both syndromes -> table lookups -> residuals -> parities.
+// counts: [0] logical X flips, [1] logical Z flips, [2] either, [3] X syndrome not in table, [4] Z syndrome not in table.
+__global__ __launch_bounds__(256) void decode_kernel(DecodeRows rows, int r1, int r2, int n, const u64* __restrict__ t1,
+                                                     const u64* __restrict__ t2, u64 xop, u64 zop, u64 seed,
+                                                     int64_t first_sample, int64_t count, PauliThresholds th,
+                                                     u64* __restrict__ counts) {
+    __shared__ unsigned int acc[5];
+    if (threadIdx.x < 5) acc[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    unsigned int local[5] = {0, 0, 0, 0, 0};
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        u64 ex, ez;
+        sample_word(seed, (u64)(first_sample + i), 0, valid, th, &ex, &ez);
+        u64 kx = 0, kz = 0;                                   // vec_to_int keys: row 0 is the most significant bit
+        for (int k = 0; k < r2; ++k) kx = (kx << 1) | (u64)(__popcll(rows.h2[k] & ex) & 1);
+        for (int k = 0; k < r1; ++k) kz = (kz << 1) | (u64)(__popcll(rows.h1[k] & ez) & 1);
+        const u64 cx = t2[kx], cz = t1[kz];
+        const bool miss_x = cx == ~0ull, miss_z = cz == ~0ull;
+        const u64 res_x = miss_x ? ex : ex ^ cx, res_z = miss_z ? ez : ez ^ cz;
+        const bool flip_x = __popcll(zop & res_x) & 1, flip_z = __popcll(xop & res_z) & 1;
+        local[0] += flip_x;
+        local[1] += flip_z;
+        local[2] += flip_x | flip_z;
+        local[3] += miss_x;
+        local[4] += miss_z;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        if (local[k]) atomicAdd(&acc[k], local[k]);
+    __syncthreads();
+    if (threadIdx.x < 5 && acc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (u64)acc[threadIdx.x]);
+}
+
 static int make_thresholds(double p_x, double p_y, double p_z, PauliThresholds* th) {
     if (!(p_x >= 0.0) || !(p_y >= 0.0) || !(p_z >= 0.0) || p_x + p_y + p_z > 1.0 + 1e-12)
         GF2_FAIL(GF2_E_ARG, "probabilities must be non-negative and sum to at most 1");
@@ -204,6 +244,45 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
     }
     GF2_TRY(gf2_d2h(ctx, hist_z, hz, hz_bytes));
     GF2_TRY(gf2_d2h(ctx, hist_x, hx, hx_bytes));
+    return GF2_OK;
+}
+
+int gf2_mc_decode(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, const uint64_t* table_c1,
+                  const uint64_t* table_c2, uint64_t x_operator, uint64_t z_operator, uint64_t seed, int64_t first_sample,
+                  int64_t count, double p_x, double p_y, double p_z, uint64_t* counts_out) {
+    if (!ctx || !c1 || !c2 || !table_c1 || !table_c2 || !counts_out) GF2_FAIL(GF2_E_ARG, "gf2_mc_decode: null argument");
+    if (c1->n != c2->n) GF2_FAIL(GF2_E_ARG, "gf2_mc_decode: the two checks have different n");
+    if (c1->n > 63 || c1->n < 1 || c1->r > 20 || c2->r > 20)
+        GF2_FAIL(GF2_E_ARG, "gf2_mc_decode: needs n <= 63 and r_1, r_2 <= 20 (table decode of small codes)");
+    if (count < 0 || first_sample < 0) GF2_FAIL(GF2_E_ARG, "gf2_mc_decode: negative range");
+    PauliThresholds th;
+    GF2_TRY(make_thresholds(p_x, p_y, p_z, &th));
+    GF2_TRY(gf2_ctx_activate(ctx));
+    for (int k = 0; k < 5; ++k) counts_out[k] = 0;
+    if (count == 0) return GF2_OK;
+    const size_t b1 = (size_t)8 << c1->r, b2 = (size_t)8 << c2->r;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    GF2_TRY(gf2_ws_reserve(ctx, 0, al(b1) + al(b2) + 256));
+    char* q = (char*)ctx->ws[0];
+    u64* t1 = (u64*)q; q += al(b1);
+    u64* t2 = (u64*)q; q += al(b2);
+    u64* counts = (u64*)q;
+    GF2_TRY(gf2_h2d(ctx, t1, table_c1, b1));
+    GF2_TRY(gf2_h2d(ctx, t2, table_c2, b2));
+    GF2_TRY(gf2_dev_zero(ctx, counts, 40));
+    DecodeRows rows;
+    memset(&rows, 0, sizeof(rows));
+    for (int64_t k = 0; k < c1->r; ++k) rows.h1[k] = c1->rows_small[k];
+    for (int64_t k = 0; k < c2->r; ++k) rows.h2[k] = c2->rows_small[k];
+    int64_t blocks = gf2_cdiv(count, 256 * 16);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    GF2_TRY(gf2_prof_begin(ctx, GF2_K_SAMPLER));
+    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, rows, (int)c1->r, (int)c2->r,
+                       (int)c1->n, t1, t2, (u64)x_operator, (u64)z_operator, (u64)seed, first_sample, count, th, counts);
+    GF2_TRY(gf2_prof_end(ctx));
+    GF2_HIP(hipGetLastError());
+    GF2_TRY(gf2_d2h(ctx, counts_out, counts, 40));
     return GF2_OK;
 }
 

@@ -15,8 +15,8 @@ Quil program emission (encode_*, error_correct, measure, ...) is out of scope (S
 pyQuil is not required: Pauli operators are returned as text labels ("X0*X3*X4*X5") unless pyQuil is
 importable, in which case PauliTerm objects are returned as in the reference.
 
-Build-defined additions: CSSCode(..., max_table_weight=), CSSCode.syndromes,
-CSSCode.monte_carlo, syndrome_batch.
+Build-defined additions (8f item 1): CSSCode(..., max_table_weight=), CSSCode.syndromes,
+CSSCode.monte_carlo, CSSCode.logical_error_rates, syndrome_batch.
 """
 import itertools
 
@@ -186,6 +186,17 @@ class CSSCode(QECC):
         from . import montecarlo
         return montecarlo.run_local(self, num_samples, p_x, p_y, p_z, seed=seed, first_sample=first_sample,
                                     mode=mode)
+
+
+    def logical_error_rates(self, num_samples, p_x, p_y, p_z, seed=0, first_sample=0):
+        """[build-defined, SURVEY.md 8f item 1]  Monte-Carlo of the classical side of error correction followed by
+        a logical measurement: for every sampled error the syndrome is looked up in this code's tables
+        (quil_classical_correct, css_code.py:649-685: the correction is applied when the syndrome is in the table,
+        otherwise the error stays), and the logical Z (X) measurement flips iff z_operator . residual_x
+        (x_operator . residual_z) is odd (noisy_measure, css_code.py:640-646).  Small codes only (n <= 63,
+        r_1, r_2 <= 20).  Returns counts: logical_x, logical_z, logical_any, uncorrectable_x, uncorrectable_z, samples."""
+        from . import montecarlo
+        return montecarlo.decode_local(self, num_samples, p_x, p_y, p_z, seed=seed, first_sample=first_sample)
 
 
 # -- free functions -----------------------------------------------------------------------------------------

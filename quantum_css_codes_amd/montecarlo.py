@@ -78,3 +78,56 @@ def run_sharded(code, num_samples, p_x, p_y, p_z, seed=0, first_sample=0, mode=N
     part = fn(code, mine, p_x, p_y, p_z, seed=seed, first_sample=start, mode=mode)
     hist_z, hist_x = all_reduce_histograms([part['hist_z'], part['hist_x']], group=group)
     return {'hist_z': hist_z, 'hist_x': hist_x, 'mode': part['mode'], 'shard': (start, mine)}
+
+
+DECODE_FIELDS = ('logical_x', 'logical_z', 'logical_any', 'uncorrectable_x', 'uncorrectable_z')
+
+
+def dense_table(table, r, n):
+    """A syndrome table (dict: vec_to_int(syndrome) -> error vector, css_code.py:715-735) as 2^r packed words
+    indexed by the key; entries the table does not have are ~0."""
+    out = np.full(1 << r, np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
+    for key, err in table.items():
+        word = 0
+        for j in np.flatnonzero(np.asarray(err)):
+            word |= 1 << int(j)
+        out[int(key)] = np.uint64(word)
+    return out
+
+
+def packed_word(vec):
+    word = 0
+    for j in np.flatnonzero(np.asarray(vec)):
+        word |= 1 << int(j)
+    return word
+
+
+def decode_local(code, num_samples, p_x, p_y, p_z, seed=0, first_sample=0):
+    """Table decode + logical-error tally of samples [first_sample, first_sample + num_samples) on this GPU
+    (gf2_mc_decode).  Returns a dict of counts (DECODE_FIELDS) plus 'samples'."""
+    if code.n > 63 or code.r_1 > 20 or code.r_2 > 20:
+        raise ValueError("table decode needs n <= 63 and r_1, r_2 <= 20")
+    ctx = _native.default_context()
+    chk1, chk2 = code._device_checks()
+    counts = ctx.mc_decode(chk1, chk2, dense_table(code._c1_syndromes, code.r_1, code.n),
+                           dense_table(code._c2_syndromes, code.r_2, code.n),
+                           packed_word(code.x_operator_matrix()[0]), packed_word(code.z_operator_matrix()[0]),
+                           int(seed), int(first_sample), int(num_samples), float(p_x), float(p_y), float(p_z))
+    out = {name: int(v) for name, v in zip(DECODE_FIELDS, counts)}
+    out['samples'] = int(num_samples)
+    return out
+
+
+def decode_sharded(code, num_samples, p_x, p_y, p_z, seed=0, first_sample=0, group=None, local_fn=None):
+    """This rank's shard of the global range, then one all-reduce of the five counts."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    start, mine = shard_range(first_sample, num_samples, rank, world)
+    part = (local_fn or decode_local)(code, mine, p_x, p_y, p_z, seed=seed, first_sample=start)
+    total, = all_reduce_histograms([np.array([part[f] for f in DECODE_FIELDS], dtype=np.uint64)], group=group)
+    out = {name: int(v) for name, v in zip(DECODE_FIELDS, total)}
+    out['samples'] = int(num_samples)
+    return out

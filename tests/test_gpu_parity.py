@@ -476,3 +476,29 @@ def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, monkeypatch):
     want = c_oracle.mc(h1, 2048, h2, 2047, 4096, 0xABC, 5 * 10**6, 20000, 0.004, 0.003, 0.002, 1)
     for got in (sparse, dense):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+# ---- table decode + logical-error tally -------------------------------------------------------------
+
+def test_logical_error_rates_vs_oracle(steane_h, rm15):
+    from quantum_css_codes_amd.montecarlo import dense_table, packed_word
+    for code, p, count in ((CSSCode(steane_h, steane_h), (0.03, 0.01, 0.02), 400000),
+                           (CSSCode(*rm15), (0.05, 0.02, 0.03), 300000)):
+        got = code.logical_error_rates(count, *p, seed=77, first_sample=10**9)
+        want = c_oracle.mc_decode(c_oracle.pack_rows(code.parity_check_c1), code.r_1,
+                                  c_oracle.pack_rows(code.parity_check_c2), code.r_2, code.n,
+                                  dense_table(code._c1_syndromes, code.r_1, code.n),
+                                  dense_table(code._c2_syndromes, code.r_2, code.n),
+                                  packed_word(code.x_operator_matrix()[0]), packed_word(code.z_operator_matrix()[0]),
+                                  77, 10**9, count, *p)
+        assert [got[f] for f in ('logical_x', 'logical_z', 'logical_any', 'uncorrectable_x', 'uncorrectable_z')] == \
+            [int(v) for v in want]
+        assert got['samples'] == count and 0 < got['logical_any'] < count
+    # against the statement built on the reference's dict tables, small sample
+    code = CSSCode(steane_h, steane_h)
+    small = code.logical_error_rates(300, 0.06, 0.03, 0.05, seed=21, first_sample=1000)
+    want = cpu_ref.decode_and_tally(cpu_ref.CSSCode(steane_h, steane_h), 21, 1000, 300, 0.06, 0.03, 0.05)
+    assert [small[f] for f in ('logical_x', 'logical_z', 'logical_any', 'uncorrectable_x', 'uncorrectable_z')] == want
+    # Steane corrects every single-qubit error: at weight <= 1 nothing flips.  p tiny -> no flips in 10^5 samples
+    quiet = code.logical_error_rates(100000, 1e-9, 1e-9, 1e-9, seed=3)
+    assert quiet['logical_any'] == 0 and quiet['uncorrectable_x'] == 0

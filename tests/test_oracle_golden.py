@@ -218,3 +218,22 @@ def test_sampler_rates():
         tot += [np.sum(ex & (1 - ez)), np.sum(ex & ez), np.sum((1 - ex) & ez)]
     rates = tot / (n * count)
     assert np.allclose(rates, [0.10, 0.05, 0.20], atol=0.01)
+
+
+def test_decode_tally_c_vs_numpy(steane_h, rm15):
+    # the packed C statement of the table decode against the one built on the reference's own dict tables
+    from oracle import c_oracle
+    from quantum_css_codes_amd.montecarlo import dense_table, packed_word   # host-side table packing (no GPU)
+    for code, p in ((ref.CSSCode(steane_h, steane_h), (0.06, 0.03, 0.05)), (ref.CSSCode(*rm15), (0.08, 0.02, 0.04))):
+        want = ref.decode_and_tally(code, 21, 1000, 400, *p)
+        got = c_oracle.mc_decode(c_oracle.pack_rows(code.parity_check_c1), code.r_1,
+                                 c_oracle.pack_rows(code.parity_check_c2), code.r_2, code.n,
+                                 dense_table(code._c1_syndromes, code.r_1, code.n),
+                                 dense_table(code._c2_syndromes, code.r_2, code.n),
+                                 packed_word(code.x_operator_matrix()[0]), packed_word(code.z_operator_matrix()[0]),
+                                 21, 1000, 400, *p)
+        assert [int(v) for v in got] == want
+        assert want[0] > 0 and want[1] > 0                  # the regime actually produces logical errors
+    # error-free channel: nothing flips, every syndrome (zero) is in the table
+    code = ref.CSSCode(steane_h, steane_h)
+    assert ref.decode_and_tally(code, 1, 0, 20, 0.0, 0.0, 0.0) == [0, 0, 0, 0, 0]
