@@ -118,6 +118,48 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeRows rows, int r1, in
     if (threadIdx.x < 5 && acc[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (u64)acc[threadIdx.x]);
 }
 
+// ---- fused Monte-Carlo for small codes (n <= 64, r_1, r_2 <= 20): sample -> syndromes -> histograms, no HBM traffic ----
+// mode GF2_HIST_FULL: bins by the big-endian key; GF2_HIST_WEIGHT: bins by weight.  Bins privatised in LDS when both
+// histograms fit 8192 bins together.
+__global__ __launch_bounds__(256) void mc_small_kernel(DecodeRows rows, int r1, int r2, int n, int mode, u64 seed,
+                                                       int64_t first_sample, int64_t count, PauliThresholds th,
+                                                       u64* __restrict__ hist_z, int nbz, u64* __restrict__ hist_x, int nbx) {
+    __shared__ unsigned int bins[8192];
+    const bool priv = nbz + nbx <= 8192;
+    if (priv) {
+        for (int i = threadIdx.x; i < nbz + nbx; i += blockDim.x) bins[i] = 0;
+        __syncthreads();
+    }
+    const u64 valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        u64 ex, ez;
+        sample_word(seed, (u64)(first_sample + i), 0, valid, th, &ex, &ez);
+        u64 kx = 0, kz = 0;
+        if (mode == GF2_HIST_FULL) {
+            for (int k = 0; k < r2; ++k) kx = (kx << 1) | (u64)(__popcll(rows.h2[k] & ex) & 1);
+            for (int k = 0; k < r1; ++k) kz = (kz << 1) | (u64)(__popcll(rows.h1[k] & ez) & 1);
+        } else {
+            for (int k = 0; k < r2; ++k) kx += (u64)(__popcll(rows.h2[k] & ex) & 1);
+            for (int k = 0; k < r1; ++k) kz += (u64)(__popcll(rows.h1[k] & ez) & 1);
+        }
+        if (priv) {
+            atomicAdd(&bins[kz], 1u);
+            atomicAdd(&bins[nbz + kx], 1u);
+        } else {
+            atomicAdd(&hist_z[kz], 1ull);
+            atomicAdd(&hist_x[kx], 1ull);
+        }
+    }
+    if (priv) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nbz; i += blockDim.x)
+            if (bins[i]) atomicAdd(&hist_z[i], (u64)bins[i]);
+        for (int i = threadIdx.x; i < nbx; i += blockDim.x)
+            if (bins[nbz + i]) atomicAdd(&hist_x[i], (u64)bins[nbz + i]);
+    }
+}
+
 static int make_thresholds(double p_x, double p_y, double p_z, PauliThresholds* th) {
     if (!(p_x >= 0.0) || !(p_y >= 0.0) || !(p_z >= 0.0) || p_x + p_y + p_z > 1.0 + 1e-12)
         GF2_FAIL(GF2_E_ARG, "probabilities must be non-negative and sum to at most 1");
@@ -175,6 +217,33 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
     GF2_TRY(make_thresholds(p_x, p_y, p_z, &th));
     GF2_TRY(gf2_ctx_activate(ctx));
 
+    // Small codes: one fused kernel, nothing but the histograms touches memory.
+    if (c1->small && c2->small && c1->r <= 20 && c2->r <= 20 && n >= 1 && getenv("GF2_MC_PIPELINE") == nullptr) {
+        const size_t hzb = (size_t)nbins_z * 8, hxb = (size_t)nbins_x * 8;
+        auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        GF2_TRY(gf2_ws_reserve(ctx, 0, al(hzb) + al(hxb)));
+        uint64_t* dz = (uint64_t*)ctx->ws[0];
+        uint64_t* dx = (uint64_t*)((char*)ctx->ws[0] + al(hzb));
+        GF2_TRY(gf2_dev_zero(ctx, dz, hzb));
+        GF2_TRY(gf2_dev_zero(ctx, dx, hxb));
+        if (count > 0) {
+            DecodeRows rows;
+            memset(&rows, 0, sizeof(rows));
+            for (int64_t k = 0; k < c1->r; ++k) rows.h1[k] = c1->rows_small[k];
+            for (int64_t k = 0; k < c2->r; ++k) rows.h2[k] = c2->rows_small[k];
+            int64_t blocks = gf2_cdiv(count, 256 * 16);
+            if (blocks > 4096) blocks = 4096;
+            if (blocks < 1) blocks = 1;
+            GF2_TRY(gf2_prof_begin(ctx, GF2_K_SAMPLER));
+            hipLaunchKernelGGL(mc_small_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, rows, (int)c1->r, (int)c2->r,
+                               (int)n, mode, (u64)seed, first_sample, count, th, (u64*)dz, (int)nbins_z, (u64*)dx, (int)nbins_x);
+            GF2_TRY(gf2_prof_end(ctx));
+            GF2_HIP(hipGetLastError());
+        }
+        GF2_TRY(gf2_d2h(ctx, hist_z, dz, hzb));
+        GF2_TRY(gf2_d2h(ctx, hist_x, dx, hxb));
+        return GF2_OK;
+    }
     // Sparse-error pipeline: when few bits are set per error the column kernel wins: sampler writes
     // sample-major errors, the sparse kernel accumulates the weight histograms directly, no syndromes stored.
     const double dens = (p_x + p_y > p_z + p_y ? p_x + p_y : p_z + p_y) * (double)n;

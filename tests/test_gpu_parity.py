@@ -502,3 +502,15 @@ def test_logical_error_rates_vs_oracle(steane_h, rm15):
     # Steane corrects every single-qubit error: at weight <= 1 nothing flips.  p tiny -> no flips in 10^5 samples
     quiet = code.logical_error_rates(100000, 1e-9, 1e-9, 1e-9, seed=3)
     assert quiet['logical_any'] == 0 and quiet['uncorrectable_x'] == 0
+
+
+def test_small_code_fused_and_pipeline_agree(rm15, steane_h, monkeypatch):
+    # the fused small-code kernel and the sampler -> syndrome -> histogram pipeline give identical histograms
+    for code in (CSSCode(steane_h, steane_h), CSSCode(*rm15)):
+        for mode in ('full', 'weight'):
+            fused = code.monte_carlo(200000, 0.04, 0.01, 0.02, seed=9, first_sample=77, mode=mode)
+            monkeypatch.setenv("GF2_MC_PIPELINE", "1")
+            piped = code.monte_carlo(200000, 0.04, 0.01, 0.02, seed=9, first_sample=77, mode=mode)
+            monkeypatch.delenv("GF2_MC_PIPELINE")
+            assert np.array_equal(fused['hist_z'], piped['hist_z']) and np.array_equal(fused['hist_x'], piped['hist_x'])
+            assert int(fused['hist_z'].sum()) == 200000
