@@ -280,22 +280,47 @@ __global__ __launch_bounds__(256) void syndrome_small_kernel(SmallRows rows, int
     }
 }
 
+// Two adjacent sample words per lane: every access is 16 bytes per lane, 1 KiB per wavefront instruction.
 template <int NMAX>
 __global__ __launch_bounds__(256) void syndrome_sliced_kernel(SmallRows rows, int r, int n,
                                                               const uint64_t* __restrict__ e, int64_t words,
                                                               int64_t lde, uint64_t* __restrict__ s,
                                                               int64_t lds_out) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < words; b += stride) {
-        u64 v[NMAX];
+    const int64_t pairs = (words + 1) >> 1;
+    const bool wide = ((lde | lds_out) & 1) == 0 && ((((uintptr_t)e) | ((uintptr_t)s)) & 15) == 0;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < pairs; b += stride) {
+        const bool two = 2 * b + 1 < words;
+        ulonglong2 v[NMAX];
 #pragma unroll
-        for (int q = 0; q < NMAX; ++q) v[q] = (q < n) ? e[(int64_t)q * lde + b] : 0ull;
+        for (int q = 0; q < NMAX; ++q) {
+            v[q] = make_ulonglong2(0ull, 0ull);
+            if (q < n) {
+                const uint64_t* src = e + (int64_t)q * lde + 2 * b;
+                if (wide && two) {
+                    v[q] = *reinterpret_cast<const ulonglong2*>(src);
+                } else {
+                    v[q].x = src[0];
+                    if (two) v[q].y = src[1];
+                }
+            }
+        }
         for (int k = 0; k < r; ++k) {
             const u64 row = rows.row[k];
-            u64 acc = 0;
+            ulonglong2 acc = make_ulonglong2(0ull, 0ull);
 #pragma unroll
-            for (int q = 0; q < NMAX; ++q) acc ^= v[q] & (0ull - ((row >> q) & 1ull));
-            s[(int64_t)k * lds_out + b] = acc;
+            for (int q = 0; q < NMAX; ++q) {
+                const u64 m = 0ull - ((row >> q) & 1ull);
+                acc.x ^= v[q].x & m;
+                acc.y ^= v[q].y & m;
+            }
+            uint64_t* dst = s + (int64_t)k * lds_out + 2 * b;
+            if (wide && two) {
+                *reinterpret_cast<ulonglong2*>(dst) = acc;
+            } else {
+                dst[0] = acc.x;
+                if (two) dst[1] = acc.y;
+            }
         }
     }
 }
@@ -531,7 +556,7 @@ int gf2_syndrome_dev(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, i
         if (lde < words || lds < words) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: bit-sliced strides too small");
         SmallRows rows;
         memcpy(rows.row, ck->rows_small, sizeof(rows.row));
-        int64_t blocks = gf2_cdiv(words, 256);
+        int64_t blocks = gf2_cdiv(gf2_cdiv(words, 2), 256);
         if (blocks > 8192) blocks = 8192;
         dim3 grid((unsigned)blocks), block(256);
         GF2_TRY(gf2_prof_begin(ctx, GF2_K_SYNDROME));
