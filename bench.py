@@ -31,7 +31,8 @@ The JSON line also carries
   cpu_baseline  the reference's NumPy path (oracle/cpu_ref.py restatement of css_code.py:728) timed on this
                 host, 1 core, on a bounded sample of the same workload.
   secondary     (rank 0, N = 1) the other syndrome kernel on the same workload, and RREF GB/s
-                (2 * m * ceil(n/64) * 8 bytes / time) for one and for 256 resident 2048 x 4096 matrices.
+                (2 * m * ceil(n/64) * 8 bytes / time) for one and for 256 resident 2048 x 4096 matrices and for one
+                32768 x 65536 matrix.
 """
 import argparse
 import json
@@ -193,24 +194,32 @@ def roofline(path, mean_launch_s, launches):
 
 
 def rref_numbers(ctx):
-    """RREF GB/s = 2 * m * ld * 8 bytes / time on resident random 2048 x 4096 matrices."""
+    """RREF GB/s = 2 * m * ceil(n/64) * 8 bytes / time on resident random matrices: one and 256 of
+    2048 x 4096 (1 MiB each, L2-resident: latency-bound), and one 32768 x 65536 (256 MiB, streamed from HBM)."""
     from quantum_css_codes_amd import _native
     res = {}
-    a = _native.pack_rows(np.random.default_rng(4096).integers(0, 2, (R1, N_QUBITS)).astype(np.uint8))
-    for batch in (1, 256):
+    rng = np.random.default_rng(4096)
+
+    def random_packed(m, n):
+        ld = (n + 63) // 64
+        return (rng.integers(0, 2**63, (m, ld), dtype=np.int64).view(np.uint64) << np.uint64(1)) | \
+            rng.integers(0, 2, (m, ld), dtype=np.int64).view(np.uint64)
+
+    for (m, n, batch, reps) in ((R1, N_QUBITS, 1, 3), (R1, N_QUBITS, 256, 3), (32768, 65536, 1, 1)):
+        a = random_packed(m, n)
         buf = ctx.alloc(batch * a.nbytes)
-        piv, rk = ctx.alloc(batch * R1 * 8), ctx.alloc(batch * 8)
+        piv, rk = ctx.alloc(batch * min(m, n) * 8), ctx.alloc(batch * 8)
         best = None
-        for _ in range(3):
+        for _ in range(reps):
             for b in range(batch):
                 _native.check(_native.lib().gf2_h2d(ctx.handle, buf.ptr + b * a.nbytes, a.ctypes.data, a.nbytes))
             ctx.timer_start()
-            _native.check(_native.lib().gf2_rref_batch_dev(ctx.handle, buf.ptr, batch, R1, N_QUBITS, N_QUBITS // 64,
-                                                           piv.ptr, rk.ptr))
+            _native.check(_native.lib().gf2_rref_batch_dev(ctx.handle, buf.ptr, batch, m, n, a.shape[1], piv.ptr, rk.ptr))
             ms = ctx.timer_stop()
             best = ms if best is None else min(best, ms)
+        assert int(rk.download((batch,), np.int64)[0]) == min(m, n)
         gbs = batch * 2 * a.nbytes / best / 1e6
-        res["2048x4096_x%d" % batch] = {"ms": best, "GB/s": gbs, "frac_hbm_peak": gbs / HBM_PEAK_GBS}
+        res["%dx%d_x%d" % (m, n, batch)] = {"ms": best, "GB/s": gbs, "frac_hbm_peak": gbs / HBM_PEAK_GBS}
         buf.free(), piv.free(), rk.free()
     return res
 

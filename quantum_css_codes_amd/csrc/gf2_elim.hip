@@ -405,6 +405,202 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
 }
 
 
+// The same panel step for matrices with more than 8192 rows: rows are streamed instead of held in registers.  The
+// current panel word and coefficient of every row live in global scratch (wpan, cco); the window is filled through an
+// LDS counter (any unused rows with a bit in an unresolved column will do -- the RREF does not depend on the choice).
+__global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __restrict__ base, int64_t m, int64_t n, int64_t ld,
+                                                                      int64_t pw, int64_t* __restrict__ pivots_base, int64_t cap,
+                                                                      int32_t* __restrict__ pivrow_base, RrefState* __restrict__ states,
+                                                                      unsigned char* __restrict__ used_base, u64* __restrict__ d_base,
+                                                                      u64* __restrict__ snap_base, u64* __restrict__ wpan_base,
+                                                                      u64* __restrict__ cco_base, int32_t* __restrict__ slot_base) {
+    __shared__ u64 VT[2048];
+    __shared__ u64 V[64], csel[64], pword[64], win_w[RB_WIN], win_c[RB_WIN];
+    __shared__ int win_row[RB_WIN], win_piv[RB_WIN], pbit[64], prow_l[64], misc[4];
+    __shared__ int win_count;
+
+    const int64_t mat = blockIdx.x;
+    u64* a = base + mat * m * ld;
+    RrefState* st = states + mat;
+    unsigned char* used = used_base + mat * m;
+    u64* dout = d_base + mat * m;
+    u64* wpan = wpan_base + mat * m;
+    u64* cco = cco_base + mat * m;
+    int32_t* slot_of = slot_base + mat * m;                             // -1, or the row's window slot in this round
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t rank = st->rank;
+    int64_t first_free = st->first_free;
+    if (rank >= m || pw * 64 >= n) {
+        if (tid == 0) st->t = 0;
+        return;
+    }
+    int64_t* pivots = pivots_base ? pivots_base + mat * cap : nullptr;
+    int32_t* pivrow = pivrow_base + mat * cap;
+    const int64_t cols_here = n - pw * 64;
+    const u64 panel_cols = cols_here >= 64 ? ~0ull : ((1ull << cols_here) - 1ull);
+    u64 unresolved = panel_cols;
+    int t = 0;
+    for (int64_t row = tid; row < m; row += RB_THREADS) {               // round 0 state: the matrix itself
+        wpan[row] = a[row * ld + pw];
+        cco[row] = 0;
+        slot_of[row] = -1;
+    }
+    __syncthreads();
+    while (unresolved && t < 64 && rank + t < m) {
+        if (tid == 0) win_count = 0;
+        __syncthreads();
+        for (int64_t r0 = 0; r0 < m; r0 += RB_THREADS) {                // fill the window; stop scanning once it is full
+            const int64_t row = r0 + tid;
+            if (row < m && !used[row] && (wpan[row] & unresolved)) {
+                const int pos = atomicAdd(&win_count, 1);
+                if (pos < RB_WIN) {
+                    slot_of[row] = pos;
+                    win_row[pos] = (int)row;
+                    win_w[pos] = wpan[row];
+                    win_c[pos] = cco[row];
+                    win_piv[pos] = 0;
+                }
+            }
+            __syncthreads();
+            if (win_count >= RB_WIN) break;
+        }
+        const int total = win_count;
+        if (total == 0) break;
+        const int nwin = total < RB_WIN ? total : RB_WIN;
+        if (wave == 0) {
+            u64 ew[2], ec[2];
+            int er[2];
+            bool ep[2] = {false, false};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int idx = lane + 64 * h;
+                const bool live = idx < nwin;
+                ew[h] = live ? win_w[idx] : 0ull;
+                ec[h] = live ? win_c[idx] : 0ull;
+                er[h] = live ? win_row[idx] : -1;
+            }
+            u64 newbits = 0;
+            int tt = t;
+            for (int b = 0; b < 64; ++b) {
+                if (!((unresolved >> b) & 1ull)) continue;
+                if (tt >= 64 || rank + tt >= m) break;
+                const u64 bal0 = __ballot(!ep[0] && ((ew[0] >> b) & 1ull));
+                const u64 bal1 = __ballot(!ep[1] && ((ew[1] >> b) & 1ull));
+                if (!(bal0 | bal1)) continue;
+                const int h = bal0 ? 0 : 1;
+                const int src = __ffsll((long long)(bal0 ? bal0 : bal1)) - 1;
+                const u64 pwd = readlane64(h ? ew[1] : ew[0], src);
+                const u64 pcs = readlane64(h ? ec[1] : ec[0], src);
+                const int prw = __builtin_amdgcn_readlane(h ? er[1] : er[0], src);
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    if (hh == h && lane == src) {
+                        ep[hh] = true;
+                    } else if ((ew[hh] >> b) & 1ull) {
+                        ew[hh] ^= pwd;
+                        ec[hh] |= 1ull << tt;
+                    }
+                }
+                if (lane == 0) {
+                    pword[tt] = pwd;
+                    csel[tt] = pcs;
+                    pbit[tt] = b;
+                    prow_l[tt] = prw;
+                }
+                newbits |= 1ull << b;
+                tt += 1;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int idx = lane + 64 * h;
+                if (idx < nwin) {
+                    win_w[idx] = ew[h];
+                    win_c[idx] = ec[h];
+                    win_piv[idx] = ep[h] ? 1 : 0;
+                }
+            }
+            if (lane == 0) {
+                misc[0] = tt;
+                misc[1] = (int)(unsigned int)newbits;
+                misc[2] = (int)(unsigned int)(newbits >> 32);
+            }
+        }
+        __syncthreads();
+        const int t_new = misc[0];
+        const u64 newbits = ((u64)(unsigned int)misc[2] << 32) | (unsigned int)misc[1];
+        for (int64_t row = tid; row < m; row += RB_THREADS) {
+            const int sl = slot_of[row];
+            if (sl >= 0) {
+                wpan[row] = win_w[sl];
+                cco[row] = win_c[sl];
+                if (win_piv[sl]) used[row] = 1;
+                slot_of[row] = -1;
+            } else {
+                u64 w = wpan[row], c = cco[row];
+#pragma unroll 4
+                for (int p = t; p < t_new; ++p) {
+                    const u64 hit = 0ull - ((w >> pbit[p]) & 1ull);
+                    w ^= pword[p] & hit;
+                    c |= (1ull << p) & hit;
+                }
+                wpan[row] = w;
+                cco[row] = c;
+            }
+        }
+        unresolved &= ~newbits;
+        t = t_new;
+        __syncthreads();
+    }
+    if (unresolved) {
+        const int64_t fc = pw * 64 + (__ffsll((long long)unresolved) - 1);
+        if (fc < first_free) first_free = fc;
+    }
+    if (tid == 0) {
+        st->t = t;
+        st->rank = rank + t;
+        st->untouched = st->first_free < pw * 64 ? st->first_free : pw * 64;
+        st->first_free = first_free;
+    }
+    if (t == 0) return;
+    if (wave == 0 && lane < t) {
+        const u64 resolved = panel_cols & ~unresolved;
+        const int pos = __popcll(resolved & ((1ull << pbit[lane]) - 1ull));
+        pivrow[rank + pos] = prow_l[lane];
+        if (pivots) pivots[rank + pos] = pw * 64 + pbit[lane];
+    }
+    u64* snap = snap_base + mat * 64 * ld;
+    for (int64_t idx = tid; idx < (int64_t)t * ld; idx += RB_THREADS) {
+        const int p = (int)(idx / ld);
+        const int64_t wd = idx - (int64_t)p * ld;
+        snap[idx] = a[(int64_t)prow_l[p] * ld + wd];
+    }
+    if (wave == 0) {
+        u64 v = lane < t ? 1ull << lane : 0ull;
+        const u64 cs = lane < t ? csel[lane] : 0ull;
+        for (int q = 0; q < t; ++q) {
+            const u64 vq = readlane64(v, q);
+            if ((cs >> q) & 1ull) v ^= vq;
+        }
+        V[lane] = v;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 2048; idx += RB_THREADS) {
+        const int g = idx >> 8, vv = idx & 255;
+        u64 x = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x ^= V[8 * g + k] & (0ull - (u64)((vv >> k) & 1));
+        VT[idx] = x;
+    }
+    __syncthreads();
+    for (int64_t row = tid; row < m; row += RB_THREADS) {
+        const u64 c = cco[row];
+        u64 d = 0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) d ^= VT[g * 256 + (int)((c >> (8 * g)) & 255ull)];
+        dout[row] = d;
+    }
+}
+
 // grid (row blocks, column chunks of 64 words, matrices), block 1024, 128 KiB dynamic LDS.
 __global__ __launch_bounds__(RB_THREADS) void rref_update_kernel(u64* __restrict__ base, int64_t m, int64_t ld,
                                                                 int64_t rows_per_wg, const RrefState* __restrict__ states,
@@ -570,8 +766,8 @@ static int launch_eliminate(gf2_ctx* ctx, int mode, u64* a_dev, int64_t batch, i
 
 extern "C" {
 
-// Blocked path: m <= 8192.  Workspace: a copy of the batch for the row gather, pivot-row lists, per-matrix state,
-// used flags, coefficients d and the snapshot of the pivot rows.
+// Blocked path.  Workspace: a copy of the batch for the row gather, pivot-row lists, per-matrix state, used flags,
+// coefficients d, the snapshot of the pivot rows and, for m > 8192, the streamed panel words / coefficients / slots.
 static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld,
                                int64_t* pivots_dev, int64_t cap, int64_t* rank_dev) {
     const int rpt = (int)gf2_cdiv(m, RB_THREADS);
@@ -579,14 +775,19 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
     const size_t abytes = al((size_t)batch * m * ld * 8), pbytes = al((size_t)batch * cap * 4);
     const size_t sbytes = al((size_t)batch * sizeof(RrefState)), ubytes = al((size_t)batch * m);
     const size_t dbytes = al((size_t)batch * m * 8), nbytes = al((size_t)batch * 64 * ld * 8);
-    GF2_TRY(gf2_ws_reserve(ctx, 1, abytes + pbytes + sbytes + ubytes + dbytes + nbytes));
+    const bool stream = rpt > 8;
+    const size_t xbytes = stream ? 2 * dbytes + al((size_t)batch * m * 4) : 0;
+    GF2_TRY(gf2_ws_reserve(ctx, 1, abytes + pbytes + sbytes + ubytes + dbytes + nbytes + xbytes));
     char* q = (char*)ctx->ws[1];
     u64* tmp = (u64*)q; q += abytes;
     int32_t* pivrow = (int32_t*)q; q += pbytes;
     RrefState* states = (RrefState*)q; q += sbytes;
     unsigned char* used = (unsigned char*)q; q += ubytes;
     u64* dco = (u64*)q; q += dbytes;
-    u64* snap = (u64*)q;
+    u64* snap = (u64*)q; q += nbytes;
+    u64* wpan = (u64*)q;
+    u64* cco = (u64*)(q + dbytes);
+    int32_t* slot_of = (int32_t*)(q + 2 * dbytes);
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
     GF2_HIP(hipMemsetAsync(states, 0, sbytes + ubytes, ctx->stream));          // rank = 0, used = 0 ...
     {
@@ -608,7 +809,10 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
 #define GF2_RP_LAUNCH(RPT)                                                                                              \
     hipLaunchKernelGGL((rref_panel_kernel<RPT>), dim3((unsigned)batch), dim3(RB_THREADS), 0, ctx->stream, a_dev, m, n, ld, \
                        pw, pivots_dev, cap, pivrow, states, used, dco, snap)
-        if (rpt <= 1)
+        if (stream)
+            hipLaunchKernelGGL(rref_panel_stream_kernel, dim3((unsigned)batch), dim3(RB_THREADS), 0, ctx->stream, a_dev, m, n,
+                               ld, pw, pivots_dev, cap, pivrow, states, used, dco, snap, wpan, cco, slot_of);
+        else if (rpt <= 1)
             GF2_RP_LAUNCH(1);
         else if (rpt <= 2)
             GF2_RP_LAUNCH(2);
@@ -639,7 +843,7 @@ int gf2_rref_batch_dev(gf2_ctx* ctx, uint64_t* a_dev, int64_t batch, int64_t m, 
     if (m == 0 || n == 0) return gf2_dev_zero(ctx, rank_dev, (size_t)batch * 8);
     if (!a_dev) GF2_FAIL(GF2_E_ARG, "gf2_rref_batch_dev: null matrix");
     const int64_t cap = m < n ? m : n;
-    if (m <= 8 * RB_THREADS && batch <= 65535 && getenv("GF2_RREF_SEQUENTIAL") == nullptr)
+    if (m < 0x7fffffffLL && batch <= 65535 && gf2_cdiv(m, 128) <= 65535 && getenv("GF2_RREF_SEQUENTIAL") == nullptr)
         return launch_rref_blocked(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
     return launch_eliminate(ctx, ELIM_RREF, (u64*)a_dev, batch, m, n, ld, 0, pivots_dev, cap, rank_dev, nullptr, nullptr,
                             nullptr);

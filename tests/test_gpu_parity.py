@@ -514,3 +514,20 @@ def test_small_code_fused_and_pipeline_agree(rm15, steane_h, monkeypatch):
             monkeypatch.delenv("GF2_MC_PIPELINE")
             assert np.array_equal(fused['hist_z'], piped['hist_z']) and np.array_equal(fused['hist_x'], piped['hist_x'])
             assert int(fused['hist_z'].sum()) == 200000
+
+
+def test_rref_more_than_8192_rows_streaming_panel_kernel(ctx):
+    # m > 8192 takes the streamed panel kernel; dependent rows and pivot-free column stripes force extra rounds
+    m, n = 8300, 9100
+    rng = np.random.default_rng(83)
+    a = rng.integers(0, 2, (m, n), dtype=np.uint8)
+    a[5000] = a[1] ^ a[2]
+    a[8299] = a[8298]
+    a[:, 100:164] = 0
+    a[:, 3000] = 0
+    a[:, 9000:9090] = a[:, 0:90]
+    packed = _native.pack_rows(a)
+    want, want_piv, want_rank = c_oracle.rref(packed, m, n)
+    pivots, rank = ctx.rref(packed, m, n)
+    assert rank == want_rank and list(pivots) == list(want_piv)
+    assert np.array_equal(packed, want)
