@@ -30,12 +30,23 @@
 #define ELIM_STATUS_OK 0
 #define ELIM_STATUS_DEPENDENT 1
 
+// State shared by the kernels of the blocked eliminations (one per matrix, in global scratch).
+struct RrefState {                                  // per matrix, in global scratch
+    int64_t rank;                                   // RREF: pivots so far.  normalisation: the next diagonal index
+    int64_t first_free;                             // RREF: first column seen without a pivot
+    int64_t skip_lo, skip_hi;                       // columns [skip_lo, skip_hi) cannot change in the current update
+    int64_t zero_lo, zero_hi;                       // rows [zero_lo, zero_hi) are rebuilt from zero (normalisation)
+    int32_t t;                                      // pivots of the current panel
+    int32_t stalled;                                // normalisation: the panel stopped early, a single step must follow
+};
+
 template <int MODE>
 __global__ __launch_bounds__(ELIM_THREADS) void eliminate_kernel(u64* __restrict__ base, int64_t m, int64_t n,
                                                                  int64_t ld, int64_t offset, int64_t* __restrict__ pivots_base,
                                                                  int64_t pivots_stride, int64_t* __restrict__ rank_base,
                                                                  int64_t* __restrict__ swaps, int64_t* __restrict__ nswaps,
-                                                                 int* __restrict__ status) {
+                                                                 int* __restrict__ status, RrefState* __restrict__ single) {
+    // `single` (normalisation only): do exactly the step single->rank, and only if the blocked panel stalled there
     __shared__ u64 pivot_row[ELIM_MAX_LD];
     __shared__ int found;          // first row (phase A) / first column (swap search), or INT_MAX
     u64* a = base + (int64_t)blockIdx.x * m * ld;
@@ -44,8 +55,14 @@ __global__ __launch_bounds__(ELIM_THREADS) void eliminate_kernel(u64* __restrict
 
     int64_t lead = 0;              // RREF: next pivot row.  NORMALIZE: the diagonal index i.
     int64_t swap_count = 0;
-    const int64_t steps = MODE == ELIM_RREF ? n : m;
-    for (int64_t step = 0; step < steps; ++step) {
+    int64_t step_begin = 0, steps = MODE == ELIM_RREF ? n : m;
+    if (single) {
+        if (!single->stalled || single->rank >= m || status[blockIdx.x] != 0) return;
+        step_begin = single->rank;
+        steps = step_begin + 1;
+        swap_count = nswaps[blockIdx.x];
+    }
+    for (int64_t step = step_begin; step < steps; ++step) {
         const int64_t col = MODE == ELIM_RREF ? step : step + offset;
         if (MODE == ELIM_RREF && lead >= m) break;
         if (MODE == ELIM_NORMALIZE) lead = step;
@@ -141,6 +158,10 @@ __global__ __launch_bounds__(ELIM_THREADS) void eliminate_kernel(u64* __restrict
     if (tid == 0) {
         if (MODE == ELIM_RREF && rank_base) rank_base[blockIdx.x] = lead;
         if (MODE == ELIM_NORMALIZE && nswaps) nswaps[blockIdx.x] = swap_count;
+        if (single) {
+            single->rank = step_begin + 1;
+            single->stalled = 0;
+        }
     }
 }
 
@@ -169,13 +190,6 @@ __global__ __launch_bounds__(ELIM_THREADS) void eliminate_kernel(u64* __restrict
 #define RB_THREADS 1024
 #define RB_WIN 128
 
-struct RrefState {                                  // per matrix, in global scratch
-    int64_t rank;
-    int64_t first_free;                             // first column seen without a pivot
-    int64_t untouched;                              // columns below this cannot change in the current update
-    int32_t t;                                      // pivots of the current panel
-    int32_t pad;
-};
 
 __device__ __forceinline__ u64 readlane64(u64 v, int src) {
     return ((u64)(unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), src) << 32) |
@@ -350,7 +364,8 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
     if (tid == 0) {
         st->t = t;
         st->rank = rank + t;
-        st->untouched = st->first_free < pw * 64 ? st->first_free : pw * 64;   // first_free as it was BEFORE this panel
+        st->skip_lo = 0;
+        st->skip_hi = st->first_free < pw * 64 ? st->first_free : pw * 64;     // first_free as it was BEFORE this panel
         st->first_free = first_free;
     }
     if (t == 0) return;
@@ -558,7 +573,8 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
     if (tid == 0) {
         st->t = t;
         st->rank = rank + t;
-        st->untouched = st->first_free < pw * 64 ? st->first_free : pw * 64;
+        st->skip_lo = 0;
+        st->skip_hi = st->first_free < pw * 64 ? st->first_free : pw * 64;
         st->first_free = first_free;
     }
     if (t == 0) return;
@@ -610,7 +626,7 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_kernel(u64* __restrict
     const RrefState st = states[mat];
     const int t = st.t;
     const int64_t cw0 = (int64_t)blockIdx.y * 64;
-    if (t == 0 || (cw0 + 64) * 64 <= st.untouched) return;
+    if (t == 0 || (cw0 * 64 >= st.skip_lo && (cw0 + 64) * 64 <= st.skip_hi)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc_n = ld - cw0 < 64 ? (int)(ld - cw0) : 64;
     const u64* snap = snap_base + mat * 64 * ld;
@@ -644,7 +660,7 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_kernel(u64* __restrict
     __syncthreads();
     u64* a = base + mat * m * ld;
     const u64* dd = d_base + mat * m;
-    const bool word_live = lane < wc_n && (cw0 + lane + 1) * 64 > st.untouched;
+    const bool word_live = lane < wc_n && !((cw0 + lane) * 64 >= st.skip_lo && (cw0 + lane + 1) * 64 <= st.skip_hi);
     // T is the kernel's only LDS, so it starts at LDS address 0: an entry is addressed as (lane*8 [+64 KiB]) +
     // nibble*512 (scalar) + an immediate below 64 KiB
     typedef const __attribute__((address_space(3))) u64* lds_u64_ptr;
@@ -656,8 +672,9 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_kernel(u64* __restrict
 #pragma unroll
         for (int u = 0; u < 8; ++u) {                                  // 8 rows' loads in flight
             const int64_t row = r0 + (int64_t)u * NW;
+            const bool from_zero = row >= st.zero_lo && row < st.zero_hi;     // uniform: rebuilt rows start from 0
             d[u] = row < row_end ? readlane64(dd[row < row_end ? row : r0], 0) : 0ull;
-            x[u] = (d[u] && word_live) ? a[row * ld + cw0 + lane] : 0ull;
+            x[u] = (d[u] && word_live && !from_zero) ? a[row * ld + cw0 + lane] : 0ull;
         }
 #pragma unroll 1
         for (int g = 0; g < 16; ++g) {                                 // groups outside, rows inside: 8 reads in flight
@@ -672,6 +689,159 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_kernel(u64* __restrict
         for (int u = 0; u < 8; ++u) {
             const int64_t row = r0 + (int64_t)u * NW;
             if (d[u] && word_live) a[row * ld + cw0 + lane] = x[u];
+        }
+    }
+}
+
+// ---- blocked normalisation (css_code.py:809-836), bit-exact ------------------------------------------------------------
+//
+// The reference adds the first odd row at or below the diagonal INTO the diagonal row (never swaps rows) and clears the
+// column in every other row; when no row has the bit it swaps in the first odd column of the diagonal row's current
+// state.  The outcome depends on that order, so the blocked form replays exactly those
+// operations, regrouped: steps i0 .. i0+63 form a panel on the 64 columns c0 = i0+offset ..; one wavefront simulates
+// them on a window of the rows i0 .. i0+127 in position order (the donor of step i is the first window entry at or after
+// the diagonal with the bit set).  With P_p the vector the reference adds to the other rows at step p,
+//     P_p = B_p ^ sum_{q<p} csel_p[q] P_q,   B_p = old_{i0+p} ^ [diagonal was even] old_{donor_p},
+// every other row ends as old_j ^ (c_j . V) . B and diagonal row p as (c_p . V) . B with c_p = {p} + later pivots that
+// hit it -- the same trailing update as the RREF, rebuilt rows starting from zero.  When the window holds no donor for
+// a step (the donor is further down, or a column swap is due) the panel stops there, its steps are applied, and that one
+// step is done by the sequential kernel on the materialised matrix.
+template <int RPT>
+__global__ __launch_bounds__(RB_THREADS) void norm_panel_kernel(u64* __restrict__ a, int64_t r, int64_t n, int64_t ld,
+                                                               int64_t offset, RrefState* __restrict__ st,
+                                                               const int* __restrict__ status, u64* __restrict__ dout,
+                                                               u64* __restrict__ snap) {
+    __shared__ u64 VT[2048];
+    __shared__ u64 V[64], csel[64], pword[64], win_w[RB_WIN], win_c[RB_WIN];
+    __shared__ int donor[64], misc[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i0 = st->rank;
+    if (i0 >= r || status[0] != 0) {
+        if (tid == 0) {
+            st->t = 0;
+            st->stalled = 0;
+        }
+        return;
+    }
+    const int64_t c0 = i0 + offset, cw = c0 >> 6;
+    const int sh = (int)(c0 & 63);
+    const int steps = r - i0 < 64 ? (int)(r - i0) : 64;
+    const u64 stepmask = steps >= 64 ? ~0ull : ((1ull << steps) - 1ull);
+
+    u64 w[RPT], c[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int64_t row = tid + (int64_t)RB_THREADS * k;
+        w[k] = 0;
+        c[k] = 0;
+        if (row < r) {
+            u64 v = a[row * ld + cw] >> sh;
+            if (sh && cw + 1 < ld) v |= a[row * ld + cw + 1] << (64 - sh);
+            w[k] = v & stepmask;
+            if (row >= i0 && row < i0 + RB_WIN) win_w[row - i0] = w[k];
+        }
+    }
+    if (tid < RB_WIN && i0 + tid >= r) win_w[tid] = 0;
+    __syncthreads();
+    if (wave == 0) {
+        u64 ew[2] = {win_w[lane], win_w[lane + 64]}, ec[2] = {0ull, 0ull};
+        int tt = 0;
+        for (int sidx = 0; sidx < steps; ++sidx) {
+            const u64 bal0 = __ballot(lane >= sidx && ((ew[0] >> sidx) & 1ull));
+            const u64 bal1 = __ballot((ew[1] >> sidx) & 1ull);
+            if (!(bal0 | bal1)) break;                                 // no donor inside the window
+            const int h = bal0 ? 0 : 1;
+            const int src = __ffsll((long long)(bal0 ? bal0 : bal1)) - 1;
+            u64 pwd = readlane64(ew[0], sidx), pcs = readlane64(ec[0], sidx);
+            int dn = -1;
+            if (!(h == 0 && src == sidx)) {                             // diagonal entry is even: add the donor
+                pwd ^= readlane64(h ? ew[1] : ew[0], src);
+                pcs ^= readlane64(h ? ec[1] : ec[0], src);
+                dn = (int)(i0 + src + 64 * h);
+            }
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                if (hh == 0 && lane == sidx) {
+                    ew[0] = pwd;
+                    ec[0] = 1ull << sidx;
+                } else if ((ew[hh] >> sidx) & 1ull) {
+                    ew[hh] ^= pwd;
+                    ec[hh] |= 1ull << sidx;
+                }
+            }
+            if (lane == 0) {
+                pword[sidx] = pwd;
+                csel[sidx] = pcs;
+                donor[sidx] = dn;
+            }
+            tt += 1;
+        }
+        win_w[lane] = ew[0];
+        win_w[lane + 64] = ew[1];
+        win_c[lane] = ec[0];
+        win_c[lane + 64] = ec[1];
+        if (lane == 0) misc[0] = tt;
+    }
+    __syncthreads();
+    const int t = misc[0];
+    if (tid == 0) {
+        st->t = t;
+        st->stalled = t < steps ? 1 : 0;
+        st->rank = i0 + t;
+        st->skip_lo = offset;
+        st->skip_hi = c0;
+        st->zero_lo = i0;
+        st->zero_hi = i0 + t;
+    }
+    if (t == 0) return;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int64_t row = tid + (int64_t)RB_THREADS * k;
+        if (row >= i0 && row < i0 + RB_WIN) {
+            c[k] = win_c[row - i0];
+        } else {
+#pragma unroll 4
+            for (int p = 0; p < t; ++p) {
+                const u64 hit = 0ull - ((w[k] >> p) & 1ull);
+                w[k] ^= pword[p] & hit;
+                c[k] |= (1ull << p) & hit;
+            }
+        }
+    }
+    // B_p = old diagonal row (+ old donor row)
+    for (int64_t idx = tid; idx < (int64_t)t * ld; idx += RB_THREADS) {
+        const int p = (int)(idx / ld);
+        const int64_t wd = idx - (int64_t)p * ld;
+        u64 v = a[(i0 + p) * ld + wd];
+        if (donor[p] >= 0) v ^= a[(int64_t)donor[p] * ld + wd];
+        snap[idx] = v;
+    }
+    if (wave == 0) {
+        u64 v = lane < t ? 1ull << lane : 0ull;
+        const u64 cs = lane < t ? csel[lane] : 0ull;
+        for (int q = 0; q < t; ++q) {
+            const u64 vq = readlane64(v, q);
+            if ((cs >> q) & 1ull) v ^= vq;
+        }
+        V[lane] = v;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 2048; idx += RB_THREADS) {
+        const int g = idx >> 8, vv = idx & 255;
+        u64 x = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x ^= V[8 * g + k] & (0ull - (u64)((vv >> k) & 1));
+        VT[idx] = x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int64_t row = tid + (int64_t)RB_THREADS * k;
+        if (row < r) {
+            u64 d = 0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) d ^= VT[g * 256 + (int)((c[k] >> (8 * g)) & 255ull)];
+            dout[row] = d;
         }
     }
 }
@@ -755,10 +925,12 @@ static int launch_eliminate(gf2_ctx* ctx, int mode, u64* a_dev, int64_t batch, i
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
     if (mode == ELIM_RREF)
         hipLaunchKernelGGL(eliminate_kernel<ELIM_RREF>, dim3((unsigned)batch), dim3(ELIM_THREADS), 0, ctx->stream, a_dev, m, n,
-                           ld, offset, pivots_dev, pivots_stride, rank_dev, swaps_dev, nswaps_dev, status_dev);
+                           ld, offset, pivots_dev, pivots_stride, rank_dev, swaps_dev, nswaps_dev, status_dev,
+                           (RrefState*)nullptr);
     else
         hipLaunchKernelGGL(eliminate_kernel<ELIM_NORMALIZE>, dim3((unsigned)batch), dim3(ELIM_THREADS), 0, ctx->stream, a_dev,
-                           m, n, ld, offset, pivots_dev, pivots_stride, rank_dev, swaps_dev, nswaps_dev, status_dev);
+                           m, n, ld, offset, pivots_dev, pivots_stride, rank_dev, swaps_dev, nswaps_dev, status_dev,
+                           (RrefState*)nullptr);
     GF2_TRY(gf2_prof_end(ctx));
     GF2_HIP(hipGetLastError());
     return GF2_OK;
@@ -792,7 +964,7 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
     GF2_HIP(hipMemsetAsync(states, 0, sbytes + ubytes, ctx->stream));          // rank = 0, used = 0 ...
     {
         std::vector<RrefState> init((size_t)batch);
-        for (auto& st : init) { st.rank = 0; st.first_free = n; st.untouched = 0; st.t = 0; st.pad = 0; }
+        for (auto& st : init) { memset(&st, 0, sizeof(st)); st.first_free = n; }
         GF2_HIP(hipMemcpyAsync(states, init.data(), (size_t)batch * sizeof(RrefState), hipMemcpyHostToDevice, ctx->stream));
         GF2_HIP(hipStreamSynchronize(ctx->stream));                              // init lives on the host stack
     }
@@ -894,8 +1066,56 @@ int gf2_normalize_dev(gf2_ctx* ctx, uint64_t* h_dev, int64_t r, int64_t n, int64
     GF2_TRY(gf2_dev_zero(ctx, status_dev, 4));
     if (r == 0) return GF2_OK;
     if (!h_dev) GF2_FAIL(GF2_E_ARG, "gf2_normalize_dev: null matrix");
-    return launch_eliminate(ctx, ELIM_NORMALIZE, (u64*)h_dev, 1, r, n, ld, offset, nullptr, 0, nullptr, swaps_dev,
-                            nswaps_dev, status_dev);
+    if (r > 8 * RB_THREADS || ld > ELIM_MAX_LD || getenv("GF2_NORMALIZE_SEQUENTIAL") != nullptr)
+        return launch_eliminate(ctx, ELIM_NORMALIZE, (u64*)h_dev, 1, r, n, ld, offset, nullptr, 0, nullptr, swaps_dev,
+                                nswaps_dev, status_dev);
+    // blocked: panel -> update -> (single sequential step if the panel stalled); the host looks at the state every 8 rounds
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t sbytes = al(sizeof(RrefState)), dbytes = al((size_t)r * 8), nbytes = al((size_t)64 * ld * 8);
+    GF2_TRY(gf2_ws_reserve(ctx, 1, sbytes + dbytes + nbytes));
+    char* q = (char*)ctx->ws[1];
+    RrefState* st = (RrefState*)q; q += sbytes;
+    u64* dco = (u64*)q; q += dbytes;
+    u64* snap = (u64*)q;
+    GF2_HIP(hipMemsetAsync(st, 0, sizeof(RrefState), ctx->stream));
+    static bool attr_done = false;
+    if (!attr_done) {
+        GF2_HIP(hipFuncSetAttribute((const void*)rref_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        attr_done = true;
+    }
+    const int rpt = (int)gf2_cdiv(r, RB_THREADS);
+    const int64_t rows_per_wg = gf2_cdiv(ld, 64) >= 8 ? 256 : 128;
+    const dim3 ugrid((unsigned)gf2_cdiv(r, rows_per_wg), (unsigned)gf2_cdiv(ld, 64), 1);
+    GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
+    for (int64_t round = 0;; ++round) {
+#define GF2_NP_LAUNCH(RPT)                                                                                              \
+    hipLaunchKernelGGL((norm_panel_kernel<RPT>), dim3(1), dim3(RB_THREADS), 0, ctx->stream, (u64*)h_dev, r, n, ld, offset, \
+                       st, status_dev, dco, snap)
+        if (rpt <= 1)
+            GF2_NP_LAUNCH(1);
+        else if (rpt <= 2)
+            GF2_NP_LAUNCH(2);
+        else if (rpt <= 4)
+            GF2_NP_LAUNCH(4);
+        else
+            GF2_NP_LAUNCH(8);
+#undef GF2_NP_LAUNCH
+        hipLaunchKernelGGL(rref_update_kernel, ugrid, dim3(RB_THREADS), 128 * 1024, ctx->stream, (u64*)h_dev, r, ld, rows_per_wg,
+                           st, dco, snap);
+        hipLaunchKernelGGL(eliminate_kernel<ELIM_NORMALIZE>, dim3(1), dim3(ELIM_THREADS), 0, ctx->stream, (u64*)h_dev, r, n, ld,
+                           offset, (int64_t*)nullptr, (int64_t)0, (int64_t*)nullptr, swaps_dev, nswaps_dev, status_dev, st);
+        GF2_HIP(hipGetLastError());
+        if ((round & 7) == 7 || round >= r) {
+            RrefState host;
+            int status = 0;
+            GF2_HIP(hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+            GF2_HIP(hipMemcpyAsync(&status, status_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+            GF2_HIP(hipStreamSynchronize(ctx->stream));
+            if (status != 0 || (host.rank >= r && !host.stalled)) break;
+        }
+    }
+    GF2_TRY(gf2_prof_end(ctx));
+    return GF2_OK;
 }
 
 int gf2_normalize(gf2_ctx* ctx, uint64_t* h, int64_t r, int64_t n, int64_t ld, int64_t offset, int64_t* swaps_out,
