@@ -634,7 +634,22 @@ int gf2_syndrome_batch(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, in
     if (rc == GF2_OK) rc = gf2_dev_alloc(ctx, (size_t)s_rows * lds * 8, (void**)&s_dev);
     if (rc == GF2_OK) rc = gf2_h2d(ctx, e_dev, e, (size_t)e_words * 8);
     if (rc == GF2_OK) rc = gf2_dev_zero(ctx, s_dev, (size_t)s_rows * lds * 8);
-    if (rc == GF2_OK) rc = gf2_syndrome_dev(ctx, ck, e_dev, batch, lde, layout, s_dev, lds);
+    // Sample-major host errors: their density is known for free here, so sparse batches (at most ~160 set bits per
+    // error) go to the column kernel, everything else to the table kernel.
+    bool sparse = false;
+    if (rc == GF2_OK && layout == GF2_LAYOUT_SAMPLE_MAJOR && ck->ht_dev) {
+        const int64_t probe = batch < 4096 ? batch : 4096, step = batch / probe;
+        int64_t bits = 0;
+        for (int64_t i = 0; i < probe; ++i)
+            for (int64_t w = 0; w < gf2_words(n); ++w) bits += __builtin_popcountll(e[i * step * lde + w]);
+        sparse = (double)bits / (double)probe <= 160.0;
+    }
+    if (rc == GF2_OK) {
+        if (sparse)
+            rc = gf2_syndrome_sparse_dev(ctx, ck, e_dev, batch, lde, s_dev, lds, nullptr, 0);
+        else
+            rc = gf2_syndrome_dev(ctx, ck, e_dev, batch, lde, layout, s_dev, lds);
+    }
     if (rc == GF2_OK) rc = gf2_d2h(ctx, s_out, s_dev, (size_t)s_rows * lds * 8);
     gf2_dev_free(ctx, e_dev);
     gf2_dev_free(ctx, s_dev);

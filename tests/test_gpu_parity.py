@@ -531,3 +531,15 @@ def test_rref_more_than_8192_rows_streaming_panel_kernel(ctx):
     pivots, rank = ctx.rref(packed, m, n)
     assert rank == want_rank and list(pivots) == list(want_piv)
     assert np.array_equal(packed, want)
+
+
+def test_host_syndrome_batch_routes_sparse_and_dense(ctx):
+    # gf2_syndrome_batch picks the column kernel for sparse host errors and the table kernel otherwise: same answers
+    r, n, batch = 300, 2000, 5000
+    rng = np.random.default_rng(300)
+    h = _native.pack_rows(rng.integers(0, 2, (r, n)))
+    for density in (0.002, 0.05, 0.5):
+        em = (rng.random((batch, n)) < density).astype(np.uint8)
+        em[::7] = 0
+        e = _native.pack_rows(em)
+        assert np.array_equal(ctx.syndrome_batch(h, r, n, e, batch), c_oracle.syndrome_batch(h, r, n, e, batch))
