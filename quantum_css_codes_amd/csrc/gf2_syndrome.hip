@@ -75,21 +75,22 @@ __global__ void build_tables_kernel(const uint64_t* __restrict__ h, int64_t r, i
 
 // ---- Four-Russians syndrome kernel ------------------------------------------------------------------------
 
-#define SYN_THREADS 1024
+#define SYN_THREADS 768                             // 12 wavefronts; two workgroups per CU -> 6 waves/SIMD, 80 VGPRs
 #define SYN_WAVES (SYN_THREADS / 64)
-#define SYN_TPW 4                                   // tiles (of 64 samples) per wave
-#define SYN_BLOCK_TILES (SYN_WAVES * SYN_TPW)       // 64 tiles = 4096 samples per workgroup
+#define SYN_TPW 5                                   // tiles (of 64 samples) per wave
+#define SYN_BLOCK_TILES (SYN_WAVES * SYN_TPW)       // 60 tiles = 3840 samples per workgroup
 #define SYN_CHUNK_PAIRS 19                          // 19 pairs x 4 KiB = 76 KiB of LDS per staging, 2 workgroups/CU
+#define SYN_UNROLL_PAIRS 16                         // pairs whose table offsets fit the 16-bit DS immediate
 
 typedef const __attribute__((address_space(3))) u64* lds_u64_ptr;
 
 // The kernel has no static LDS, so its dynamic LDS starts at LDS address 0 and a table entry is addressed by
-// its plain byte offset: nibble*8 in a VGPR plus an instruction immediate (at most 65535; pairs 16.. add 64 KiB
-// to the VGPR instead).
+// its plain byte offset: nibble*8 in a VGPR plus an instruction immediate (at most 65535, i.e. the first 16 pairs;
+// the up to 3 pairs beyond that take a plain loop with the pair's base added to the VGPR).
 template <int OFFSET>
 __device__ __forceinline__ u64 lds_entry(unsigned int nib8) {
-    if (OFFSET < 65536 - 8) return *(lds_u64_ptr)(uintptr_t)(nib8 + (unsigned)OFFSET);
-    return *(lds_u64_ptr)(uintptr_t)((nib8 | 0x10000u) + (unsigned)(OFFSET - 65536));
+    static_assert(OFFSET >= 0 && OFFSET <= 65536 - 8, "table offset must fit the DS immediate");
+    return *(lds_u64_ptr)(uintptr_t)(nib8 + (unsigned)OFFSET);
 }
 
 // (byte B of x) & mask in one VALU op (SDWA byte select).
@@ -121,21 +122,26 @@ __device__ __forceinline__ u64 lookup_dword(const unsigned int d, u64 a, unsigne
 // 32 table reads for the 32 nibbles of one 16-byte error piece; BASE = byte offset of the pair's tables.
 template <int BASE>
 __device__ __forceinline__ u64 lookup_piece(const uint4 v, u64 a, unsigned int mask78) {
+    // 8 reads in flight at a time: with 32 wavefronts per CU that is enough to keep the LDS busy, and it keeps the
+    // kernel inside its 64-VGPR budget without spilling
     a = lookup_dword<BASE + 0 * 1024>(v.x, a, mask78);
+    __builtin_amdgcn_sched_barrier(0);
     a = lookup_dword<BASE + 1 * 1024>(v.y, a, mask78);
+    __builtin_amdgcn_sched_barrier(0);
     a = lookup_dword<BASE + 2 * 1024>(v.z, a, mask78);
+    __builtin_amdgcn_sched_barrier(0);
     a = lookup_dword<BASE + 3 * 1024>(v.w, a, mask78);
     return a;
 }
 
-// Pairs t = 0 .. np-1 of the staged chunk, fully unrolled so every table offset is an immediate.  The piece
+// Pairs t = 0 .. min(np, 16)-1 of the staged chunk, fully unrolled so every table offset is an immediate.  The piece
 // of pair t+1 is requested before the 32 lookups of pair t (explicit one-deep prefetch; the scheduling barrier
 // keeps the compiler from hoisting all 19 loads and spilling).
 template <int T>
 struct PairUnroll {
     static __device__ __forceinline__ void run(const uint4* __restrict__ tile, int lane, const int32_t* __restrict__ pairs,
                                                int np, const uint4 cur, u64& a, unsigned int mask78) {
-        constexpr int t = SYN_CHUNK_PAIRS - T;
+        constexpr int t = SYN_UNROLL_PAIRS - T;
         uint4 next = cur;
         if (t + 1 < np) next = tile[(int64_t)pairs[t + 1] * 64 + lane];
         __builtin_amdgcn_sched_barrier(0);
@@ -152,7 +158,7 @@ struct PairUnroll<0> {
 // Blocks are dealt round-robin over the 8 XCDs, so blocks b and b+8 share an L2.  The blocks of one XCD get
 // the same sample chunk and different slabs: the chunk's errors come from HBM once per XCD and are served
 // from its L2 to the other slabs.
-__global__ __launch_bounds__(SYN_THREADS, 8) void syndrome_tiled_kernel(
+__global__ __launch_bounds__(SYN_THREADS, 6) void syndrome_tiled_kernel(
     const u64* __restrict__ tables, const int32_t* __restrict__ pair_list, const int32_t* __restrict__ npairs,
     int64_t max_pairs, int64_t slabs, int64_t r, int64_t ident_off, const uint64_t* __restrict__ e, int64_t batch,
     int64_t ldt, uint64_t* __restrict__ s, int64_t sstride, int64_t chunks) {
@@ -192,23 +198,43 @@ __global__ __launch_bounds__(SYN_THREADS, 8) void syndrome_tiled_kernel(
         for (int k = 0; k < SYN_TPW; ++k) {
             const int64_t tile = tile0 + (int64_t)k * SYN_WAVES;
             if (tile >= tiles) break;
-            const int64_t sample = tile * 64 + lane;
             const uint64_t* tbase = e + tile * 64 * ldt;
             u64 a = 0;
-            if (p0) {
-                if (sample < batch) a = s[slab * sstride + sample];
-            } else if (ident_off >= 0) {
-                const uint64_t* lp = tbase + lane * 2;
-                a = lp[(iw0 >> 1) * 128 + (iw0 & 1)] >> ish;
-                if (ish && iw0 + 1 < ldt) a |= lp[((iw0 + 1) >> 1) * 128 + ((iw0 + 1) & 1)] << (64 - ish);
-                a &= imask;
-            }
             if (np > 0) {
                 const uint4* tptr = reinterpret_cast<const uint4*>(tbase);
                 const uint4 first = tptr[(int64_t)pairs[p0] * 64 + lane];
-                PairUnroll<SYN_CHUNK_PAIRS>::run(tptr, lane, pairs + p0, np, first, a, mask78);
+                const int npu = np < SYN_UNROLL_PAIRS ? np : SYN_UNROLL_PAIRS;
+                PairUnroll<SYN_UNROLL_PAIRS>::run(tptr, lane, pairs + p0, npu, first, a, mask78);
+#pragma unroll 1
+                for (int t = SYN_UNROLL_PAIRS; t < np; ++t) {              // the few pairs beyond the immediate range
+                    const uint4 v = tptr[(int64_t)pairs[p0 + t] * 64 + lane];
+                    const unsigned int d[4] = {v.x, v.y, v.z, v.w};
+                    const unsigned int base = (unsigned int)t * 4096u;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned int lo = d[k] << 3, hi = d[k] >> 1;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            a ^= *(lds_u64_ptr)(uintptr_t)(base + (k * 8 + 2 * b) * 128 + ((lo >> (8 * b)) & 0x78u));
+                            a ^= *(lds_u64_ptr)(uintptr_t)(base + (k * 8 + 2 * b + 1) * 128 + ((hi >> (8 * b)) & 0x78u));
+                        }
+                    }
+                }
             }
-            if (sample < batch) s[slab * sstride + sample] = a;      // slab-major: 512 B per wavefront store
+            // everything that is only needed once per tile comes after the lookups, so that no 64-bit address or
+            // mask has to stay live across the unrolled body (spills there cost HBM traffic through scratch)
+            const int64_t sample = tile * 64 + lane;
+            if (sample < batch) {
+                if (p0) {
+                    a ^= s[slab * sstride + sample];
+                } else if (ident_off >= 0) {
+                    const uint64_t* lp = tbase + lane * 2;
+                    u64 idv = lp[(iw0 >> 1) * 128 + (iw0 & 1)] >> ish;
+                    if (ish && iw0 + 1 < ldt) idv |= lp[((iw0 + 1) >> 1) * 128 + ((iw0 + 1) & 1)] << (64 - ish);
+                    a ^= idv & imask;
+                }
+                s[slab * sstride + sample] = a;                          // slab-major: 512 B per wavefront store
+            }
         }
         p0 += SYN_CHUNK_PAIRS;
     } while (p0 < np_total);
