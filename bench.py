@@ -227,8 +227,8 @@ def rref_numbers(ctx):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch-log2", type=int, default=20, help="samples per GPU per step (2^k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other syndrome kernel and the RREF timings")
@@ -276,6 +276,9 @@ def main():
 
     for _ in range(args.warmup):
         path.step()
+    if world > 1:
+        # the first collective sets up the communicator: keep that out of the timed region
+        all_reduce_histograms([path.hz.download((R1 + 1,), np.uint64), path.hx.download((R2 + 1,), np.uint64)])
     path.hz.zero(), path.hx.zero()
     ctx.profile(True)
     ctx.profile_reset()

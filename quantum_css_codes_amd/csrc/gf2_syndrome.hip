@@ -298,6 +298,30 @@ __global__ __launch_bounds__(256) void syndrome_small_kernel(SmallRows rows, int
                                                              int64_t batch, int64_t lde,
                                                              uint64_t* __restrict__ s, int64_t lds_out) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (lde == 1 && lds_out == 1 && ((((uintptr_t)e) | ((uintptr_t)s)) & 15) == 0) {
+        // one word per sample on both sides: two samples per lane, 16-byte accesses
+        const int64_t pairs = (batch + 1) >> 1;
+        for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < pairs; p += stride) {
+            const bool two = 2 * p + 1 < batch;
+            ulonglong2 v;
+            if (two) {
+                v = reinterpret_cast<const ulonglong2*>(e)[p];
+            } else {
+                v.x = e[2 * p];
+                v.y = 0;
+            }
+            ulonglong2 out = make_ulonglong2(0ull, 0ull);
+            for (int k = 0; k < r; ++k) {
+                out.x |= (u64)(__popcll(rows.row[k] & v.x) & 1) << k;
+                out.y |= (u64)(__popcll(rows.row[k] & v.y) & 1) << k;
+            }
+            if (two)
+                reinterpret_cast<ulonglong2*>(s)[p] = out;
+            else
+                s[2 * p] = out.x;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < batch; i += stride) {
         const u64 v = e[i * lde];
         u64 out = 0;
