@@ -223,33 +223,79 @@ def syndrome_table(parity_check, max_weight=None):
     return it along with a lookup table from syndromes (as bin_matrix.vec_to_int keys) to error vectors
     of weight at most t (css_code.py:715-735).
 
-    Each weight class is enumerated in bin_matrix.weight_w_vectors order and its syndromes computed in
-    one batch on the GPU; a class containing a syndrome already seen (in an earlier class or earlier in
-    the same class) ends the search and is discarded as a whole, exactly as the reference's loop does.
-    max_weight [build-defined] caps the search for large codes, where the reference cannot finish.
+    Each weight class is enumerated in bin_matrix.weight_w_vectors order, in chunks, and its syndromes are
+    computed on the GPU; a class containing a syndrome already seen (in an earlier class or earlier in the
+    same class) ends the search and is discarded as a whole, exactly as the reference's loop does.  Keys are
+    formed and compared as machine words when r <= 63 (the reference's own keys are only meaningful there,
+    SURVEY.md 7.3 item 2) and as Python ints beyond.  max_weight [build-defined] caps the search for large
+    codes, where the reference cannot finish.
     """
     parity_check = np.asarray(parity_check)
     r, n = parity_check.shape
     ctx = _native.default_context()
     packed_h = _native.pack_rows(parity_check)
+    chk = ctx.check_create(packed_h, r, n) if r else None
     table = {}
+    seen = np.zeros(0, dtype=np.uint64)                       # keys of `table`, sorted (r <= 63)
+    chunk_size = 1 << 18
+    weights = (np.uint64(1) << np.arange(r - 1, -1, -1, dtype=np.uint64)) if 0 < r <= 63 else None
     for w in range(n + 1):
         if max_weight is not None and w > max_weight:
             return max_weight, table
-        supports = bin_matrix.weight_w_supports(n, w)
-        count = supports.shape[0]
-        errors = np.zeros((count, n), dtype=np.uint8)
-        if w:
-            errors[np.arange(count)[:, None], supports] = 1
-        syndromes = _native.unpack_rows(ctx.syndrome_batch(packed_h, r, n, _native.pack_rows(errors), count), r)
-        keys = [bin_matrix.vec_to_int(row) for row in syndromes]
-        layer = {}
-        for key, err in zip(keys, errors):
-            if key in table or key in layer:
-                return w - 1, table
-            layer[key] = err.astype('int')
-        table = {**table, **layer}
+        layer_keys, layer_errs = [], []
+        layer_seen = np.zeros(0, dtype=np.uint64)             # keys of this weight class so far (r <= 63)
+        layer_seen_big = set()                                # the same as Python ints (r > 63)
+        combos = itertools.combinations(range(n), w)
+        while True:
+            batch = list(itertools.islice(combos, chunk_size))
+            count = len(batch)
+            if count == 0:
+                break
+            supports = np.array(batch, dtype=np.int64).reshape(count, w)
+            errors = np.zeros((count, n), dtype=np.uint8)
+            if w:
+                errors[np.arange(count)[:, None], supports] = 1
+            if r:
+                syn = _native.unpack_rows(_syndromes_of(ctx, chk, packed_h, r, n, _native.pack_rows(errors), count), r,
+                                          dtype=np.uint8)
+            else:
+                syn = np.zeros((count, 0), dtype=np.uint8)
+            if weights is not None or r == 0:
+                keys = (syn.astype(np.uint64) @ weights) if r else np.zeros(count, dtype=np.uint64)
+                collide = (np.unique(keys).size != count or np.isin(keys, seen).any() or
+                           np.isin(keys, layer_seen).any())
+                if collide:
+                    return w - 1, table
+                layer_seen = np.union1d(layer_seen, keys)
+                layer_keys.extend(int(k) for k in keys)
+            else:
+                keys = [bin_matrix.vec_to_int(row) for row in syn]
+                fresh = set(keys)
+                if len(fresh) != count or any(k in table for k in keys) or not fresh.isdisjoint(layer_seen_big):
+                    return w - 1, table
+                layer_seen_big |= fresh
+                layer_keys.extend(keys)
+            layer_errs.append(errors)
+        errs = np.concatenate(layer_errs) if layer_errs else np.zeros((0, n), dtype=np.uint8)
+        for key, err in zip(layer_keys, errs):
+            table[key] = err.astype('int')
+        if weights is not None:
+            seen = np.union1d(seen, layer_seen)
     return n, table
+
+
+def _syndromes_of(ctx, chk, packed_h, r, n, packed_e, count):
+    """Packed syndromes (count x words(r)) of packed errors through a prepared check."""
+    if chk.handle is None:
+        return ctx.syndrome_batch(packed_h, r, n, packed_e, count)
+    lde, lds = packed_e.shape[1], max(1, _native.words_for(r))
+    e_buf = ctx.alloc(packed_e.nbytes).upload(packed_e)
+    s_buf = ctx.alloc(count * lds * 8).zero()
+    ctx.syndrome_dev(chk, e_buf, count, lde, s_buf, lds)
+    out = s_buf.download((count, lds), "<u8")
+    e_buf.free()
+    s_buf.free()
+    return out
 
 
 def swap_columns(mat, indices):

@@ -543,3 +543,28 @@ def test_host_syndrome_batch_routes_sparse_and_dense(ctx):
         em[::7] = 0
         e = _native.pack_rows(em)
         assert np.array_equal(ctx.syndrome_batch(h, r, n, e, batch), c_oracle.syndrome_batch(h, r, n, e, batch))
+
+
+def test_syndrome_table_mid_size_codes_vs_oracle():
+    # tables of mid-size codes (the reference's Python loop takes minutes here)
+    rng = np.random.default_rng(23)
+    # a [23, 12] random code: r = 11
+    h = rng.integers(0, 2, (11, 23))
+    t, table = css_code.syndrome_table(h)
+    want_t, want = cpu_ref.syndrome_table(h)
+    assert t == want_t and list(table.keys()) == [int(k) for k in want.keys()]
+    for k in table:
+        assert np.array_equal(table[k], want[k])
+    # r > 63: keys are exact Python ints; capped search
+    h = rng.integers(0, 2, (70, 80))
+    t, table = css_code.syndrome_table(h, max_weight=1)
+    want_t, want = cpu_ref.syndrome_table(np.array(h, dtype=object), max_weight=1)
+    assert t == want_t and list(table.keys()) == [int(k) for k in want.keys()] and len(table) == 81
+    # chunked enumeration across several GPU batches: n = 60, weight <= 4 is 523k vectors; compare with a direct count
+    h = rng.integers(0, 2, (30, 60))
+    t, table = css_code.syndrome_table(h, max_weight=4)
+    assert 0 <= t <= 4
+    from math import comb
+    assert len(table) == sum(comb(60, w) for w in range(t + 1))
+    for key, err in list(table.items())[::5000]:
+        assert key == bin_matrix.vec_to_int(np.mod(h @ err, 2))
