@@ -125,11 +125,9 @@ __device__ __forceinline__ u64 lookup_piece(const uint4 v, u64 a, unsigned int m
     // 8 reads in flight at a time: with 32 wavefronts per CU that is enough to keep the LDS busy, and it keeps the
     // kernel inside its 64-VGPR budget without spilling
     a = lookup_dword<BASE + 0 * 1024>(v.x, a, mask78);
-    __builtin_amdgcn_sched_barrier(0);
     a = lookup_dword<BASE + 1 * 1024>(v.y, a, mask78);
     __builtin_amdgcn_sched_barrier(0);
     a = lookup_dword<BASE + 2 * 1024>(v.z, a, mask78);
-    __builtin_amdgcn_sched_barrier(0);
     a = lookup_dword<BASE + 3 * 1024>(v.w, a, mask78);
     return a;
 }

@@ -568,3 +568,54 @@ def test_syndrome_table_mid_size_codes_vs_oracle():
     assert len(table) == sum(comb(60, w) for w in range(t + 1))
     for key, err in list(table.items())[::5000]:
         assert key == bin_matrix.vec_to_int(np.mod(h @ err, 2))
+
+
+def test_abi_argument_errors(ctx):
+    # error codes and messages of the C ABI (include/gf2hip.h): nothing is computed, nothing crashes
+    import ctypes
+    lib = _native.lib()
+    h = _native.pack_rows(np.eye(3, 200, dtype=np.uint8))
+    chk = ctx.check_create(h, 3, 200)
+    small = ctx.check_create(_native.pack_rows(np.eye(3, 7, dtype=np.uint8)), 3, 7)
+    buf = ctx.alloc(1 << 16).zero()
+
+    def rc_of(fn, *args):
+        code = fn(*args)
+        return code, lib.gf2_last_error().decode()
+
+    code, msg = rc_of(lib.gf2_syndrome_dev, ctx.handle, chk.handle, buf.ptr, 10, 1, 0, buf.ptr, 1)
+    assert code == _native.GF2_E_ARG and "lde too small" in msg
+    code, msg = rc_of(lib.gf2_syndrome_dev, ctx.handle, chk.handle, buf.ptr, 10, 4, 7, buf.ptr, 1)
+    assert code == _native.GF2_E_ARG and "unknown layout" in msg
+    code, msg = rc_of(lib.gf2_syndrome_dev, ctx.handle, chk.handle, buf.ptr, 10, 4, _native.LAYOUT_BIT_SLICED, buf.ptr, 1)
+    assert code == _native.GF2_E_ARG and "bit-sliced" in msg
+    code, msg = rc_of(lib.gf2_syndrome_dev, ctx.handle, small.handle, buf.ptr, 10, 1, _native.LAYOUT_TILED, buf.ptr, 16)
+    assert code == _native.GF2_E_ARG and "tiled" in msg
+    code, msg = rc_of(lib.gf2_syndrome_sparse_dev, ctx.handle, small.handle, buf.ptr, 10, 1, buf.ptr, 1, None, 0)
+    assert code == _native.GF2_E_ARG and "no transposed columns" in msg
+    code, msg = rc_of(lib.gf2_syndrome_sparse_dev, ctx.handle, chk.handle, buf.ptr, 10, 4, None, 0, buf.ptr, 9)
+    assert code == _native.GF2_E_ARG and "r+1 bins" in msg
+    code, msg = rc_of(lib.gf2_histogram_dev, ctx.handle, buf.ptr, 10, 1, 0, 30, _native.HIST_FULL, buf.ptr, 8)
+    assert code == _native.GF2_E_ARG and "r <= 24" in msg
+    code, msg = rc_of(lib.gf2_histogram_dev, ctx.handle, buf.ptr, 10, 1, 0, 3, _native.HIST_WEIGHT, buf.ptr, 8)
+    assert code == _native.GF2_E_ARG and "r+1 bins" in msg
+    code, msg = rc_of(lib.gf2_sample_errors_dev, ctx.handle, 200, 1, 0, 10, 0.6, 0.3, 0.3, buf.ptr, buf.ptr, 4, 0)
+    assert code == _native.GF2_E_ARG and "sum to at most 1" in msg
+    code, msg = rc_of(lib.gf2_sample_errors_dev, ctx.handle, 200, 1, 0, 10, -0.1, 0.0, 0.0, buf.ptr, buf.ptr, 4, 0)
+    assert code == _native.GF2_E_ARG
+    rank = ctypes.c_int64()
+    code, msg = rc_of(lib.gf2_rref, ctx.handle, None, 3, 200, 1, None, ctypes.byref(rank))
+    assert code == _native.GF2_E_ARG and "bad shape" in msg
+    nsw = ctypes.c_int64()
+    code, msg = rc_of(lib.gf2_normalize, ctx.handle, h.ctypes.data, 3, 200, 4, 199, None, ctypes.byref(nsw))
+    assert code == _native.GF2_E_COLUMNS and msg == "not enough columns"
+    with pytest.raises(ValueError, match="not enough columns"):
+        css_code.normalize_parity_check(np.eye(3, 5, dtype=int), 3)
+    with pytest.raises(_native.GF2Error):
+        ctx.mc_run(chk, small, 1, 0, 10, 0.1, 0.0, 0.0, _native.HIST_WEIGHT)     # different n
+    # zero-sized work is a no-op everywhere
+    assert ctx.syndrome_batch(h, 3, 200, np.zeros((0, 4), dtype="<u8"), 0).shape == (0, 1)
+    assert bin_matrix.reduced_row_echelon_form(np.zeros((0, 9), dtype=int)).shape == (0, 9)
+    assert css_code.syndrome_batch(np.zeros((0, 9), dtype=int), np.zeros((5, 9), dtype=int)).shape == (5, 0)
+    got = ctx.mc_run(chk, chk, 1, 0, 0, 0.1, 0.0, 0.0, _native.HIST_WEIGHT)
+    assert int(got[0].sum()) == 0
