@@ -342,44 +342,71 @@ def pauli_thresholds(p_x, p_y, p_z):
     return t_any, t_x, t_y
 
 
-def _bernoulli_word(base, threshold, undecided):
-    """64 Bernoulli(threshold / 2^32) bits, only at the positions set in `undecided`.  Position j
-    owns an implicit 32-bit uniform u_j whose k-th most significant bit is bit j of draw k;
-    the output bit is (u_j < threshold).  This is the plain (non-lazy) evaluation."""
-    if threshold >= (1 << 32):
-        return undecided
-    draws = [mix64(base + GOLDEN * (k + 1)) for k in range(32)]
-    out = 0
-    for j in range(64):
-        if not (undecided >> j) & 1:
-            continue
-        u = 0
-        for k in range(32):
-            u = (u << 1) | ((draws[k] >> j) & 1)
-        if u < threshold:
-            out |= 1 << j
-    return out
+def binomial_cdf_table(t_any, nb):
+    """cdf[k] = floor(2^32 * P(Bin(nb, q) <= k)), q = t_any / 2^32, in IEEE doubles with the operation order of
+    DESIGN.md "Sampler".  The number of errors of a word is K = #{k < nb : u >= cdf[k]}."""
+    cdf = [1 << 32] * 65
+    if nb <= 0:
+        return cdf
+    if t_any >= (1 << 32):
+        for k in range(nb):
+            cdf[k] = 0
+        return cdf
+    q = float(t_any) / 4294967296.0
+    om = 1.0 - q
+    pmf = 1.0
+    for _ in range(nb):
+        pmf *= om
+    cum = 0.0
+    for k in range(nb):
+        cum += pmf
+        c = float(np.floor(cum * 4294967296.0))
+        if c > 4294967296.0:
+            c = 4294967296.0
+        cdf[k] = int(c)
+        pmf = pmf * float(nb - k) / float(k + 1) * q / om
+    return cdf
+
+
+class _UniformStream(object):
+    """32-bit uniforms: high half then low half of draw 0, 1, 2, ... of one stream."""
+
+    def __init__(self, base):
+        self.base, self.queue, self.draws = base, [], 0
+
+    def next(self):
+        if not self.queue:
+            word = mix64(self.base + GOLDEN * (self.draws + 1))
+            self.draws += 1
+            self.queue = [word >> 32, word & 0xFFFFFFFF]
+        return self.queue.pop(0)
 
 
 def sample_pauli_error(seed, sample, n, p_x, p_y, p_z):
-    """[build-defined, x3]  Error of global sample index `sample`: a pure function of
-    (seed, sample).  Returns (e_x, e_z) as length-n int arrays.  X/Y/Z with probabilities
-    p_x/p_y/p_z per qubit, independently; e_x marks X or Y, e_z marks Z or Y."""
+    """[build-defined, x3]  Error of global sample index `sample`: a pure function of (seed, sample).  Returns
+    (e_x, e_z) as length-n int arrays.  Per 64-qubit word: the number of erroneous qubits comes from one uniform by
+    inverse binomial CDF, their positions by Floyd's algorithm, then one uniform per erroneous qubit decides whether
+    it has an X component and one per X-carrying qubit whether it is a Y (DESIGN.md "Sampler")."""
     t_any, t_x, t_y = pauli_thresholds(p_x, p_y, p_z)
     ks = mix64(seed + GOLDEN * (sample + 1))
     e_x = np.zeros(n, dtype='int')
     e_z = np.zeros(n, dtype='int')
-    for w in range((n + 63) // 64):
-        valid = _M64 if (w + 1) * 64 <= n else (1 << (n - w * 64)) - 1
-        bases = [mix64(ks ^ ((STREAM_MULT * (4 * w + s + 1)) & _M64)) for s in range(3)]
-        any_err = _bernoulli_word(bases[0], t_any, valid)
-        has_x = _bernoulli_word(bases[1], t_x, any_err)
-        is_y = _bernoulli_word(bases[2], t_y, has_x)
-        xw = has_x
-        zw = (any_err & ~has_x) | is_y
-        for j in range(min(64, n - w * 64)):
-            e_x[w * 64 + j] = (xw >> j) & 1
-            e_z[w * 64 + j] = (zw >> j) & 1
+    words = (n + 63) // 64
+    for w in range(words):
+        nb = 64 if w < words - 1 else n - 64 * (words - 1)
+        cdf = binomial_cdf_table(t_any, nb)
+        streams = [_UniformStream(mix64(ks ^ ((STREAM_MULT * (4 * w + s + 1)) & _M64))) for s in range(3)]
+        u = streams[0].next()
+        k_err = sum(1 for k in range(nb) if u >= cdf[k])
+        chosen = set()
+        for i in range(nb - k_err, nb):                       # Floyd: k_err distinct positions in range(nb)
+            t = (streams[0].next() * (i + 1)) >> 32
+            chosen.add(i if t in chosen else t)
+        for j in sorted(chosen):
+            has_x = streams[1].next() < t_x
+            is_y = has_x and streams[2].next() < t_y
+            e_x[64 * w + j] = 1 if has_x else 0
+            e_z[64 * w + j] = 1 if (not has_x or is_y) else 0
     return e_x, e_z
 
 

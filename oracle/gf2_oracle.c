@@ -164,18 +164,37 @@ static u64 quantise(double x) {
     return (u64)t;
 }
 
-/* Bit j of the result = (u_j < threshold) for positions in `mask`, where u_j's k-th most significant bit
- * is bit j of draw k.  All 32 draws are always taken; the comparison is a 64-lane ripple comparator. */
-static u64 bernoulli_word(u64 base, u64 threshold, u64 mask) {
-    if (threshold >= (1ull << 32)) return mask;
-    u64 less = 0, equal = ~0ull;
-    for (int k = 0; k < 32; ++k) {
-        const u64 draw = mix64(base + GOLDEN * (u64)(k + 1));
-        const u64 tbit = ((threshold >> (31 - k)) & 1ull) ? ~0ull : 0ull;
-        less |= equal & ~draw & tbit;
-        equal &= ~(draw ^ tbit);
+/* Inverse binomial CDF table: cdf[k] = floor(2^32 * P(Bin(nb, q) <= k)), q = t_any / 2^32, IEEE doubles in exactly
+ * this operation order (DESIGN.md "Sampler").  K = number of k < nb with u >= cdf[k]. */
+static void binomial_cdf(u64 t_any, int nb, u64* cdf) {
+    for (int k = 0; k < 65; ++k) cdf[k] = 4294967296ull;
+    if (nb <= 0) return;
+    if (t_any >= 4294967296ull) {
+        for (int k = 0; k < nb; ++k) cdf[k] = 0;
+        return;
     }
-    return less & mask;
+    const double q = (double)t_any / 4294967296.0, om = 1.0 - q;
+    double pmf = 1.0;
+    for (int i = 0; i < nb; ++i) pmf *= om;
+    double cum = 0.0;
+    for (int k = 0; k < nb; ++k) {
+        cum += pmf;
+        double c = __builtin_floor(cum * 4294967296.0);
+        if (c > 4294967296.0) c = 4294967296.0;
+        cdf[k] = (u64)c;
+        pmf = pmf * (double)(nb - k) / (double)(k + 1) * q / om;
+    }
+}
+
+/* 32-bit uniforms of one stream: high half, then low half of draw 0, 1, 2, ... */
+typedef struct { u64 base; u64 word; unsigned int taken; } uniform_stream;
+
+static u64 next_uniform(uniform_stream* st) {
+    const unsigned int d = st->taken >> 1;
+    if ((st->taken & 1u) == 0) st->word = mix64(st->base + GOLDEN * (u64)(d + 1));
+    const u64 out = (st->taken & 1u) ? (st->word & 0xFFFFFFFFull) : (st->word >> 32);
+    st->taken += 1;
+    return out;
 }
 
 int orc_sample_errors(int64_t n, u64 seed, int64_t first, int64_t count, double p_x, double p_y, double p_z,
@@ -185,18 +204,39 @@ int orc_sample_errors(int64_t n, u64 seed, int64_t first, int64_t count, double 
     const u64 t_x = p_t > 0.0 ? quantise(p_xy / p_t) : 0;
     const u64 t_y = p_xy > 0.0 ? quantise(p_y / p_xy) : 0;
     const int64_t words = (n + 63) >> 6;
+    const int nb_last = n > 0 ? (int)(n - (words - 1) * 64) : 0;
+    u64 cdf_full[65], cdf_last[65];
+    binomial_cdf(t_any, 64, cdf_full);
+    binomial_cdf(t_any, nb_last, cdf_last);
     for (int64_t i = 0; i < count; ++i) {
         const u64 ks = mix64(seed + GOLDEN * ((u64)(first + i) + 1));
         for (int64_t w = 0; w < lde; ++w) {
             u64 x = 0, z = 0;
             if (w < words) {
-                const int64_t left = n - w * 64;
-                const u64 valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
-                const u64 any_err = bernoulli_word(mix64(ks ^ (STREAM_MULT * (u64)(4 * w + 1))), t_any, valid);
-                const u64 has_x = bernoulli_word(mix64(ks ^ (STREAM_MULT * (u64)(4 * w + 2))), t_x, any_err);
-                const u64 is_y = bernoulli_word(mix64(ks ^ (STREAM_MULT * (u64)(4 * w + 3))), t_y, has_x);
-                x = has_x;
-                z = (any_err & ~has_x) | is_y;
+                const int nb = w == words - 1 ? nb_last : 64;
+                const u64* cdf = w == words - 1 ? cdf_last : cdf_full;
+                uniform_stream s0 = {mix64(ks ^ (STREAM_MULT * (u64)(4 * w + 1))), 0, 0};
+                uniform_stream s1 = {mix64(ks ^ (STREAM_MULT * (u64)(4 * w + 2))), 0, 0};
+                uniform_stream s2 = {mix64(ks ^ (STREAM_MULT * (u64)(4 * w + 3))), 0, 0};
+                const u64 u = next_uniform(&s0);
+                int k_err = 0;
+                for (int k = 0; k < nb; ++k)
+                    if (u >= cdf[k]) k_err += 1;                   /* the table is non-decreasing */
+                u64 chosen = 0;                                    /* Floyd's sampling of k_err distinct positions */
+                for (int i2 = nb - k_err; i2 < nb; ++i2) {
+                    const int t = (int)((next_uniform(&s0) * (u64)(i2 + 1)) >> 32);
+                    if ((chosen >> t) & 1ull)
+                        chosen |= 1ull << i2;
+                    else
+                        chosen |= 1ull << t;
+                }
+                u64 with_x = 0, as_y = 0;
+                for (int j = 0; j < nb; ++j)
+                    if (((chosen >> j) & 1ull) && next_uniform(&s1) < t_x) with_x |= 1ull << j;
+                for (int j = 0; j < nb; ++j)
+                    if (((with_x >> j) & 1ull) && next_uniform(&s2) < t_y) as_y |= 1ull << j;
+                x = with_x;
+                z = (chosen & ~with_x) | as_y;
             }
             ex[i * lde + w] = x;
             ez[i * lde + w] = z;

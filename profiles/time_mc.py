@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""End-to-end gf2_mc_run (sampler included) on the n = 4096 workload of bench.py."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quantum_css_codes_amd import _native  # noqa: E402
+
+ctx = _native.default_context()
+rng = np.random.default_rng(1)
+hm1 = rng.integers(0, 2, (2048, 4096), dtype=np.uint8)
+hm1[:, :2048] = np.eye(2048, dtype=np.uint8)
+hm2 = rng.integers(0, 2, (2047, 4096), dtype=np.uint8)
+hm2[:, 2048:4095] = np.eye(2047, dtype=np.uint8)
+c1 = ctx.check_create(_native.pack_rows(hm1), 2048, 4096)
+c2 = ctx.check_create(_native.pack_rows(hm2), 2047, 4096)
+p = 0.01 / 3
+ctx.mc_run(c1, c2, 1, 0, 1 << 20, p, p, p, _native.HIST_WEIGHT)
+count = 1 << 24
+t0 = time.perf_counter()
+hz, hx = ctx.mc_run(c1, c2, 1, 0, count, p, p, p, _native.HIST_WEIGHT)
+dt = time.perf_counter() - t0
+assert int(hz.sum()) == count
+print("gf2_mc_run n=4096 end to end (sampler + syndromes + histograms): %.3e samples/s" % (count / dt))

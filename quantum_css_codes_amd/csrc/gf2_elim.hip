@@ -968,10 +968,9 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
         GF2_HIP(hipMemcpyAsync(states, init.data(), (size_t)batch * sizeof(RrefState), hipMemcpyHostToDevice, ctx->stream));
         GF2_HIP(hipStreamSynchronize(ctx->stream));                              // init lives on the host stack
     }
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!ctx->lds_optin[1]) {
         GF2_HIP(hipFuncSetAttribute((const void*)rref_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_done = true;
+        ctx->lds_optin[1] = true;
     }
     const int64_t panels = gf2_words(n) < ld ? gf2_words(n) : ld;
     // rows per update workgroup: a lone matrix wants many workgroups, a large batch wants the table build amortised
@@ -1078,10 +1077,9 @@ int gf2_normalize_dev(gf2_ctx* ctx, uint64_t* h_dev, int64_t r, int64_t n, int64
     u64* dco = (u64*)q; q += dbytes;
     u64* snap = (u64*)q;
     GF2_HIP(hipMemsetAsync(st, 0, sizeof(RrefState), ctx->stream));
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!ctx->lds_optin[1]) {
         GF2_HIP(hipFuncSetAttribute((const void*)rref_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        attr_done = true;
+        ctx->lds_optin[1] = true;
     }
     const int rpt = (int)gf2_cdiv(r, RB_THREADS);
     const int64_t rows_per_wg = gf2_cdiv(ld, 64) >= 8 ? 256 : 128;

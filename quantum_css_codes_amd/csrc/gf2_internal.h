@@ -53,6 +53,9 @@ struct gf2_ctx {
     // workspaces grown on demand: slot 0 = Monte-Carlo pipeline, slot 1 = re-tiling of sample-major errors
     void* ws[2];
     size_t ws_bytes[2];
+    // large dynamic-LDS opt-in (hipFuncSetAttribute) done for this context's device: [0] syndrome_tiled_kernel,
+    // [1] rref_update_kernel
+    bool lds_optin[2];
 };
 
 int gf2_ctx_activate(gf2_ctx* ctx);

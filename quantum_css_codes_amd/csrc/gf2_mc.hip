@@ -19,43 +19,79 @@ __host__ __device__ static inline u64 mix64(u64 z) {
     return z ^ (z >> 31);
 }
 
-// 64 Bernoulli(threshold / 2^32) bits at the positions set in `undecided`.  Position j owns an implicit
-// 32-bit uniform whose k-th most significant bit is bit j of draw k; output = (uniform < threshold).
-// Evaluated most-significant-bit first and only while some position is still undecided.
-__device__ static inline u64 bernoulli_word(u64 base, u64 threshold, u64 undecided) {
-    if (threshold >= (1ull << 32)) return undecided;
-    u64 out = 0;
-    for (int k = 0; k < 32 && undecided; ++k) {
-        const u64 draw = mix64(base + GF2_GOLDEN * (u64)(k + 1));
-        if ((threshold >> (31 - k)) & 1ull) {
-            out |= undecided & ~draw;
-            undecided &= draw;
-        } else {
-            undecided &= ~draw;
-        }
-    }
-    return out;
-}
-
-struct PauliThresholds {
-    u64 t_any, t_x, t_y;
+// Sampler (DESIGN.md "Sampler"): per 64-qubit word of a sample, three independent streams of 32-bit uniforms
+// (high then low half of successive splitmix64 draws).
+//   stream 0: the first uniform picks the number K of erroneous qubits in the word by inverse binomial CDF (an integer
+//             table made on the host); K distinct positions follow by Floyd's algorithm, one uniform each.
+//   stream 1: one uniform per erroneous qubit, ascending: the error has an X component iff uniform < t_x.
+//   stream 2: one uniform per qubit with an X component, ascending: it is a Y iff uniform < t_y.
+struct SamplerTables {
+    u64 t_x, t_y;              // thresholds in [0, 2^32]
+    u64 cdf_full[65];          // K = #{k < 64 : u >= cdf_full[k]} for whole words
+    u64 cdf_last[65];          // the same for the last word of nb_last valid qubits
+    int nb_last;
 };
 
-__device__ static inline void sample_word(u64 seed, u64 sample, u64 w, u64 valid, PauliThresholds th, u64* ex, u64* ez) {
+struct UniformStream {
+    u64 base, cur;
+    unsigned int k;
+    bool half;
+    __device__ __forceinline__ explicit UniformStream(u64 b) : base(b), cur(0), k(0), half(false) {}
+    __device__ __forceinline__ u64 next() {                   // 32-bit uniform: high half, then low half of each draw
+        if (!half) {
+            cur = mix64(base + GF2_GOLDEN * (u64)(k + 1));
+            k += 1;
+            half = true;
+            return cur >> 32;
+        }
+        half = false;
+        return cur & 0xFFFFFFFFull;
+    }
+};
+
+// cdf: the table for this word (in LDS); nb: valid qubits of this word (1..64).
+__device__ static inline void sample_word(u64 seed, u64 sample, u64 w, int nb, const u64* cdf, u64 t_x, u64 t_y,
+                                          u64* ex, u64* ez) {
     const u64 ks = mix64(seed + GF2_GOLDEN * (sample + 1));
-    const u64 any_err = bernoulli_word(mix64(ks ^ (GF2_STREAM_MULT * (4 * w + 1))), th.t_any, valid);
-    const u64 has_x = bernoulli_word(mix64(ks ^ (GF2_STREAM_MULT * (4 * w + 2))), th.t_x, any_err);
-    const u64 is_y = bernoulli_word(mix64(ks ^ (GF2_STREAM_MULT * (4 * w + 3))), th.t_y, has_x);
+    UniformStream s0(mix64(ks ^ (GF2_STREAM_MULT * (4 * w + 1))));
+    const u64 u = s0.next();
+    int count = 0;
+    while (count < nb && u >= cdf[count]) count += 1;
+    u64 any_err = 0;
+    for (int idx = 0; idx < count; ++idx) {                    // Floyd: `count` distinct positions out of nb
+        const int i = nb - count + idx;
+        const int t = (int)((s0.next() * (u64)(i + 1)) >> 32);
+        any_err |= 1ull << (((any_err >> t) & 1ull) ? i : t);
+    }
+    u64 has_x = 0, is_y = 0;
+    if (any_err) {
+        UniformStream s1(mix64(ks ^ (GF2_STREAM_MULT * (4 * w + 2))));
+        for (u64 x = any_err; x; x &= x - 1)
+            if (s1.next() < t_x) has_x |= x & (0ull - x);
+    }
+    if (has_x) {
+        UniformStream s2(mix64(ks ^ (GF2_STREAM_MULT * (4 * w + 3))));
+        for (u64 x = has_x; x; x &= x - 1)
+            if (s2.next() < t_y) is_y |= x & (0ull - x);
+    }
     *ex = has_x;
     *ez = (any_err & ~has_x) | is_y;
+}
+
+// Copies the two CDF tables of the kernel argument into LDS (per-lane table indices need addressable memory).
+__device__ __forceinline__ void stage_cdf(const SamplerTables& tb, u64* cdf_lds) {
+    for (int i = threadIdx.x; i < 130; i += blockDim.x) cdf_lds[i] = i < 65 ? tb.cdf_full[i] : tb.cdf_last[i - 65];
+    __syncthreads();
 }
 
 // One lane per output word.  Sample-major: idx = i * lde + w.  Tiled: idx is the tiled word offset
 // (i>>6)*64*ldt + (w>>1)*128 + (i&63)*2 + (w&1).  Either way consecutive lanes write consecutive words.
 template <bool TILED>
 __global__ __launch_bounds__(256) void sampler_kernel(u64 seed, int64_t first_sample, int64_t count, int64_t n,
-                                                      int64_t words, int64_t lde, int64_t total, PauliThresholds th,
+                                                      int64_t words, int64_t lde, int64_t total, SamplerTables th,
                                                       uint64_t* __restrict__ ex, uint64_t* __restrict__ ez) {
+    __shared__ u64 cdf_lds[130];
+    stage_cdf(th, cdf_lds);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
         int64_t i, w;
@@ -69,9 +105,9 @@ __global__ __launch_bounds__(256) void sampler_kernel(u64 seed, int64_t first_sa
         }
         u64 x = 0, z = 0;
         if (i < count && w < words) {
-            const int64_t left = n - w * 64;
-            const u64 valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
-            sample_word(seed, (u64)(first_sample + i), (u64)w, valid, th, &x, &z);
+            const bool last = w == words - 1;
+            sample_word(seed, (u64)(first_sample + i), (u64)w, last ? th.nb_last : 64, cdf_lds + (last ? 65 : 0), th.t_x,
+                        th.t_y, &x, &z);
         }
         ex[idx] = x;
         ez[idx] = z;
@@ -87,17 +123,17 @@ struct DecodeRows {
 // counts: [0] logical X flips, [1] logical Z flips, [2] either, [3] X syndrome not in table, [4] Z syndrome not in table.
 __global__ __launch_bounds__(256) void decode_kernel(DecodeRows rows, int r1, int r2, int n, const u64* __restrict__ t1,
                                                      const u64* __restrict__ t2, u64 xop, u64 zop, u64 seed,
-                                                     int64_t first_sample, int64_t count, PauliThresholds th,
+                                                     int64_t first_sample, int64_t count, SamplerTables th,
                                                      u64* __restrict__ counts) {
     __shared__ unsigned int acc[5];
+    __shared__ u64 cdf_lds[130];
     if (threadIdx.x < 5) acc[threadIdx.x] = 0;
-    __syncthreads();
-    const u64 valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    stage_cdf(th, cdf_lds);
     unsigned int local[5] = {0, 0, 0, 0, 0};
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         u64 ex, ez;
-        sample_word(seed, (u64)(first_sample + i), 0, valid, th, &ex, &ez);
+        sample_word(seed, (u64)(first_sample + i), 0, n, cdf_lds + 65, th.t_x, th.t_y, &ex, &ez);
         u64 kx = 0, kz = 0;                                   // vec_to_int keys: row 0 is the most significant bit
         for (int k = 0; k < r2; ++k) kx = (kx << 1) | (u64)(__popcll(rows.h2[k] & ex) & 1);
         for (int k = 0; k < r1; ++k) kz = (kz << 1) | (u64)(__popcll(rows.h1[k] & ez) & 1);
@@ -122,7 +158,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeRows rows, int r1, in
 // mode GF2_HIST_FULL: bins by the big-endian key; GF2_HIST_WEIGHT: bins by weight.  Bins privatised in LDS when both
 // histograms fit 8192 bins together.
 __global__ __launch_bounds__(256) void mc_small_kernel(DecodeRows rows, int r1, int r2, int n, int mode, u64 seed,
-                                                       int64_t first_sample, int64_t count, PauliThresholds th,
+                                                       int64_t first_sample, int64_t count, SamplerTables th,
                                                        u64* __restrict__ hist_z, int nbz, u64* __restrict__ hist_x, int nbx) {
     __shared__ unsigned int bins[8192];
     const bool priv = nbz + nbx <= 8192;
@@ -130,11 +166,12 @@ __global__ __launch_bounds__(256) void mc_small_kernel(DecodeRows rows, int r1, 
         for (int i = threadIdx.x; i < nbz + nbx; i += blockDim.x) bins[i] = 0;
         __syncthreads();
     }
-    const u64 valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    __shared__ u64 cdf_lds[130];
+    stage_cdf(th, cdf_lds);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         u64 ex, ez;
-        sample_word(seed, (u64)(first_sample + i), 0, valid, th, &ex, &ez);
+        sample_word(seed, (u64)(first_sample + i), 0, n, cdf_lds + 65, th.t_x, th.t_y, &ex, &ez);
         u64 kx = 0, kz = 0;
         if (mode == GF2_HIST_FULL) {
             for (int k = 0; k < r2; ++k) kx = (kx << 1) | (u64)(__popcll(rows.h2[k] & ex) & 1);
@@ -160,13 +197,38 @@ __global__ __launch_bounds__(256) void mc_small_kernel(DecodeRows rows, int r1, 
     }
 }
 
-static int make_thresholds(double p_x, double p_y, double p_z, PauliThresholds* th) {
+// Inverse binomial CDF as integers: cdf[k] = floor(2^32 * P(Bin(nb, q) <= k)), q = T / 2^32, in IEEE doubles with
+// this exact operation order (oracle/gf2_oracle.c and oracle/cpu_ref.py repeat it).  K = #{k < nb : u >= cdf[k]}.
+static void binomial_cdf_table(uint64_t t_any, int nb, u64* cdf) {
+    for (int k = 0; k < 65; ++k) cdf[k] = 4294967296ull;
+    if (nb <= 0) return;
+    if (t_any >= 4294967296ull) {
+        for (int k = 0; k < nb; ++k) cdf[k] = 0;               // every qubit errs
+        return;
+    }
+    const double q = (double)t_any / 4294967296.0, om = 1.0 - q;
+    double pmf = 1.0;
+    for (int i = 0; i < nb; ++i) pmf *= om;
+    double cum = 0.0;
+    for (int k = 0; k < nb; ++k) {
+        cum += pmf;
+        double c = __builtin_floor(cum * 4294967296.0);
+        if (c > 4294967296.0) c = 4294967296.0;
+        cdf[k] = (u64)c;
+        pmf = pmf * (double)(nb - k) / (double)(k + 1) * q / om;
+    }
+}
+
+static int make_thresholds(double p_x, double p_y, double p_z, int64_t n, SamplerTables* th) {
     if (!(p_x >= 0.0) || !(p_y >= 0.0) || !(p_z >= 0.0) || p_x + p_y + p_z > 1.0 + 1e-12)
         GF2_FAIL(GF2_E_ARG, "probabilities must be non-negative and sum to at most 1");
     const double p_t = p_x + p_y + p_z, p_xy = p_x + p_y;
-    th->t_any = gf2_quantise(p_t);
+    const uint64_t t_any = gf2_quantise(p_t);
     th->t_x = p_t > 0.0 ? gf2_quantise(p_xy / p_t) : 0;
     th->t_y = p_xy > 0.0 ? gf2_quantise(p_y / p_xy) : 0;
+    th->nb_last = n > 0 ? (int)(n - ((n - 1) / 64) * 64) : 0;
+    binomial_cdf_table(t_any, 64, th->cdf_full);
+    binomial_cdf_table(t_any, th->nb_last, th->cdf_last);
     return GF2_OK;
 }
 
@@ -180,8 +242,8 @@ int gf2_sample_errors_dev(gf2_ctx* ctx, int64_t n, uint64_t seed, int64_t first_
     if (layout == GF2_LAYOUT_TILED) lde = gf2_tiled_ld(n);
     if (n < 0 || count < 0 || first_sample < 0 || lde < gf2_words(n) || lde < 1)
         GF2_FAIL(GF2_E_ARG, "gf2_sample_errors_dev: bad shape");
-    PauliThresholds th;
-    GF2_TRY(make_thresholds(p_x, p_y, p_z, &th));
+    SamplerTables th;
+    GF2_TRY(make_thresholds(p_x, p_y, p_z, n, &th));
     if (count == 0) return GF2_OK;
     if (!ex_dev || !ez_dev) GF2_FAIL(GF2_E_ARG, "gf2_sample_errors_dev: null buffer");
     GF2_TRY(gf2_ctx_activate(ctx));
@@ -213,8 +275,8 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
     if (want_z < 0 || want_x < 0) GF2_FAIL(GF2_E_ARG, "gf2_mc_run: full histograms need r <= 24");
     if (nbins_z != want_z || nbins_x != want_x)
         GF2_FAIL(GF2_E_ARG, "gf2_mc_run: expected %lld and %lld bins", (long long)want_z, (long long)want_x);
-    PauliThresholds th;
-    GF2_TRY(make_thresholds(p_x, p_y, p_z, &th));
+    SamplerTables th;
+    GF2_TRY(make_thresholds(p_x, p_y, p_z, n, &th));
     GF2_TRY(gf2_ctx_activate(ctx));
 
     // Small codes: one fused kernel, nothing but the histograms touches memory.
@@ -249,7 +311,7 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
     const double dens = (p_x + p_y > p_z + p_y ? p_x + p_y : p_z + p_y) * (double)n;
     if (mode == GF2_HIST_WEIGHT && c1->ht_dev && c2->ht_dev && dens <= 160.0 && getenv("GF2_MC_DENSE") == nullptr) {
         const int64_t lde_s = gf2_words(n);
-        int64_t chunk_s = (int64_t)(256ll << 20) / (2 * lde_s * 8);
+        int64_t chunk_s = (int64_t)(2048ll << 20) / (2 * lde_s * 8);      // 2 GiB of packed errors per round trip
         if (chunk_s > count) chunk_s = count > 0 ? count : 1;
         auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t eb = (size_t)chunk_s * lde_s * 8, hzb = (size_t)nbins_z * 8, hxb = (size_t)nbins_x * 8;
@@ -324,8 +386,8 @@ int gf2_mc_decode(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, const 
     if (c1->n > 63 || c1->n < 1 || c1->r > 20 || c2->r > 20)
         GF2_FAIL(GF2_E_ARG, "gf2_mc_decode: needs n <= 63 and r_1, r_2 <= 20 (table decode of small codes)");
     if (count < 0 || first_sample < 0) GF2_FAIL(GF2_E_ARG, "gf2_mc_decode: negative range");
-    PauliThresholds th;
-    GF2_TRY(make_thresholds(p_x, p_y, p_z, &th));
+    SamplerTables th;
+    GF2_TRY(make_thresholds(p_x, p_y, p_z, c1->n, &th));
     GF2_TRY(gf2_ctx_activate(ctx));
     for (int k = 0; k < 5; ++k) counts_out[k] = 0;
     if (count == 0) return GF2_OK;

@@ -575,11 +575,10 @@ static int launch_tiled(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_til
     if (blocks > 0x7fffffffLL) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: batch too large for one launch");
     const int64_t stage_pairs = ck->max_pairs < SYN_CHUNK_PAIRS ? ck->max_pairs : SYN_CHUNK_PAIRS;
     const size_t shmem = (size_t)stage_pairs * 4096;
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (!ctx->lds_optin[0]) {
         GF2_HIP(hipFuncSetAttribute((const void*)syndrome_tiled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     SYN_CHUNK_PAIRS * 4096));
-        attr_set = true;
+        ctx->lds_optin[0] = true;
     }
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_SYNDROME));
     hipLaunchKernelGGL(syndrome_tiled_kernel, dim3((unsigned)blocks), dim3(SYN_THREADS), shmem, ctx->stream,
