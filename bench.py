@@ -30,7 +30,8 @@ The JSON line also carries
                 from the committed rocprofv3 passes (profiles/traffic.json).
   cpu_baseline  the reference's NumPy path (oracle/cpu_ref.py restatement of css_code.py:728) timed on this
                 host, 1 core, on a bounded sample of the same workload.
-  secondary     (rank 0, N = 1) the other syndrome kernel on the same workload, and RREF GB/s
+  secondary     (rank 0, N = 1) the end-to-end Monte-Carlo (sampler included), the other syndrome kernel on the same
+                workload, and RREF GB/s
                 (2 * m * ceil(n/64) * 8 bytes / time) for one and for 256 resident 2048 x 4096 matrices and for one
                 32768 x 65536 matrix.
 """
@@ -327,7 +328,18 @@ def main():
             o_ms, o_launch, o_n, o_hist = timed(ctx, other, 10, 2)
             other_z = other.hz.download((R1 + 1,), np.uint64)
             assert np.array_equal(other_z, single_z * np.uint64(10)), "the two syndrome kernels disagree"
+            # end to end: nothing resident, gf2_mc_run draws the errors itself (fused sampler + sparse kernel)
+            mc_count = 1 << 24
+            ctx.mc_run(chk1, chk2, SEED, 0, 1 << 20, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)
+            t_mc = time.perf_counter()
+            mc_z, _ = ctx.mc_run(chk1, chk2, SEED, 0, mc_count, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)
+            t_mc = time.perf_counter() - t_mc
+            assert int(mc_z.sum()) == mc_count and np.array_equal(
+                ctx.mc_run(chk1, chk2, SEED, first, batch, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)[0], single_z)
             out["secondary"] = {
+                "monte_carlo_end_to_end": {"value": mc_count / t_mc, "unit": "syndromes/s",
+                                           "what": "gf2_mc_run: sampler fused into the sparse kernel, no resident input, "
+                                                   "host wall time incl. histogram download, %d samples" % mc_count},
                 other.algo + "_kernel": {"value": 10 * batch / (o_ms / 1e3), "unit": "syndromes/s", "ms_per_step": o_ms / 10,
                                          "roofline": roofline(other, o_launch, o_n), "histogram_ms_per_step": o_hist / 10},
                 "rref": rref_numbers(ctx)}

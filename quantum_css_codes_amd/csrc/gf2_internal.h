@@ -91,6 +91,9 @@ struct gf2_check {
 };
 
 int gf2_build_columns(gf2_ctx* ctx, gf2_check* ck);
+bool gf2_mc_sparse_fused_ok(const gf2_check* c1, const gf2_check* c2);
+int gf2_mc_sparse_fused(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t seed, int64_t first_sample,
+                        int64_t count, double p_x, double p_y, double p_z, uint64_t* hz_dev, uint64_t* hx_dev);
 
 static inline int64_t gf2_words(int64_t bits) { return (bits + 63) >> 6; }
 static inline int64_t gf2_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -20,6 +20,7 @@
 // 2.3 instead of 5 instructions per column) measured the same time, which is how the bound was identified.
 // The dense Four-Russians kernel (gf2_syndrome.hip) remains the data-independent path; DESIGN.md gives the crossover.
 #include "gf2_internal.h"
+#include "gf2_sampler.h"
 
 #define SPARSE_LIST_CAP 512
 #define SPARSE_WAVES 8
@@ -222,6 +223,114 @@ __global__ __launch_bounds__(64 * SPARSE_WAVES) void syndrome_sparse_kernel(
     }
 }
 
+// ---- fused Monte-Carlo: sampler + both syndromes + both weight histograms, no error words in memory -------------------
+//
+// n <= 4096 and r_1, r_2 <= 2048: a wavefront owns a sample, lane = 64-qubit word = syndrome dword.  The lane draws
+// its own error words (e_x, e_z) with sample_word, then runs the sparse column accumulation once per component
+// (e_z against H1, e_x against H2, css_code.py:457-470).  The identity-block bits, which the stand-alone kernel
+// re-reads from memory, come from the neighbouring lanes' registers here.
+struct SparseSide {
+    const uint32_t* ht;        // transposed check, 64 dwords per column, column n is zero
+    int64_t r, ident_off;
+    u64* hist;
+    int nbins;
+};
+
+__device__ __forceinline__ unsigned int sparse_component_weight(u64 w, const SparseSide& side, int64_t n, int lane,
+                                                               unsigned int* mylist) {
+    // identity block: dword `lane` covers rows 32*lane.. <-> error bits ident_off + 32*lane ..
+    unsigned int acc = 0;
+    if (side.ident_off >= 0) {
+        const int64_t bit = side.ident_off + 32 * (int64_t)lane;
+        const int src = (int)(bit >> 6), sh = (int)(bit & 63);
+        const u64 lo = __shfl(w, src & 63), hi = __shfl(w, (src + 1) & 63);
+        u64 v = src < 64 ? lo >> sh : 0ull;
+        if (sh && src + 1 < 64) v |= hi << (64 - sh);
+        const int64_t row0 = 32 * (int64_t)lane;
+        unsigned int keep = row0 < side.r ? (side.r - row0 < 32 ? ~(~0u << (side.r - row0)) : ~0u) : 0u;
+        acc = (unsigned int)v & keep;
+        w &= ~ident_mask(side.ident_off, side.r, lane);
+    }
+    u64 x = w;
+    unsigned int total = 0;
+    for (;;) {
+        const u64 active = __ballot(x != 0);
+        if (!active) break;
+        if (x) {
+            const int b = __ffsll((long long)x) - 1;
+            x &= x - 1;
+            const unsigned int pos = total + __builtin_amdgcn_mbcnt_hi((unsigned int)(active >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((unsigned int)active, 0u));
+            if (pos < SPARSE_LIST_CAP) mylist[pos] = (unsigned int)((lane << 6) + b);
+        }
+        total += (unsigned int)__popcll(active);
+    }
+    const char* htb = reinterpret_cast<const char*>(side.ht);
+    const unsigned int lane4 = lane * 4u;
+    if (total && total <= SPARSE_LIST_CAP) {
+        if (lane < 8) mylist[total + lane] = (unsigned int)n;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (unsigned int k0 = 0; k0 < total; k0 += 8) {
+            unsigned int v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint32_t*>(htb + ((mylist[k0 + i] << 8) | lane4));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc ^= v[i];
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else if (total) {                                             // dense sample: walk the words one by one
+        u64 nz = __ballot(w != 0);
+        while (nz) {
+            const int src = __ffsll((long long)nz) - 1;
+            nz &= nz - 1;
+            u64 word = ((u64)(unsigned int)__builtin_amdgcn_readlane((int)(w >> 32), src) << 32) |
+                       (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)w, src);
+            while (word) {
+                const int b = __ffsll((long long)word) - 1;
+                word &= word - 1;
+                acc ^= *reinterpret_cast<const uint32_t*>(htb + (((unsigned int)((src << 6) + b) << 8) | lane4));
+            }
+        }
+    }
+    return wave_total((unsigned int)__popc(acc));
+}
+
+__global__ __launch_bounds__(64 * SPARSE_WAVES) void mc_sparse_fused_kernel(SparseSide side_z, SparseSide side_x, int64_t n,
+                                                                           u64 seed, int64_t first_sample, int64_t count,
+                                                                           SamplerTables th) {
+    __shared__ unsigned int list[SPARSE_WAVES][SPARSE_LIST_CAP + 8];
+    __shared__ unsigned int bins_z[2052], bins_x[2052];
+    __shared__ u64 cdf_lds[130];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 2052; i += blockDim.x) {
+        bins_z[i] = 0;
+        bins_x[i] = 0;
+    }
+    stage_cdf(th, cdf_lds);
+    const int words = (int)((n + 63) >> 6);
+    const bool last = lane == words - 1;
+    const int64_t total_waves = (int64_t)gridDim.x * SPARSE_WAVES;
+    for (int64_t i = (int64_t)blockIdx.x * SPARSE_WAVES + wave; i < count; i += total_waves) {
+        u64 ex = 0, ez = 0;
+        if (lane < words)
+            sample_word(seed, (u64)(first_sample + i), (u64)lane, last ? th.nb_last : 64, cdf_lds + (last ? 65 : 0), th.t_x,
+                        th.t_y, &ex, &ez);
+        const unsigned int wz = sparse_component_weight(ez, side_z, n, lane, list[wave]);
+        const unsigned int wx = sparse_component_weight(ex, side_x, n, lane, list[wave]);
+        if (lane == 0) {
+            atomicAdd(&bins_z[wz], 1u);
+            atomicAdd(&bins_x[wx], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < side_z.nbins; i += blockDim.x)
+        if (bins_z[i]) atomicAdd(&side_z.hist[i], (u64)bins_z[i]);
+    for (int i = threadIdx.x; i < side_x.nbins; i += blockDim.x)
+        if (bins_x[i]) atomicAdd(&side_x.hist[i], (u64)bins_x[i]);
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 
 int gf2_build_columns(gf2_ctx* ctx, gf2_check* ck) {
@@ -264,6 +373,29 @@ static void launch_sparse(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_d
     else
         GF2_SPARSE_LAUNCH(4);
 #undef GF2_SPARSE_LAUNCH
+}
+
+// Fused sparse Monte-Carlo (internal; gf2_mc_run uses it).  hist buffers must be zeroed by the caller.
+int gf2_mc_sparse_fused(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t seed, int64_t first_sample,
+                        int64_t count, double p_x, double p_y, double p_z, uint64_t* hz_dev, uint64_t* hx_dev) {
+    SamplerTables th;
+    GF2_TRY(make_thresholds(p_x, p_y, p_z, c1->n, &th));
+    if (count == 0) return GF2_OK;
+    SparseSide sz = {c1->ht_dev, c1->r, c1->ident_off, (u64*)hz_dev, (int)(c1->r + 1)};
+    SparseSide sx = {c2->ht_dev, c2->r, c2->ident_off, (u64*)hx_dev, (int)(c2->r + 1)};
+    int64_t blocks = gf2_cdiv(count, SPARSE_WAVES * 8);
+    const int64_t cap = (int64_t)ctx->num_cus * 4;
+    if (blocks > cap) blocks = cap;
+    GF2_TRY(gf2_prof_begin(ctx, GF2_K_SYNDROME));
+    hipLaunchKernelGGL(mc_sparse_fused_kernel, dim3((unsigned)blocks), dim3(64 * SPARSE_WAVES), 0, ctx->stream, sz, sx, c1->n,
+                       (u64)seed, first_sample, count, th);
+    GF2_TRY(gf2_prof_end(ctx));
+    GF2_HIP(hipGetLastError());
+    return GF2_OK;
+}
+
+bool gf2_mc_sparse_fused_ok(const gf2_check* c1, const gf2_check* c2) {
+    return c1->ht_dev && c2->ht_dev && c1->ht_k == 1 && c2->ht_k == 1 && c1->n <= 4096 && c1->n == c2->n;
 }
 
 extern "C" {

@@ -469,12 +469,15 @@ def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, monkeypatch):
     h1, h2 = _native.pack_rows(hm1), _native.pack_rows(hm2)
     c1, c2 = ctx.check_create(h1, 2048, 4096), ctx.check_create(h2, 2047, 4096)
     args = (0xABC, 5 * 10**6, 20000, 0.004, 0.003, 0.002, _native.HIST_WEIGHT)
-    sparse = ctx.mc_run(c1, c2, *args)
+    fused = ctx.mc_run(c1, c2, *args)                         # sampler fused into the sparse kernel
+    monkeypatch.setenv("GF2_MC_UNFUSED", "1")
+    sparse = ctx.mc_run(c1, c2, *args)                        # sampler kernel -> sparse kernel
+    monkeypatch.delenv("GF2_MC_UNFUSED")
     monkeypatch.setenv("GF2_MC_DENSE", "1")
-    dense = ctx.mc_run(c1, c2, *args)
+    dense = ctx.mc_run(c1, c2, *args)                         # sampler kernel -> table kernel -> histogram kernel
     monkeypatch.delenv("GF2_MC_DENSE")
     want = c_oracle.mc(h1, 2048, h2, 2047, 4096, 0xABC, 5 * 10**6, 20000, 0.004, 0.003, 0.002, 1)
-    for got in (sparse, dense):
+    for got in (fused, sparse, dense):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
 
 
@@ -619,3 +622,21 @@ def test_abi_argument_errors(ctx):
     assert css_code.syndrome_batch(np.zeros((0, 9), dtype=int), np.zeros((5, 9), dtype=int)).shape == (5, 0)
     got = ctx.mc_run(chk, chk, 1, 0, 0, 0.1, 0.0, 0.0, _native.HIST_WEIGHT)
     assert int(got[0].sum()) == 0
+
+
+@pytest.mark.parametrize("case", [(100, 300, 0, 100), (300, 1000, 300, 600), (2048, 4096, 0, 2048), (130, 4000, None, None)])
+def test_fused_sparse_monte_carlo_shapes(case, ctx):
+    # fused sampler + sparse kernel on shapes with and without identity blocks, n not a multiple of 64
+    r1, n, off1, off2 = case
+    rng = np.random.default_rng(r1 + n)
+    r2 = r1 - 1
+    hm1, hm2 = rng.integers(0, 2, (r1, n)), rng.integers(0, 2, (r2, n))
+    if off1 is not None:
+        hm1[:, off1:off1 + r1] = np.identity(r1, dtype=int)
+        hm2[:, off2:off2 + r2] = np.identity(r2, dtype=int)
+    h1, h2 = _native.pack_rows(hm1), _native.pack_rows(hm2)
+    c1, c2 = ctx.check_create(h1, r1, n), ctx.check_create(h2, r2, n)
+    for p in ((0.004, 0.003, 0.002), (0.02, 0.0, 0.01), (0.0, 0.0, 0.0)):
+        got = ctx.mc_run(c1, c2, 77, 123456, 3000, *p, _native.HIST_WEIGHT)
+        want = c_oracle.mc(h1, r1, h2, r2, n, 77, 123456, 3000, *p, 1)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (case, p)
