@@ -62,6 +62,4 @@ for name, code, count in (("steane", CSSCode(steane, steane), 10**8), ("rm15", C
     print("  %s H2 (%dx%d) bit-sliced (%.2f GiB working set): %.3f ms for 2^31 samples = %.3e syndromes/s, %.0f GB/s "
           "= algorithmic (%.2f B/sample), %.1f%% of 8 TB/s"
           % (name, r2, n, moved / 2**30, ms, big / ms * 1e3, moved / ms / 1e6, (n + r2) / 8, moved / ms / 1e6 / 80))
-    # spot check of the bit-sliced result against the sample-major kernel on the first 4096 samples
-    first_e = eb.download((n, bw), "<u8")[:, :64] if False else None
     eb.free(), sb.free()

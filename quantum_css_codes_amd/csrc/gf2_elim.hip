@@ -56,10 +56,10 @@ __global__ __launch_bounds__(ELIM_THREADS) void eliminate_kernel(u64* __restrict
     int64_t lead = 0;              // RREF: next pivot row.  NORMALIZE: the diagonal index i.
     int64_t swap_count = 0;
     int64_t step_begin = 0, steps = MODE == ELIM_RREF ? n : m;
-    if (single) {
+    if (single) {                  // stalled == 1: one step; stalled == 2: every remaining step
         if (!single->stalled || single->rank >= m || status[blockIdx.x] != 0) return;
         step_begin = single->rank;
-        steps = step_begin + 1;
+        steps = single->stalled == 2 ? m : step_begin + 1;
         swap_count = nswaps[blockIdx.x];
     }
     for (int64_t step = step_begin; step < steps; ++step) {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(ELIM_THREADS) void eliminate_kernel(u64* __restrict
         if (MODE == ELIM_RREF && rank_base) rank_base[blockIdx.x] = lead;
         if (MODE == ELIM_NORMALIZE && nswaps) nswaps[blockIdx.x] = swap_count;
         if (single) {
-            single->rank = step_begin + 1;
+            single->rank = steps;
             single->stalled = 0;
         }
     }
@@ -1085,6 +1085,7 @@ int gf2_normalize_dev(gf2_ctx* ctx, uint64_t* h_dev, int64_t r, int64_t n, int64
     const int64_t rows_per_wg = gf2_cdiv(ld, 64) >= 8 ? 256 : 128;
     const dim3 ugrid((unsigned)gf2_cdiv(r, rows_per_wg), (unsigned)gf2_cdiv(ld, 64), 1);
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
+    int64_t last_rank = 0;
     for (int64_t round = 0;; ++round) {
 #define GF2_NP_LAUNCH(RPT)                                                                                              \
     hipLaunchKernelGGL((norm_panel_kernel<RPT>), dim3(1), dim3(RB_THREADS), 0, ctx->stream, (u64*)h_dev, r, n, ld, offset, \
@@ -1110,6 +1111,19 @@ int gf2_normalize_dev(gf2_ctx* ctx, uint64_t* h_dev, int64_t r, int64_t n, int64
             GF2_HIP(hipMemcpyAsync(&status, status_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
             GF2_HIP(hipStreamSynchronize(ctx->stream));
             if (status != 0 || (host.rank >= r && !host.stalled)) break;
+            if (host.rank - last_rank < 64) {
+                // mostly stalls (a matrix that needs a column swap at nearly every step): the panels do not pay;
+                // let the sequential kernel take every remaining step from here
+                host.stalled = 2;
+                GF2_HIP(hipMemcpyAsync(st, &host, sizeof(host), hipMemcpyHostToDevice, ctx->stream));
+                GF2_HIP(hipStreamSynchronize(ctx->stream));
+                hipLaunchKernelGGL(eliminate_kernel<ELIM_NORMALIZE>, dim3(1), dim3(ELIM_THREADS), 0, ctx->stream, (u64*)h_dev, r,
+                                   n, ld, offset, (int64_t*)nullptr, (int64_t)0, (int64_t*)nullptr, swaps_dev, nswaps_dev,
+                                   status_dev, st);
+                GF2_HIP(hipGetLastError());
+                break;
+            }
+            last_rank = host.rank;
         }
     }
     GF2_TRY(gf2_prof_end(ctx));

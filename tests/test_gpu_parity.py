@@ -640,3 +640,20 @@ def test_fused_sparse_monte_carlo_shapes(case, ctx):
         got = ctx.mc_run(c1, c2, 77, 123456, 3000, *p, _native.HIST_WEIGHT)
         want = c_oracle.mc(h1, r1, h2, r2, n, 77, 123456, 3000, *p, 1)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), (case, p)
+
+
+@pytest.mark.parametrize("case", [(300, 700, 0), (200, 900, 130)])
+def test_normalize_with_a_column_swap_at_every_step(case, ctx):
+    # the identity-target columns are all zero, so every step swaps a column in: the blocked panels stall each time and
+    # the kernel hands over to the sequential path; swaps and result must still be the reference's
+    r, n, off = case
+    rng = np.random.default_rng(r)
+    h = rng.integers(0, 2, (r, n))
+    h[:, off:off + r] = 0
+    h[:, off + r:off + 2 * r] = np.identity(r, dtype=int)[rng.permutation(r)]
+    packed = _native.pack_rows(h)
+    rc, want, want_swaps = c_oracle.normalize(packed, r, n, off)
+    assert rc == 0 and len(want_swaps) == r
+    swaps = ctx.normalize(packed, r, n, off)
+    assert swaps == want_swaps
+    assert np.array_equal(packed, want)
