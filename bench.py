@@ -30,8 +30,8 @@ The JSON line also carries
                 from the committed rocprofv3 passes (profiles/traffic.json).
   cpu_baseline  the reference's NumPy path (oracle/cpu_ref.py restatement of css_code.py:728) timed on this
                 host, 1 core, on a bounded sample of the same workload.
-  secondary     (rank 0, N = 1) the end-to-end Monte-Carlo (sampler included), the other syndrome kernel on the same
-                workload, and RREF GB/s
+  secondary     (rank 0, N = 1) the end-to-end Monte-Carlo (sampler included), the other syndrome kernels (column gather,
+                dense table) on the same workload, and RREF GB/s
                 (2 * m * ceil(n/64) * 8 bytes / time) for one and for 256 resident 2048 x 4096 matrices and for one
                 32768 x 65536 matrix.
 """
@@ -105,12 +105,21 @@ class Path(object):
             lde = _native.words_for(N_QUBITS)
             self.ex, self.ez = ctx.alloc(batch * lde * 8), ctx.alloc(batch * lde * 8)
             ctx.sample_errors_dev(N_QUBITS, SEED, first, batch, p, p, p, self.ex, self.ez, lde)
-            self.kernel = "syndrome_sparse_kernel"
+            self.kernel = "slab_pipeline"                                # compact + gather + combine, gf2_slabs.hip
             self.alg_bytes_per_sample = N_QUBITS / 8.0                   # SURVEY.md 8d read-only variant, per component
 
             def step():
                 ctx.syndrome_sparse_dev(chk1, self.ez, batch, lde, None, 0, self.hz, R1 + 1)
                 ctx.syndrome_sparse_dev(chk2, self.ex, batch, lde, None, 0, self.hx, R2 + 1)
+
+            def prefix_hist(count):
+                a, b = ctx.alloc((R1 + 1) * 8).zero(), ctx.alloc((R2 + 1) * 8).zero()
+                ctx.syndrome_sparse_dev(chk1, self.ez, count, lde, None, 0, a, R1 + 1)
+                ctx.syndrome_sparse_dev(chk2, self.ex, count, lde, None, 0, b, R2 + 1)
+                out = a.download((R1 + 1,), np.uint64), b.download((R2 + 1,), np.uint64)
+                a.free(), b.free()
+                return out
+            self.prefix_hist = prefix_hist
 
             def prefix(count):
                 a, b = ctx.alloc(count * self.ls1 * 8).zero(), ctx.alloc(count * self.ls2 * 8).zero()
@@ -154,6 +163,14 @@ class Path(object):
         assert np.array_equal(c_oracle.histogram(got1, 512, R1, 1, R1 + 1), want_z), "H1.e_z differs from the oracle"
         assert np.array_equal(c_oracle.histogram(got2, 512, R2, 1, R2 + 1), want_x), "H2.e_x differs from the oracle"
         assert int(self.hz.download((R1 + 1,), np.uint64).sum()) == self.batch
+        if self.algo == "sparse":
+            # the histogram-only route of the timed region (LDS-slab pipeline), forced onto the same 512-sample prefix
+            os.environ["GF2_SPARSE_SLABS"] = "1"
+            try:
+                got_z, got_x = self.prefix_hist(512)
+            finally:
+                del os.environ["GF2_SPARSE_SLABS"]
+            assert np.array_equal(got_z, want_z) and np.array_equal(got_x, want_x), "slab pipeline differs from the oracle"
 
     def free(self):
         for name in ("ex", "ez", "s1", "s2", "hz", "hx"):
@@ -322,6 +339,19 @@ def main():
             out["cpu_baseline"] = cpu_baseline(code)
         if world == 1 and not args.no_secondary:
             single_z = (hist_z // np.uint64(args.steps)).astype(np.uint64)      # same batch every step
+            gather = None
+            if args.algo == "sparse":
+                # the same resident errors through the wavefront-per-sample column-gather kernel (gf2_sparse.hip)
+                os.environ["GF2_SPARSE_GATHER"] = "1"
+                try:
+                    g_ms, g_launch, g_n, _ = timed(ctx, path, 10, 2)
+                    assert np.array_equal(path.hz.download((R1 + 1,), np.uint64), single_z * np.uint64(10)), \
+                        "column-gather kernel and slab pipeline disagree"
+                finally:
+                    del os.environ["GF2_SPARSE_GATHER"]
+                path.kernel = "syndrome_sparse_kernel"
+                gather = {"value": 10 * batch / (g_ms / 1e3), "unit": "syndromes/s", "ms_per_step": g_ms / 10,
+                          "roofline": roofline(path, g_launch, g_n)}
             path.free()
             other = Path(ctx, "dense" if args.algo == "sparse" else "sparse", chk1, chk2, batch, first)
             other.check_against_oracle(h1, h2, first)
@@ -343,6 +373,8 @@ def main():
                 other.algo + "_kernel": {"value": 10 * batch / (o_ms / 1e3), "unit": "syndromes/s", "ms_per_step": o_ms / 10,
                                          "roofline": roofline(other, o_launch, o_n), "histogram_ms_per_step": o_hist / 10},
                 "rref": rref_numbers(ctx)}
+            if gather is not None:
+                out["secondary"]["column_gather_kernel"] = gather
             other.free()
         print(json.dumps(out))
     if world > 1:

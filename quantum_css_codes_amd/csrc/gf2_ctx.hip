@@ -64,7 +64,7 @@ int gf2_ctx_destroy(gf2_ctx* ctx) {
     if (!ctx) return GF2_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 3; ++k)
         if (ctx->ws[k]) (void)hipFree(ctx->ws[k]);
     for (int i = 0; i < gf2_ctx::kProfSlots; ++i) {
         (void)hipEventDestroy(ctx->prof_ev[i][0]);

@@ -50,12 +50,13 @@ struct gf2_ctx {
     hipEvent_t prof_ev[kProfSlots][2];
     int prof_family[kProfSlots];
     int prof_used;
-    // workspaces grown on demand: slot 0 = Monte-Carlo pipeline, slot 1 = re-tiling of sample-major errors
-    void* ws[2];
-    size_t ws_bytes[2];
+    // workspaces grown on demand: slot 0 = Monte-Carlo pipeline, slot 1 = re-tiling of sample-major errors,
+    // slot 2 = records and partial weights of the LDS-slab sparse pipeline
+    void* ws[3];
+    size_t ws_bytes[3];
     // large dynamic-LDS opt-in (hipFuncSetAttribute) done for this context's device: [0] syndrome_tiled_kernel,
-    // [1] rref_update_kernel
-    bool lds_optin[2];
+    // [1] rref_update_kernel, [2] syndrome_slabs_kernel
+    bool lds_optin[3];
 };
 
 int gf2_ctx_activate(gf2_ctx* ctx);
@@ -87,10 +88,18 @@ struct gf2_check {
     // identity block's columns are zero); null when unsupported (small check, r > 8192)
     uint32_t* ht_dev;
     int ht_k;
+    // row-slab tables of the LDS sparse pipeline (gf2_slabs.hip): nslabs512 x slab_cols entries of 64 bytes (512 rows of
+    // one non-identity column; the last entry of a slab is zero); null when the check does not qualify
+    void* slab_tab_dev;
+    int slab_cols, slab_null, nslabs512;   // entries per row-part plane, index of a zero entry, row slabs
     uint64_t rows_small[64];
 };
 
 int gf2_build_columns(gf2_ctx* ctx, gf2_check* ck);
+int gf2_build_slab_table(gf2_ctx* ctx, gf2_check* ck);
+bool gf2_slabs_ok(const gf2_check* ck);
+int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde,
+                       uint64_t* hist_dev);
 bool gf2_mc_sparse_fused_ok(const gf2_check* c1, const gf2_check* c2);
 int gf2_mc_sparse_fused(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t seed, int64_t first_sample,
                         int64_t count, double p_x, double p_y, double p_z, uint64_t* hz_dev, uint64_t* hx_dev);

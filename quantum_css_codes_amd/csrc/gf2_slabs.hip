@@ -1,0 +1,541 @@
+// Sparse-error syndrome weights with the transposed check resident in LDS (gfx950).
+//
+// Same product as np.mod(np.matmul(parity_check, e), 2) (css_code.py:728), reduced to the weight histogram the
+// Monte-Carlo workload keeps.  The wavefront-per-sample kernel (gf2_sparse.hip) gathers 256-byte columns of the
+// transposed check from L2 and is bound by L2 gather bandwidth (about 14 column reads per sample and component at
+// the benchmark's p = 0.01).  Here the check never moves: the rows are cut into slabs of 512, every CU keeps ONE slab
+// of the transposed check in LDS for the whole launch (64 bytes per non-identity column, 128 KiB at n = 4096), and
+// the samples visit the slabs.  Three kernels on the context's stream:
+//
+//   compact   wavefront = 64 samples at a time, lane = 64-bit word of the packed error row (512 contiguous bytes per
+//             load; words inside the identity block are not read).  Non-zero words are compacted (ballot + mbcnt)
+//             into a per-wave item list; then lane = item, and each set bit appends its column's ordinal to the
+//             sample's 64-byte record (slot 0 = count, up to 31 columns, slots taken with an LDS atomic; order is
+//             irrelevant to an XOR).  Records go to a workspace, 4 KiB contiguous per wavefront.  A sample with more
+//             columns than a record holds is finished on the spot by the wavefront-per-sample routine.
+//   gather    workgroup = (slab, share of the samples), 16 wavefronts, no barrier after the table is loaded.  Four
+//             lanes per sample, 128 rows each: start from the identity-block bits of the error row (64 contiguous
+//             bytes per sample and slab, read straight from the packed errors), XOR one ds_read_b128 per listed column
+//             (unused slots point at a zero entry, so there is no per-lane predicate), popcount, 2 DPP adds, one
+//             16-bit partial weight per sample and slab.
+//   combine   lane = sample: adds the partial weights and counts the total in an LDS-privatised histogram.
+//
+// Every byte of the errors is read once from HBM (non-identity words by compact, identity words by gather); the
+// records add 64 bytes written and 64 bytes read per slab and sample.  A lookup is 64 bytes wide per sample, so a
+// group of 16 lanes holds 4 samples on 4 sixteen-bank quarters: 2.1 LDS cycles per group on average with random
+// columns.
+#include "gf2_internal.h"
+#include "gf2_sparse_dev.h"
+
+#define CMP_WAVES 4
+#define CMP_THREADS (64 * CMP_WAVES)
+#define CMP_SUB 16                            // samples per compaction sub-pass
+#define CMP_ITEM_CAP 320                      // non-zero words per sub-pass (expected ~180 at p = 0.01)
+#define REC_SLOTS 32                          // 16-bit slots per record: count + 31 columns
+#define REC_OVER 0xFFu                        // count byte of a sample that was finished by the slow routine
+#define REC_FLAG 0xFFFFu                      // its partial weights
+#define GAT_THREADS 1024
+#define GAT_WAVES 16
+#define SLAB_ROWS 512
+#define SLAB_MAX_COLS 2400                    // (cols + 1) * 64 bytes of LDS <= 150 KiB
+#define SLAB_MAX_BINS 2304
+#define SLAB_MAX_BATCH (1 << 21)              // samples per pass through the workspace
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_ptr;
+
+__device__ __forceinline__ unsigned int wave_max(unsigned int v) {
+    v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xF, 0xF, true));
+    v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xF, 0xF, true));
+    v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0u, v, 0x141, 0xF, 0xF, true));
+    v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0u, v, 0x140, 0xF, 0xF, true));
+    v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0u, v, 0x142, 0xA, 0xF, true));
+    v = max(v, (unsigned int)__builtin_amdgcn_update_dpp(0u, v, 0x143, 0xC, 0xF, true));
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// ---- compact ---------------------------------------------------------------------------------------------------------
+
+struct CompactArgs {
+    const u64* e;
+    const uint32_t* ht;        // transposed check of the wavefront-per-sample routine (samples beyond a record)
+    u32x4* rec;                // ceil(batch / 64) * 64 records of 64 bytes
+    u64* hist;
+    int64_t batch, lde;
+    int r, n, ident_off, null_ord;
+};
+
+// LDS per wavefront: item list (values + tags), the 64 records as four planes (plane q = slots 8q..8q+7, 16 bytes per
+// sample, so that both the lane = item stores and the lane = sample reads are spread over the banks), the counters.
+struct CompactWaveLds {
+    u64 item_v[CMP_ITEM_CAP];
+    unsigned short item_m[CMP_ITEM_CAP];
+    unsigned char pad[4096 - CMP_ITEM_CAP * 10];
+    unsigned char planes[4096];
+    unsigned int cnt[64];
+};
+
+// Word `lane` of the 16 error rows that start at sample s_first (lanes whose word lies inside the identity block load
+// nothing; rows past the batch are clamped and masked by the caller).
+__device__ __forceinline__ void load_rows(const CompactArgs& a, int64_t s_first, u64 amask, int lane, u64 (&w)[CMP_SUB]) {
+#pragma unroll
+    for (int j = 0; j < CMP_SUB; ++j) w[j] = 0;
+    if (amask) {
+#pragma unroll
+        for (int j = 0; j < CMP_SUB; ++j) {
+            const int64_t sample = s_first + j;
+            w[j] = a.e[(sample < a.batch ? sample : a.batch - 1) * a.lde + lane];
+        }
+    }
+}
+
+__global__ __launch_bounds__(CMP_THREADS, 4) void slab_compact_kernel(CompactArgs a) {
+    __shared__ CompactWaveLds lds_all[CMP_WAVES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    CompactWaveLds& L = lds_all[wave];
+
+    const int words = (a.n + 63) >> 6;
+    u64 amask = 0;                                     // the non-identity columns of word `lane`
+    if (lane < words) {
+        amask = ~ident_mask(a.ident_off, a.r, lane);
+        if (lane == words - 1 && (a.n & 63)) amask &= ~(~0ull << (a.n & 63));
+    }
+    const unsigned int null_ent = (unsigned int)a.null_ord << 4;        // entries are LDS byte offsets inside a row-part plane
+    const unsigned int null2 = null_ent | (null_ent << 16);
+    const u32x4 null4 = {null2, null2, null2, null2};
+    const SparseSide side = {a.ht, (int64_t)a.r, (int64_t)a.ident_off, nullptr, 0};
+
+    const int64_t ntiles = (a.batch + 63) >> 6;
+    const int64_t total_waves = (int64_t)gridDim.x * CMP_WAVES;
+    // The 16 row loads of a sub-pass issue back to back (one branch around them, rows clamped into the batch), and the
+    // loads of the next sub-pass are in flight while this one is compacted.
+    u64 wn[CMP_SUB];
+    load_rows(a, ((int64_t)blockIdx.x * CMP_WAVES + wave) * 64, amask, lane, wn);
+#pragma unroll 1
+    for (int64_t tile = (int64_t)blockIdx.x * CMP_WAVES + wave; tile < ntiles; tile += total_waves) {
+        const int64_t s0 = tile * 64;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) reinterpret_cast<u32x4*>(L.planes)[q * 64 + lane] = null4;
+        L.cnt[lane] = 0;
+#pragma unroll 1
+        for (int sub = 0; sub < 64 / CMP_SUB; ++sub) {
+            u64 w[CMP_SUB];
+#pragma unroll
+            for (int j = 0; j < CMP_SUB; ++j) w[j] = s0 + sub * CMP_SUB + j < a.batch ? wn[j] & amask : 0ull;
+            {
+                const int64_t nxt = sub + 1 < 64 / CMP_SUB ? s0 + (sub + 1) * CMP_SUB : (tile + total_waves) * 64;
+                load_rows(a, nxt, amask, lane, wn);
+            }
+            unsigned int base = 0;
+#pragma unroll
+            for (int j = 0; j < CMP_SUB; ++j) {
+                const bool nz = w[j] != 0;
+                const u64 act = __ballot(nz);
+                if (nz) {
+                    const unsigned int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(act >> 32),
+                                                        __builtin_amdgcn_mbcnt_lo((unsigned int)act, 0u));
+                    if (pos < CMP_ITEM_CAP) {
+                        L.item_v[pos] = w[j];
+                        L.item_m[pos] = (unsigned short)(((sub * CMP_SUB + j) << 6) | lane);
+                    }
+                }
+                base += (unsigned int)__popcll(act);
+            }
+            wave_lds_sync();
+            if (base > CMP_ITEM_CAP) {                              // uniform: these 16 samples take the slow routine
+                if ((lane >> 4) == sub) L.cnt[lane] = 1000;
+                base = 0;
+            }
+            for (unsigned int i0 = 0; i0 < base; i0 += 64) {
+                const unsigned int i = i0 + lane;
+                if (i < base) {
+                    u64 v = L.item_v[i];
+                    const unsigned int m = L.item_m[i];
+                    const unsigned int j = m >> 6, col0 = (m & 63u) << 6;
+                    unsigned char* const myrec = L.planes + j * 16;
+                    unsigned int slot = atomicAdd(&L.cnt[j], (unsigned int)__popcll(v)) + 1u;   // one reservation per word
+                    while (v) {
+                        const unsigned int col = col0 + (unsigned int)(__ffsll((long long)v) - 1);
+                        v &= v - 1;
+                        const unsigned int ord = (a.ident_off >= 0 && (int)col >= a.ident_off) ? col - a.r : col;
+                        if (slot < REC_SLOTS)
+                            *reinterpret_cast<unsigned short*>(myrec + (slot >> 3) * 1024 + (slot & 7) * 2) =
+                                (unsigned short)(ord << 4);
+                        ++slot;
+                    }
+                }
+            }
+            wave_lds_sync();
+        }
+
+        // lane = sample from here on
+        const unsigned int c = L.cnt[lane];
+        const bool over = c >= REC_SLOTS;
+        {
+            u64 todo = __ballot(over && s0 + lane < a.batch);
+            unsigned int* const slow_list = reinterpret_cast<unsigned int*>(&L);    // the item list is free now
+            while (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const u64 ww = lane < words ? a.e[(s0 + j) * a.lde + lane] : 0ull;
+                const unsigned int wt = sparse_component_weight(ww, side, a.n, lane, slow_list);
+                if (lane == 0) atomicAdd(&a.hist[wt], 1ull);
+            }
+            wave_lds_sync();
+        }
+        // Records leave the tile sorted by count (counting sort over the 64 samples): the gather kernel walks 16 records
+        // per step up to the largest count among them.  Slot 0 = count (REC_OVER: finished by the slow routine) | tile-local sample << 8.
+        const unsigned int key = over ? 0u : c;
+        unsigned int* const sort_bins = reinterpret_cast<unsigned int*>(&L);          // 32 bins + 32 offsets, item list is free
+        if (lane < 32) sort_bins[lane] = 0;
+        wave_lds_sync();
+        const unsigned int in_bucket = atomicAdd(&sort_bins[key], 1u);
+        wave_lds_sync();
+        {
+            unsigned int run = lane < 32 ? sort_bins[lane] : 0u;                      // inclusive scan over the bins
+#pragma unroll
+            for (int d = 1; d < 32; d <<= 1) {
+                const unsigned int up = __shfl_up(run, d);
+                if (lane >= d) run += up;
+            }
+            if (lane < 32) sort_bins[32 + lane] = run - sort_bins[lane];
+        }
+        wave_lds_sync();
+        const unsigned int rank = sort_bins[32 + key] + in_bucket;
+        u32x4 R[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) R[q] = reinterpret_cast<const u32x4*>(L.planes)[q * 64 + lane];
+        R[0].x = (R[0].x & 0xFFFF0000u) | (over ? REC_OVER : c) | ((unsigned int)lane << 8);
+        u32x4* out = a.rec + (s0 + rank) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q] = R[q];
+        wave_lds_sync();
+    }
+}
+
+// ---- gather ----------------------------------------------------------------------------------------------------------
+
+struct GatherArgs {
+    const u32x4* tab;          // nslabs x tab_cols x 4 vectors: entry (slab, ord) = rows 512 slab .. + 511 of column ord
+    const u64* e;
+    const u32x4* rec;
+    unsigned short* pw;        // nslabs x batch_pad partial weights
+    int64_t batch, batch_pad, lde;
+    int tab_stride, nslabs, r, ident_off, null_ord;   // tab_stride: entries per row-part plane (= 4 mod 16)
+};
+
+__device__ __forceinline__ unsigned int keep_rows(int r, int row0) {
+    const int left = r - row0;
+    return left >= 32 ? ~0u : (left <= 0 ? 0u : ~(~0u << left));
+}
+
+// LDS offset of a table entry: plane base of this lane's row part + the 16-bit entry (one SDWA add per lookup).
+__device__ __forceinline__ unsigned int entry_addr_lo(unsigned int part_base, unsigned int pair) {
+    unsigned int out;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(out) : "v"(part_base), "v"(pair));
+    return out;
+}
+__device__ __forceinline__ unsigned int entry_addr_hi(unsigned int part_base, unsigned int pair) {
+    unsigned int out;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(out) : "v"(part_base), "v"(pair));
+    return out;
+}
+
+// Record at position `pos` (all four lanes of a record load the same 64 bytes); positions past the end read zeros.
+__device__ __forceinline__ void fetch_record(__amdgpu_buffer_rsrc_t rec_rsrc, unsigned int pos, u32x4 (&R)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) R[q] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, pos << 6, q * 16, 0);
+}
+
+// The five error dwords that hold the identity-block bits of this lane's 128 rows of sample `sample`; addresses clamped into
+// the row, the caller masks what lies outside.  No select on loaded values, so the loads stay in flight.
+__device__ __forceinline__ void fetch_ident(const GatherArgs& a, unsigned int sample, unsigned int row_bytes, unsigned int dw0,
+                                            unsigned int row_dwords, bool aligned16, int id_sh, bool last_part,
+                                            unsigned int (&iw)[5]) {
+#pragma unroll
+    for (int t = 0; t < 5; ++t) iw[t] = 0;
+    if (a.ident_off < 0) return;
+    const unsigned int* rowp32 = reinterpret_cast<const unsigned int*>(
+        reinterpret_cast<const char*>(a.e) + (u64)(sample < (unsigned int)a.batch ? sample : 0u) * row_bytes);
+    if (aligned16) {
+        const u32x4 x = *reinterpret_cast<const u32x4*>(rowp32 + dw0);
+        iw[0] = x.x;
+        iw[1] = x.y;
+        iw[2] = x.z;
+        iw[3] = x.w;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) iw[t] = rowp32[dw0 + t < row_dwords ? dw0 + t : 0u];
+    }
+    if (id_sh) {
+        // the fifth dword is the neighbouring row part's first one; only the last part of the slab loads it
+        if (last_part || !aligned16) iw[4] = rowp32[dw0 + 4 < row_dwords ? dw0 + 4 : 0u];
+    }
+}
+
+// Sample a record belongs to: records are permuted inside their tile of 64 (slot 0 carries the tile-local index).
+__device__ __forceinline__ unsigned int record_sample(unsigned int pos, unsigned int slot0) {
+    return (pos & ~63u) + ((slot0 >> 8) & 63u);
+}
+
+__global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs a) {
+    extern __shared__ __align__(16) unsigned char lds[];            // the only LDS: the table starts at LDS address 0
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // Workgroups b and b + 8 run on the same XCD (round-robin dispatch).  The nslabs workgroups that walk the same
+    // samples are put on one XCD, so that a record (and the 128-byte lines of the error rows that two slabs share) is
+    // fetched from HBM once and found in that XCD's L2 by the other slabs.
+    int slab, share;
+    const int shares = gridDim.x / a.nslabs;
+    if ((shares & 7) == 0) {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        slab = local % a.nslabs;
+        share = (local / a.nslabs) * 8 + xcd;
+    } else {
+        slab = blockIdx.x % a.nslabs;
+        share = blockIdx.x / a.nslabs;
+    }
+    {
+        const u32x4* src = a.tab + (int64_t)slab * a.tab_stride * 4;
+        for (int v = threadIdx.x; v < a.tab_stride * 4; v += GAT_THREADS) reinterpret_cast<u32x4*>(lds)[v] = src[v];
+    }
+    __syncthreads();
+
+    const int part = lane & 3;                                      // rows 128 part .. 128 part + 127 of the slab
+    const unsigned int part_base = (unsigned int)part * (unsigned int)a.tab_stride * 16u;
+    const int row0 = slab * SLAB_ROWS + part * 128;
+    unsigned int keep[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) keep[q] = keep_rows(a.r, row0 + 32 * q);
+    const int id_sh = a.ident_off >= 0 ? (a.ident_off & 31) : 0;
+    // first identity dword of the slab (uniform) and of this lane: rows are multiples of 128, so the split is exact
+    const unsigned int slab_dw0 = a.ident_off >= 0 ? (unsigned int)(a.ident_off >> 5) + slab * (SLAB_ROWS / 32) : 0u;
+    const unsigned int dw0 = slab_dw0 + part * 4;
+    const unsigned int row_dwords = (unsigned int)a.lde * 2u, row_bytes = (unsigned int)a.lde * 8u;
+    const bool aligned16 = (a.lde & 1) == 0 && (reinterpret_cast<uintptr_t>(a.e) & 15) == 0 && (slab_dw0 & 3) == 0 &&
+                           slab_dw0 + 16 <= row_dwords;      // uniform: one 16-byte load per lane
+    unsigned int inrow[5];                                          // error dwords past the end of the row read as zero
+#pragma unroll
+    for (int t = 0; t < 5; ++t) inrow[t] = (a.ident_off >= 0 && dw0 + t < row_dwords && (t < 4 || id_sh)) ? ~0u : 0u;
+    const unsigned int null_ent = (unsigned int)a.null_ord << 4;
+    const bool from_neighbour = id_sh != 0 && aligned16;            // uniform
+    bool mask_ident = a.ident_off >= 0 && (slab + 1) * SLAB_ROWS > a.r;              // uniform: rows past r in this slab
+    if (a.ident_off >= 0 && slab_dw0 + 17 > row_dwords) mask_ident = true;           // or dwords past the end of the row
+    const __amdgpu_buffer_rsrc_t rec_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.rec), 0, (int)(a.batch_pad * 64), 0x00020000);
+    unsigned short* const pw = a.pw + (int64_t)slab * a.batch_pad;
+
+    const unsigned int ngroups = (unsigned int)(a.batch_pad >> 4);  // 16 records per wavefront step
+    const unsigned int stride = (unsigned int)shares * GAT_WAVES;
+    const unsigned int lane_rec = lane >> 2;
+
+    // Software pipeline, two stages: the records of step i + 2 and the identity words of step i + 1 (their address needs
+    // the record) are in flight while the lookups of step i run.  Three record and three identity buffers take turns
+    // (the loop is unrolled by three), so nothing is copied between stages.
+    u32x4 RA[4], RB[4], RC[4];
+    unsigned int iwA[5], iwB[5], iwC[5];
+    unsigned int grp = (unsigned int)share * GAT_WAVES + wave;
+    fetch_record(rec_rsrc, grp * 16 + lane_rec, RA);
+    fetch_record(rec_rsrc, (grp + stride) * 16 + lane_rec, RB);
+    fetch_ident(a, record_sample(grp * 16 + lane_rec, RA[0].x), row_bytes, dw0, row_dwords, aligned16, id_sh, part == 3, iwA);
+
+    auto step = [&](u32x4 (&R)[4], unsigned int (&iw)[5], u32x4 (&Rnext)[4], u32x4 (&Rfar)[4], unsigned int (&iwnext)[5]) {
+        const unsigned int pos = grp * 16 + lane_rec;
+        fetch_record(rec_rsrc, pos + 2 * stride * 16, Rfar);
+        fetch_ident(a, record_sample(pos + stride * 16, Rnext[0].x), row_bytes, dw0, row_dwords, aligned16, id_sh, part == 3,
+                    iwnext);
+        const unsigned int slot0 = R[0].x & 0xFFFFu;
+        const bool flagged = (slot0 & 0xFFu) == REC_OVER;
+        const unsigned int sample = record_sample(pos, slot0);
+        const bool valid = sample < (unsigned int)a.batch;
+        const unsigned int c = flagged || !valid ? 0u : (slot0 & 0xFFu);
+        if (from_neighbour) {                                       // quad_perm [1,2,3,3]: lane p takes lane p + 1's first dword
+            const unsigned int nb = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)iw[0], 0xF9, 0xF, 0xF, false);
+            if (part != 3) iw[4] = nb;
+        }
+        if (mask_ident) {                                           // uniform: only a slab that ends the rows or the row needs it
+#pragma unroll
+            for (int t = 0; t < 5; ++t) iw[t] &= inrow[t];
+        }
+        unsigned int X[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) X[q] = __builtin_amdgcn_alignbit(iw[q + 1], iw[q], id_sh);
+        if (mask_ident) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) X[q] &= keep[q];
+        }
+        // the tile is sorted by count (finished and out-of-batch samples first, as 0): the last record has the most slots
+        const unsigned int mx = (unsigned int)__builtin_amdgcn_readlane((int)c, 63) + 1u;
+        const unsigned int first_pair = (R[0].x & 0xFFFF0000u) | null_ent;    // slot 0 becomes a zero entry
+#pragma unroll
+        for (int k0 = 0; k0 < REC_SLOTS; k0 += 4) {
+            if ((unsigned int)k0 >= mx) break;
+            const unsigned int lo = k0 == 0 ? first_pair : (k0 & 4 ? R[k0 >> 3].z : R[k0 >> 3].x);
+            const unsigned int hi = k0 & 4 ? R[k0 >> 3].w : R[k0 >> 3].y;
+            const u32x4 v0 = *(lds_u32x4_ptr)(uintptr_t)entry_addr_lo(part_base, lo);
+            const u32x4 v1 = *(lds_u32x4_ptr)(uintptr_t)entry_addr_hi(part_base, lo);
+            const u32x4 v2 = *(lds_u32x4_ptr)(uintptr_t)entry_addr_lo(part_base, hi);
+            const u32x4 v3 = *(lds_u32x4_ptr)(uintptr_t)entry_addr_hi(part_base, hi);
+            X[0] ^= v0.x ^ v1.x ^ v2.x ^ v3.x;
+            X[1] ^= v0.y ^ v1.y ^ v2.y ^ v3.y;
+            X[2] ^= v0.z ^ v1.z ^ v2.z ^ v3.z;
+            X[3] ^= v0.w ^ v1.w ^ v2.w ^ v3.w;
+        }
+        unsigned int wt = __popc(X[0]) + __popc(X[1]) + __popc(X[2]) + __popc(X[3]);
+        wt += __builtin_amdgcn_update_dpp(0u, wt, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+        wt += __builtin_amdgcn_update_dpp(0u, wt, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+        if (part == 0 && valid) pw[sample] = (unsigned short)(flagged ? REC_FLAG : wt);
+    };
+#pragma unroll 1
+    while (grp < ngroups) {
+        step(RA, iwA, RB, RC, iwB);
+        grp += stride;
+        if (grp >= ngroups) break;
+        step(RB, iwB, RC, RA, iwC);
+        grp += stride;
+        if (grp >= ngroups) break;
+        step(RC, iwC, RA, RB, iwA);
+        grp += stride;
+    }
+}
+
+// ---- combine ---------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void slab_combine_kernel(const unsigned short* __restrict__ pw, int64_t batch, int64_t batch_pad,
+                                                          int nslabs, u64* __restrict__ hist, int nbins) {
+    __shared__ unsigned int bins[SLAB_MAX_BINS];
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) bins[i] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
+    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; s < batch; s += stride) {
+        unsigned int w0 = 0, w1 = 0;
+        bool skip0 = false, skip1 = s + 1 >= batch;
+        for (int k = 0; k < nslabs; ++k) {
+            const unsigned int two = *reinterpret_cast<const unsigned int*>(pw + (int64_t)k * batch_pad + s);
+            skip0 |= (two & 0xFFFFu) == REC_FLAG;
+            skip1 |= (two >> 16) == REC_FLAG;
+            w0 += two & 0xFFFFu;
+            w1 += two >> 16;
+        }
+        if (!skip0) atomicAdd(&bins[w0], 1u);
+        if (!skip1) atomicAdd(&bins[w1], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x)
+        if (bins[i]) atomicAdd(&hist[i], (u64)bins[i]);
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------
+
+// tab[slab][part][ord] (16 bytes) = rows 512 slab + 128 part .. + 127 of the ord-th non-identity column; ht has 64 dwords
+// per column.  Entries ncols .. stride - 1 of every plane are zero.
+__global__ void build_slab_table_kernel(const uint32_t* __restrict__ ht, int n, int r, int ident_off, int ncols, int stride,
+                                        int nslabs, u32x4* __restrict__ tab) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;        // (part, ord)
+    const int slab = blockIdx.y;
+    if (idx >= stride * 4 || slab >= nslabs) return;
+    const int part = idx / stride, ord = idx % stride;
+    u32x4 v = {0, 0, 0, 0};
+    if (ord < ncols) {
+        const int col = (ident_off >= 0 && ord >= ident_off) ? ord + r : ord;
+        if (col < n) v = *reinterpret_cast<const u32x4*>(ht + (int64_t)col * 64 + 16 * slab + 4 * part);
+    }
+    tab[(int64_t)slab * stride * 4 + idx] = v;
+}
+
+int gf2_build_slab_table(gf2_ctx* ctx, gf2_check* ck) {
+    ck->slab_tab_dev = nullptr;
+    ck->slab_cols = 0;
+    ck->nslabs512 = 0;
+    if (!ck->ht_dev || ck->ht_k != 1 || ck->n > 4096) return GF2_OK;
+    const int64_t ncols = ck->ident_off >= 0 ? ck->n - ck->r : ck->n;
+    if (ncols > SLAB_MAX_COLS || ck->r + 1 > SLAB_MAX_BINS) return GF2_OK;
+    const int nslabs = (int)gf2_cdiv(ck->r, SLAB_ROWS);
+    // entries per plane: the columns, at least one zero entry, padded to 4 mod 16 so that the four row parts of one entry
+    // sit on four different quarters of the LDS banks
+    int stride = (int)ncols + 1;
+    while ((stride & 15) != 4) ++stride;
+    GF2_TRY(gf2_dev_alloc(ctx, (size_t)nslabs * stride * 64, (void**)&ck->slab_tab_dev));
+    dim3 grid((unsigned)gf2_cdiv(stride * 4, 256), (unsigned)nslabs);
+    hipLaunchKernelGGL(build_slab_table_kernel, grid, dim3(256), 0, ctx->stream, (const uint32_t*)ck->ht_dev, (int)ck->n,
+                       (int)ck->r, (int)ck->ident_off, (int)ncols, stride, nslabs, (u32x4*)ck->slab_tab_dev);
+    GF2_HIP(hipGetLastError());
+    GF2_HIP(hipStreamSynchronize(ctx->stream));
+    ck->slab_cols = stride;
+    ck->slab_null = (int)ncols;
+    ck->nslabs512 = nslabs;
+    return GF2_OK;
+}
+
+bool gf2_slabs_ok(const gf2_check* ck) { return ck->slab_tab_dev != nullptr; }
+
+// Weight histogram of batch resident sample-major errors (hist: r + 1 bins, accumulated into).
+int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde,
+                       uint64_t* hist_dev) {
+    const int nbins = (int)ck->r + 1;
+    const size_t lds_bytes = (size_t)ck->slab_cols * 64;
+    if (!ctx->lds_optin[2]) {
+        GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
+        ctx->lds_optin[2] = true;
+    }
+    const int64_t pass = batch < SLAB_MAX_BATCH ? batch : SLAB_MAX_BATCH;
+    const int64_t pad = gf2_cdiv(pass, 64) * 64;
+    const size_t rec_bytes = (size_t)pad * 64, pw_bytes = (size_t)ck->nslabs512 * pad * 2;
+    GF2_TRY(gf2_ws_reserve(ctx, 2, rec_bytes + pw_bytes));
+    u32x4* rec = (u32x4*)ctx->ws[2];
+    unsigned short* pw = (unsigned short*)((char*)ctx->ws[2] + rec_bytes);
+    for (int64_t first = 0; first < batch; first += pass) {
+        const int64_t count = batch - first < pass ? batch - first : pass;
+        const uint64_t* e = e_dev + first * lde;
+        CompactArgs ca;
+        ca.e = (const u64*)e;
+        ca.ht = ck->ht_dev;
+        ca.rec = rec;
+        ca.hist = (u64*)hist_dev;
+        ca.batch = count;
+        ca.lde = lde;
+        ca.r = (int)ck->r;
+        ca.n = (int)ck->n;
+        ca.ident_off = (int)ck->ident_off;
+        ca.null_ord = ck->slab_null;
+        int64_t cblocks = gf2_cdiv(gf2_cdiv(count, 64), CMP_WAVES);
+        if (cblocks > (int64_t)ctx->num_cus * 4) cblocks = (int64_t)ctx->num_cus * 4;
+        hipLaunchKernelGGL(slab_compact_kernel, dim3((unsigned)cblocks), dim3(CMP_THREADS), 0, ctx->stream, ca);
+        GF2_HIP(hipGetLastError());
+
+        GatherArgs ga;
+        ga.tab = (const u32x4*)ck->slab_tab_dev;
+        ga.e = (const u64*)e;
+        ga.rec = rec;
+        ga.pw = pw;
+        ga.batch = count;
+        ga.batch_pad = pad;
+        ga.lde = lde;
+        ga.tab_stride = ck->slab_cols;
+        ga.nslabs = ck->nslabs512;
+        ga.r = (int)ck->r;
+        ga.ident_off = (int)ck->ident_off;
+        ga.null_ord = ck->slab_null;
+        int64_t shares = ctx->num_cus / ck->nslabs512;
+        const int64_t max_shares = gf2_cdiv(gf2_cdiv(count, 16), GAT_WAVES);
+        if (shares > max_shares) shares = max_shares;
+        if (shares < 1) shares = 1;
+        hipLaunchKernelGGL(slab_gather_kernel, dim3((unsigned)(shares * ck->nslabs512)), dim3(GAT_THREADS), lds_bytes,
+                           ctx->stream, ga);
+        GF2_HIP(hipGetLastError());
+
+        int64_t mblocks = gf2_cdiv(count, 512);
+        if (mblocks > (int64_t)ctx->num_cus * 2) mblocks = (int64_t)ctx->num_cus * 2;
+        hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3(256), 0, ctx->stream, pw, count, pad,
+                           ck->nslabs512, (u64*)hist_dev, nbins);
+        GF2_HIP(hipGetLastError());
+    }
+    return GF2_OK;
+}

@@ -21,8 +21,8 @@
 // The dense Four-Russians kernel (gf2_syndrome.hip) remains the data-independent path; DESIGN.md gives the crossover.
 #include "gf2_internal.h"
 #include "gf2_sampler.h"
+#include "gf2_sparse_dev.h"
 
-#define SPARSE_LIST_CAP 512
 #define SPARSE_WAVES 8
 
 // grid (slabs, words of n), block 64.  Lane i holds row 64*slab+i; column 64*word+b of the slab is the ballot of
@@ -49,27 +49,6 @@ __global__ void build_columns_kernel(const uint64_t* __restrict__ h, int64_t r, 
     }
     const int64_t col = word * 64 + lane;
     if (col < n) cols[col * ldc64 + slab] = mine;
-}
-
-// Sum over the 64 lanes (returned uniformly): DPP butterfly inside each row of 16, then row broadcasts.
-__device__ __forceinline__ unsigned int wave_total(unsigned int v) {
-    v += __builtin_amdgcn_update_dpp(0u, v, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0u, v, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0u, v, 0x141, 0xF, 0xF, true);   // row_half_mirror
-    v += __builtin_amdgcn_update_dpp(0u, v, 0x140, 0xF, 0xF, true);   // row_mirror
-    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xA, 0xF, true);   // row_bcast15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xC, 0xF, true);   // row_bcast31 into rows 2 and 3
-    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-__device__ __forceinline__ u64 ident_mask(int64_t ident_off, int64_t r, int64_t word) {
-    if (ident_off < 0) return 0ull;
-    const int64_t lo = ident_off - word * 64, hi = ident_off + r - word * 64;
-    if (hi <= 0 || lo >= 64) return 0ull;
-    u64 m = ~0ull;
-    if (lo > 0) m &= ~0ull << lo;
-    if (hi < 64) m &= ~(~0ull << hi);
-    return m;
 }
 
 // K = dwords of the column per lane (rows 2048*k + 32*lane ..).  ht: (n + 1) columns of 64*K dwords, column n is zero.
@@ -229,73 +208,6 @@ __global__ __launch_bounds__(64 * SPARSE_WAVES) void syndrome_sparse_kernel(
 // its own error words (e_x, e_z) with sample_word, then runs the sparse column accumulation once per component
 // (e_z against H1, e_x against H2, css_code.py:457-470).  The identity-block bits, which the stand-alone kernel
 // re-reads from memory, come from the neighbouring lanes' registers here.
-struct SparseSide {
-    const uint32_t* ht;        // transposed check, 64 dwords per column, column n is zero
-    int64_t r, ident_off;
-    u64* hist;
-    int nbins;
-};
-
-__device__ __forceinline__ unsigned int sparse_component_weight(u64 w, const SparseSide& side, int64_t n, int lane,
-                                                               unsigned int* mylist) {
-    // identity block: dword `lane` covers rows 32*lane.. <-> error bits ident_off + 32*lane ..
-    unsigned int acc = 0;
-    if (side.ident_off >= 0) {
-        const int64_t bit = side.ident_off + 32 * (int64_t)lane;
-        const int src = (int)(bit >> 6), sh = (int)(bit & 63);
-        const u64 lo = __shfl(w, src & 63), hi = __shfl(w, (src + 1) & 63);
-        u64 v = src < 64 ? lo >> sh : 0ull;
-        if (sh && src + 1 < 64) v |= hi << (64 - sh);
-        const int64_t row0 = 32 * (int64_t)lane;
-        unsigned int keep = row0 < side.r ? (side.r - row0 < 32 ? ~(~0u << (side.r - row0)) : ~0u) : 0u;
-        acc = (unsigned int)v & keep;
-        w &= ~ident_mask(side.ident_off, side.r, lane);
-    }
-    u64 x = w;
-    unsigned int total = 0;
-    for (;;) {
-        const u64 active = __ballot(x != 0);
-        if (!active) break;
-        if (x) {
-            const int b = __ffsll((long long)x) - 1;
-            x &= x - 1;
-            const unsigned int pos = total + __builtin_amdgcn_mbcnt_hi((unsigned int)(active >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((unsigned int)active, 0u));
-            if (pos < SPARSE_LIST_CAP) mylist[pos] = (unsigned int)((lane << 6) + b);
-        }
-        total += (unsigned int)__popcll(active);
-    }
-    const char* htb = reinterpret_cast<const char*>(side.ht);
-    const unsigned int lane4 = lane * 4u;
-    if (total && total <= SPARSE_LIST_CAP) {
-        if (lane < 8) mylist[total + lane] = (unsigned int)n;
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (unsigned int k0 = 0; k0 < total; k0 += 8) {
-            unsigned int v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const uint32_t*>(htb + ((mylist[k0 + i] << 8) | lane4));
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc ^= v[i];
-        }
-        __builtin_amdgcn_wave_barrier();
-    } else if (total) {                                             // dense sample: walk the words one by one
-        u64 nz = __ballot(w != 0);
-        while (nz) {
-            const int src = __ffsll((long long)nz) - 1;
-            nz &= nz - 1;
-            u64 word = ((u64)(unsigned int)__builtin_amdgcn_readlane((int)(w >> 32), src) << 32) |
-                       (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)w, src);
-            while (word) {
-                const int b = __ffsll((long long)word) - 1;
-                word &= word - 1;
-                acc ^= *reinterpret_cast<const uint32_t*>(htb + (((unsigned int)((src << 6) + b) << 8) | lane4));
-            }
-        }
-    }
-    return wave_total((unsigned int)__popc(acc));
-}
-
 __global__ __launch_bounds__(64 * SPARSE_WAVES) void mc_sparse_fused_kernel(SparseSide side_z, SparseSide side_x, int64_t n,
                                                                            u64 seed, int64_t first_sample, int64_t count,
                                                                            SamplerTables th) {
@@ -413,7 +325,12 @@ int gf2_syndrome_sparse_dev(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e
     if (!e_dev) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_sparse_dev: null errors");
     GF2_TRY(gf2_ctx_activate(ctx));
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_SYNDROME));
-    if (s_dev && hist_dev)
+    // histogram only: the LDS-slab pipeline (gf2_slabs.hip) once the batch amortises its three launches and the table
+    // loads; GF2_SPARSE_SLABS / GF2_SPARSE_GATHER force one or the other (same results)
+    if (!s_dev && gf2_slabs_ok(ck) && getenv("GF2_SPARSE_GATHER") == nullptr &&
+        (batch >= 32768 || getenv("GF2_SPARSE_SLABS") != nullptr))
+        GF2_TRY(gf2_syndrome_slabs(ctx, ck, e_dev, batch, lde, hist_dev));
+    else if (s_dev && hist_dev)
         launch_sparse<true, true>(ctx, ck, e_dev, batch, lde, (uint32_t*)s_dev, lds * 2, (u64*)hist_dev, (int)nbins);
     else if (s_dev)
         launch_sparse<true, false>(ctx, ck, e_dev, batch, lde, (uint32_t*)s_dev, lds * 2, nullptr, 0);

@@ -657,3 +657,63 @@ def test_normalize_with_a_column_swap_at_every_step(case, ctx):
     swaps = ctx.normalize(packed, r, n, off)
     assert swaps == want_swaps
     assert np.array_equal(packed, want)
+
+
+@pytest.mark.parametrize("case", [(2047, 4096, 2049, 1500, 0.007), (2048, 4096, 0, 5000, 0.01), (2048, 4096, 2048, 700, 0.012),
+                                  (1000, 3000, 37, 1100, 0.004), (300, 2500, None, 600, 0.005), (2048, 4000, 1952, 513, 0.007),
+                                  (130, 777, 500, 2049, 0.03), (2048, 4096, 0, 64, 0.0)])
+def test_syndrome_slab_pipeline(case, ctx, monkeypatch):
+    # histogram-only calls take the LDS row-slab pipeline (compact -> gather -> combine) when the check qualifies; it must
+    # agree with the oracle and with the column-gather kernel on sparse samples, on samples beyond the record capacity
+    # and on ragged batches
+    r, n, ioff, batch, density = case
+    rng = np.random.default_rng(r * 5 + n + batch)
+    hm = rng.integers(0, 2, (r, n))
+    if ioff is not None:
+        hm[:, ioff:ioff + r] = np.identity(r, dtype=int)
+    em = (rng.random((batch, n)) < density).astype(np.uint8)
+    heavy = rng.choice(batch, size=min(batch, 9), replace=False)
+    em[heavy] = (rng.random((len(heavy), n)) < 0.03).astype(np.uint8)     # beyond 32 listed columns
+    em[heavy[0]] = 1
+    h, e = _native.pack_rows(hm), _native.pack_rows(em)
+    chk = ctx.check_create(h, r, n)
+    lde = e.shape[1]
+    e_buf = ctx.alloc(e.nbytes).upload(e)
+    want = c_oracle.histogram(c_oracle.syndrome_batch(h, r, n, e, batch), batch, r, 1, r + 1)
+    monkeypatch.setenv("GF2_SPARSE_SLABS", "1")              # small batches default to the column-gather kernel
+    hist = ctx.alloc((r + 1) * 8).zero()
+    ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist, r + 1)
+    assert np.array_equal(hist.download((r + 1,), np.uint64), want)
+    monkeypatch.delenv("GF2_SPARSE_SLABS")
+    monkeypatch.setenv("GF2_SPARSE_GATHER", "1")
+    hist2 = ctx.alloc((r + 1) * 8).zero()
+    ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist2, r + 1)
+    assert np.array_equal(hist2.download((r + 1,), np.uint64), want)
+
+
+def test_syndrome_slab_pipeline_default_route_large_batch(ctx, monkeypatch):
+    # above the batch threshold the histogram-only call takes the slab pipeline by itself (64 sample shares per slab,
+    # XCD-grouped); same histogram as the column-gather kernel and as the dense table kernel's syndromes
+    r, n, ioff, batch = 2047, 4096, 2049, 70001
+    rng = np.random.default_rng(11)
+    hm = rng.integers(0, 2, (r, n), dtype=np.uint8)
+    hm[:, ioff:ioff + r] = np.identity(r, dtype=np.uint8)
+    h = _native.pack_rows(hm)
+    chk = ctx.check_create(h, r, n)
+    ex, ez = ctx.alloc(batch * 512), ctx.alloc(batch * 512)
+    ctx.sample_errors_dev(n, 3, 5, batch, 0.004, 0.003, 0.003, ex, ez, 64)
+    hists = []
+    for force_gather in (False, True):
+        if force_gather:
+            monkeypatch.setenv("GF2_SPARSE_GATHER", "1")
+        hist = ctx.alloc((r + 1) * 8).zero()
+        ctx.syndrome_sparse_dev(chk, ex, batch, 64, None, 0, hist, r + 1)
+        hists.append(hist.download((r + 1,), np.uint64))
+    assert np.array_equal(hists[0], hists[1]) and int(hists[0].sum()) == batch
+    e = ex.download((batch, 64), "<u8")
+    want = c_oracle.histogram(c_oracle.syndrome_batch(h, r, n, e[:3000].copy(), 3000), 3000, r, 1, r + 1)
+    first = ctx.alloc((r + 1) * 8).zero()
+    monkeypatch.delenv("GF2_SPARSE_GATHER")
+    monkeypatch.setenv("GF2_SPARSE_SLABS", "1")
+    ctx.syndrome_sparse_dev(chk, ex, 3000, 64, None, 0, first, r + 1)
+    assert np.array_equal(first.download((r + 1,), np.uint64), want)
