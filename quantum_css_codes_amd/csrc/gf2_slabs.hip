@@ -29,8 +29,8 @@
 
 #define CMP_WAVES 4
 #define CMP_THREADS (64 * CMP_WAVES)
-#define CMP_SUB 16                            // samples per compaction sub-pass
-#define CMP_ITEM_CAP 320                      // non-zero words per sub-pass (expected ~180 at p = 0.01)
+#define CMP_SUB 8                             // samples per compaction sub-pass
+#define CMP_ITEM_CAP 176                      // non-zero words per sub-pass (expected ~90 at p = 0.01)
 #define REC_SLOTS 32                          // 16-bit slots per record: count + 31 columns
 #define REC_OVER 0xFFu                        // count byte of a sample that was finished by the slow routine
 #define REC_FLAG 0xFFFFu                      // its partial weights
@@ -75,7 +75,7 @@ struct CompactArgs {
 struct CompactWaveLds {
     u64 item_v[CMP_ITEM_CAP];
     unsigned short item_m[CMP_ITEM_CAP];
-    unsigned char pad[4096 - CMP_ITEM_CAP * 10];
+    unsigned char pad[2304 - CMP_ITEM_CAP * 10];   // the slow routine's list (SPARSE_LIST_CAP + 8 dwords) reuses this region
     unsigned char planes[4096];
     unsigned int cnt[64];
 };
@@ -94,7 +94,9 @@ __device__ __forceinline__ void load_rows(const CompactArgs& a, int64_t s_first,
     }
 }
 
-__global__ __launch_bounds__(CMP_THREADS, 4) void slab_compact_kernel(CompactArgs a) {
+static_assert(2304 >= (SPARSE_LIST_CAP + 8) * 4, "item region too small for the slow routine's list");
+
+__global__ __launch_bounds__(CMP_THREADS, 5) void slab_compact_kernel(CompactArgs a) {
     __shared__ CompactWaveLds lds_all[CMP_WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(CMP_THREADS, 4) void slab_compact_kernel(CompactArg
             }
             wave_lds_sync();
             if (base > CMP_ITEM_CAP) {                              // uniform: these 16 samples take the slow routine
-                if ((lane >> 4) == sub) L.cnt[lane] = 1000;
+                if (lane / CMP_SUB == sub) L.cnt[lane] = 1000;
                 base = 0;
             }
             for (unsigned int i0 = 0; i0 < base; i0 += 64) {
@@ -407,24 +409,36 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
 
 // ---- combine ---------------------------------------------------------------------------------------------------------
 
+// Four consecutive samples per lane and step: one 8-byte load per slab (at most four slabs: r <= 2048), all issued before
+// any is used.
 __global__ __launch_bounds__(256) void slab_combine_kernel(const unsigned short* __restrict__ pw, int64_t batch, int64_t batch_pad,
                                                           int nslabs, u64* __restrict__ hist, int nbins) {
     __shared__ unsigned int bins[SLAB_MAX_BINS];
     for (int i = threadIdx.x; i < nbins; i += blockDim.x) bins[i] = 0;
     __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 2;
-    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 2; s < batch; s += stride) {
-        unsigned int w0 = 0, w1 = 0;
-        bool skip0 = false, skip1 = s + 1 >= batch;
-        for (int k = 0; k < nslabs; ++k) {
-            const unsigned int two = *reinterpret_cast<const unsigned int*>(pw + (int64_t)k * batch_pad + s);
-            skip0 |= (two & 0xFFFFu) == REC_FLAG;
-            skip1 |= (two >> 16) == REC_FLAG;
-            w0 += two & 0xFFFFu;
-            w1 += two >> 16;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; s < batch; s += stride) {
+        u64 four[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) four[k] = *reinterpret_cast<const u64*>(pw + (int64_t)(k < nslabs ? k : 0) * batch_pad + s);
+        unsigned int w[4] = {0, 0, 0, 0};
+        bool skip[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) skip[t] = s + t >= batch;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < nslabs) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const unsigned int v = (unsigned int)(four[k] >> (16 * t)) & 0xFFFFu;
+                    skip[t] |= v == REC_FLAG;
+                    w[t] += v;
+                }
+            }
         }
-        if (!skip0) atomicAdd(&bins[w0], 1u);
-        if (!skip1) atomicAdd(&bins[w1], 1u);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (!skip[t]) atomicAdd(&bins[w[t]], 1u);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nbins; i += blockDim.x)
@@ -506,7 +520,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
         ca.ident_off = (int)ck->ident_off;
         ca.null_ord = ck->slab_null;
         int64_t cblocks = gf2_cdiv(gf2_cdiv(count, 64), CMP_WAVES);
-        if (cblocks > (int64_t)ctx->num_cus * 4) cblocks = (int64_t)ctx->num_cus * 4;
+        if (cblocks > (int64_t)ctx->num_cus * 5) cblocks = (int64_t)ctx->num_cus * 5;
         hipLaunchKernelGGL(slab_compact_kernel, dim3((unsigned)cblocks), dim3(CMP_THREADS), 0, ctx->stream, ca);
         GF2_HIP(hipGetLastError());
 
@@ -531,8 +545,8 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
                            ctx->stream, ga);
         GF2_HIP(hipGetLastError());
 
-        int64_t mblocks = gf2_cdiv(count, 512);
-        if (mblocks > (int64_t)ctx->num_cus * 2) mblocks = (int64_t)ctx->num_cus * 2;
+        int64_t mblocks = gf2_cdiv(count, 1024);
+        if (mblocks > (int64_t)ctx->num_cus) mblocks = ctx->num_cus;
         hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3(256), 0, ctx->stream, pw, count, pad,
                            ck->nslabs512, (u64*)hist_dev, nbins);
         GF2_HIP(hipGetLastError());
