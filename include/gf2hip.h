@@ -135,6 +135,15 @@ int gf2_matmul_abt(gf2_ctx* ctx, const uint64_t* a, int64_t ra, int64_t lda,
                    const uint64_t* b, int64_t rb, int64_t ldb, int64_t n,
                    uint64_t* c, int64_t ldc);
 
+/* css_code.syndrome_table (css_code.py:715-735) for n <= 64, r <= 24 [SURVEY.md 8f item 2].  h_rows: r words, qubit j =
+ * bit j.  table_out: 2^r words indexed by bin_matrix.vec_to_int(syndrome) (row 0 = most significant bit,
+ * bin_matrix.py:36-43); an entry is the packed error of weight <= t with that syndrome, or all ones.  *t_out is the
+ * decoding threshold the reference returns: the classes 0..t have pairwise distinct syndromes and class t + 1 does not
+ * (or t = n, or t = max_weight when max_weight >= 0 [build-defined cap] is reached first).  *entries_out (may be null)
+ * = number of filled entries. */
+int gf2_syndrome_table(gf2_ctx* ctx, const uint64_t* h_rows, int64_t r, int64_t n, int64_t max_weight,
+                       uint64_t* table_out, int64_t* t_out, int64_t* entries_out);
+
 /* Row Hamming weights: np.sum(mat, axis=1) of css_code.is_doubly_even (css_code.py:846-850). */
 int gf2_row_weights(gf2_ctx* ctx, const uint64_t* a, int64_t m, int64_t n, int64_t ld, uint32_t* weights_out);
 

@@ -65,6 +65,7 @@ SIGNATURES = {
     "gf2_swap_columns": [_p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64],
     "gf2_matmul_abt": [_p, _p, _c_i64, _c_i64, _p, _c_i64, _c_i64, _c_i64, _p, _c_i64],
     "gf2_row_weights": [_p, _p, _c_i64, _c_i64, _c_i64, _p],
+    "gf2_syndrome_table": [_p, _p, _c_i64, _c_i64, _c_i64, _p, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)],
     "gf2_check_create": [_p, _p, _c_i64, _c_i64, _c_i64, _pp],
     "gf2_check_destroy": [_p, _p],
     "gf2_syndrome_batch": [_p, _p, _c_i64, _c_i64, _c_i64, _p, _c_i64, _c_i64, ctypes.c_int, _p, _c_i64],
@@ -344,6 +345,20 @@ class Context(object):
         ld = packed.shape[1] if m else max(1, words_for(n))
         check(lib().gf2_row_weights(self.handle, _ptr(packed), m, n, ld, _ptr(out)))
         return out[:m]
+
+    TABLE_MAX_N, TABLE_MAX_R = 64, 24
+    TABLE_EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+    def syndrome_table(self, packed, r, n, max_weight=None):
+        """css_code.syndrome_table on the device (n <= 64, r <= 24): returns (t, dense) where dense[key] is the packed
+        error with syndrome key = vec_to_int(syndrome), or TABLE_EMPTY."""
+        rows = np.ascontiguousarray(packed[:, 0] if r else np.zeros(0, dtype="<u8"), dtype="<u8")
+        dense = np.empty(1 << r, dtype="<u8")
+        t, entries = _c_i64(), _c_i64()
+        check(lib().gf2_syndrome_table(self.handle, _ptr(rows) if r else None, r, n,
+                                       -1 if max_weight is None else max_weight, _ptr(dense), ctypes.byref(t),
+                                       ctypes.byref(entries)))
+        return int(t.value), dense
 
     # -- syndromes ----------------------------------------------------------------------------------------
     def check_create(self, packed, r, n):

@@ -1,0 +1,163 @@
+// css_code.syndrome_table (css_code.py:715-735) on the device for codes of at most 64 bits and 24 checks (gfx950).
+//
+// The reference walks the weight classes w = 0, 1, 2, ..., maps every error of weight w to vec_to_int(H e mod 2)
+// (bin_matrix.py:36-43: row 0 is the most significant bit) and stops at the first class that contains a syndrome
+// already seen, in an earlier class or earlier in the same one; that class is dropped as a whole and the classes before
+// it are the table.  Inside the accepted classes every syndrome occurs once, so the result does not depend on the
+// order in which a class is enumerated, and the device may enumerate it in any order:
+//
+//   table[key] (2^r words, all ones = empty) holds the packed error (qubit j = bit j) that produced syndrome `key`.
+//   One launch per weight class.  A lane takes a run of consecutive errors in colexicographic order: it unranks its
+//   first error with a binomial table in LDS (combinatorial number system) and steps to the next one with Gosper's
+//   bit trick; the parity-check rows sit in SGPRs (kernel argument); the syndrome key is r AND + popcount parities; the
+//   table slot is claimed with a 64-bit atomicCAS.  A failed claim raises the collision flag and the class is swept out
+//   of the table again (its entries are the ones of popcount w).
+#include "gf2_internal.h"
+
+#define TBL_MAX_R 24
+#define TBL_RUN 64                             // consecutive errors per lane
+#define TBL_EMPTY (~0ull)
+
+struct TableRows {
+    u64 row[TBL_MAX_R];
+};
+
+// binom[c * 65 + k] = C(c, k) for c, k <= 64 (saturated at 2^63)
+__global__ __launch_bounds__(256) void table_class_kernel(TableRows h, int r, int n, int w, u64 total,
+                                                          const u64* __restrict__ binom, u64* __restrict__ table,
+                                                          int* __restrict__ collide) {
+    __shared__ u64 cw[65];                                          // C(c, k) for the k this lane is unranking
+    const u64 lane_first = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * TBL_RUN;
+    // unrank lane_first in the combinatorial number system: for k = w .. 1 take the largest c with C(c, k) <= rank
+    u64 e = 0, rank = lane_first;
+    for (int k = w; k >= 1; --k) {
+        __syncthreads();
+        if (threadIdx.x < 65) cw[threadIdx.x] = binom[threadIdx.x * 65 + k];
+        __syncthreads();
+        if (lane_first < total) {
+            int c = k - 1;                                          // C(k - 1, k) = 0 <= rank always
+            while (c + 1 < n && cw[c + 1] <= rank) ++c;
+            e |= 1ull << c;
+            rank -= cw[c];
+        }
+    }
+    if (lane_first >= total) return;
+    const u64 limit = n < 64 ? (1ull << n) : 0ull;                  // 0: no limit below 2^64
+    u64 left = total - lane_first < TBL_RUN ? total - lane_first : TBL_RUN;
+    for (; left; --left) {
+        if (*reinterpret_cast<volatile int*>(collide)) return;
+        u64 key = 0;
+#pragma unroll
+        for (int i = 0; i < TBL_MAX_R; ++i)
+            if (i < r) key = (key << 1) | (u64)(__popcll(h.row[i] & e) & 1);
+        if (atomicCAS(&table[key], TBL_EMPTY, e) != TBL_EMPTY) {
+            atomicExch(collide, 1);
+            return;
+        }
+        if (left > 1) {                                             // Gosper: next word with the same popcount
+            const u64 lowest = e & (0ull - e);
+            const u64 ripple = e + lowest;
+            e = (((ripple ^ e) >> 2) >> (__ffsll((long long)lowest) - 1)) | ripple;
+            if (limit && e >= limit) return;                        // cannot happen within `total`; guards the table
+        }
+    }
+}
+
+__global__ void table_sweep_kernel(u64* __restrict__ table, u64 entries, int w) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < entries && table[i] != TBL_EMPTY && __popcll(table[i]) == w) table[i] = TBL_EMPTY;
+}
+
+__global__ void table_fill_kernel(u64* __restrict__ table, u64 entries) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < entries) table[i] = TBL_EMPTY;
+}
+
+extern "C" int gf2_syndrome_table(gf2_ctx* ctx, const uint64_t* h_rows, int64_t r, int64_t n, int64_t max_weight,
+                                  uint64_t* table_out, int64_t* t_out, int64_t* entries_out) {
+    if (!ctx || !table_out || !t_out) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_table: null argument");
+    if (r < 0 || r > TBL_MAX_R || n < 0 || n > 64) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_table: needs n <= 64 and r <= %d", TBL_MAX_R);
+    if (r > 0 && !h_rows) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_table: null rows");
+    GF2_TRY(gf2_ctx_activate(ctx));
+    TableRows rows;
+    for (int i = 0; i < TBL_MAX_R; ++i) rows.row[i] = i < r ? h_rows[i] : 0ull;
+    // Pascal's triangle, saturated
+    static u64 binom_host[65 * 65];
+    for (int c = 0; c <= 64; ++c)
+        for (int k = 0; k <= 64; ++k) {
+            u64 v;
+            if (k == 0)
+                v = 1;
+            else if (c == 0)
+                v = 0;
+            else {
+                const u64 a = binom_host[(c - 1) * 65 + k - 1], b = binom_host[(c - 1) * 65 + k];
+                v = (a > (1ull << 63) || b > (1ull << 63) || a + b > (1ull << 63)) ? (1ull << 63) + 1 : a + b;
+            }
+            binom_host[c * 65 + k] = v;
+        }
+    const u64 entries = 1ull << r;
+    u64 *table_dev = nullptr, *binom_dev = nullptr;
+    int* collide_dev = nullptr;
+    GF2_TRY(gf2_dev_alloc(ctx, entries * 8, (void**)&table_dev));
+    int rc = gf2_dev_alloc(ctx, sizeof(binom_host), (void**)&binom_dev);
+    if (rc == GF2_OK) rc = gf2_dev_alloc(ctx, 4, (void**)&collide_dev);
+    int64_t t = n, kept = 0;
+    if (rc == GF2_OK) {
+        hipLaunchKernelGGL(table_fill_kernel, dim3((unsigned)gf2_cdiv((int64_t)entries, 256)), dim3(256), 0, ctx->stream,
+                           table_dev, entries);
+        if (hipMemcpyAsync(binom_dev, binom_host, sizeof(binom_host), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemsetAsync(collide_dev, 0, 4, ctx->stream) != hipSuccess)
+            rc = GF2_E_HIP;
+    }
+    for (int64_t w = 0; rc == GF2_OK && w <= n; ++w) {
+        if (max_weight >= 0 && w > max_weight) {
+            t = max_weight;
+            break;
+        }
+        const u64 total = binom_host[n * 65 + w];
+        if (total > (1ull << 40)) {
+            gf2_set_error("gf2_syndrome_table: weight class %lld of n = %lld has more than 2^40 errors; pass max_weight",
+                          (long long)w, (long long)n);
+            rc = GF2_E_ARG;
+            break;
+        }
+        bool collided = total > entries - (u64)kept;                // pigeonhole: more errors than free syndromes
+        if (!collided) {
+            const u64 lanes = (total + TBL_RUN - 1) / TBL_RUN;
+            hipLaunchKernelGGL(table_class_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ctx->stream, rows,
+                               (int)r, (int)n, (int)w, total, binom_dev, table_dev, collide_dev);
+            int flag = 0;
+            if (hipGetLastError() != hipSuccess ||
+                hipMemcpyAsync(&flag, collide_dev, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                gf2_set_error("gf2_syndrome_table: weight class %lld failed on the device", (long long)w);
+                rc = GF2_E_HIP;
+                break;
+            }
+            collided = flag != 0;
+            if (collided)
+                hipLaunchKernelGGL(table_sweep_kernel, dim3((unsigned)gf2_cdiv((int64_t)entries, 256)), dim3(256), 0,
+                                   ctx->stream, table_dev, entries, (int)w);
+        }
+        if (collided) {
+            t = w - 1;
+            break;
+        }
+        kept += (int64_t)total;
+    }
+    if (rc == GF2_OK) {
+        if (hipMemcpyAsync(table_out, table_dev, entries * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            gf2_set_error("gf2_syndrome_table: copying the table back failed");
+            rc = GF2_E_HIP;
+        }
+    }
+    (void)gf2_dev_free(ctx, table_dev);
+    (void)gf2_dev_free(ctx, binom_dev);
+    (void)gf2_dev_free(ctx, collide_dev);
+    if (rc != GF2_OK) return rc;
+    *t_out = t;
+    if (entries_out) *entries_out = kept;
+    return GF2_OK;
+}

@@ -223,8 +223,8 @@ def syndrome_table(parity_check, max_weight=None):
     return it along with a lookup table from syndromes (as bin_matrix.vec_to_int keys) to error vectors
     of weight at most t (css_code.py:715-735).
 
-    Each weight class is enumerated in bin_matrix.weight_w_vectors order, in chunks, and its syndromes are
-    computed on the GPU; a class containing a syndrome already seen (in an earlier class or earlier in the
+    Codes of at most 64 bits and 24 checks are searched entirely on the device (gf2_table.hip).  Otherwise each
+    weight class is enumerated in bin_matrix.weight_w_vectors order, in chunks, and its syndromes are computed on the GPU; a class containing a syndrome already seen (in an earlier class or earlier in the
     same class) ends the search and is discarded as a whole, exactly as the reference's loop does.  Keys are
     formed and compared as machine words when r <= 63 (the reference's own keys are only meaningful there,
     SURVEY.md 7.3 item 2) and as Python ints beyond.  max_weight [build-defined] caps the search for large
@@ -234,6 +234,18 @@ def syndrome_table(parity_check, max_weight=None):
     r, n = parity_check.shape
     ctx = _native.default_context()
     packed_h = _native.pack_rows(parity_check)
+    if 0 < n <= ctx.TABLE_MAX_N and r <= ctx.TABLE_MAX_R:
+        # whole search on the device (gf2_syndrome_table): one kernel per weight class, first collision ends it
+        t, dense = ctx.syndrome_table(packed_h, r, n, max_weight)
+        keys = np.nonzero(dense != ctx.TABLE_EMPTY)[0]
+        words = dense[keys]
+        # the reference's insertion order: by weight, then bin_matrix.weight_w_vectors order (supports ascending
+        # lexicographically = the word read with qubit 0 as its most significant bit, descending)
+        rev = np.unpackbits(words.view(np.uint8).reshape(-1, 8), axis=1, bitorder="little")
+        rev = np.packbits(rev, axis=1, bitorder="big").view(">u8").reshape(-1).astype(np.uint64)
+        order = np.lexsort((~rev, np.bitwise_count(words)))
+        errs = _native.unpack_rows(words[order].reshape(-1, 1), n, dtype=np.uint8).astype('int')
+        return t, dict(zip(keys[order].tolist(), errs))
     chk = ctx.check_create(packed_h, r, n) if r else None
     table = {}
     seen = np.zeros(0, dtype=np.uint64)                       # keys of `table`, sorted (r <= 63)

@@ -717,3 +717,45 @@ def test_syndrome_slab_pipeline_default_route_large_batch(ctx, monkeypatch):
     monkeypatch.setenv("GF2_SPARSE_SLABS", "1")
     ctx.syndrome_sparse_dev(chk, ex, 3000, 64, None, 0, first, r + 1)
     assert np.array_equal(first.download((r + 1,), np.uint64), want)
+
+
+@pytest.mark.parametrize("case", ["steane", "rm15_c2", "identity", "r0", "repetition", "random_31_16", "random_64_24",
+                                  "duplicate_columns", "zero_column"])
+def test_syndrome_table_device_search(case, ctx, steane_h, rm15):
+    # gf2_syndrome_table (n <= 64, r <= 24) against the oracle's restatement of css_code.py:715-735: same threshold,
+    # same keys in the same insertion order, same error vectors
+    rng = np.random.default_rng(5)
+    cap = None
+    if case == "steane":
+        h = steane_h
+    elif case == "rm15_c2":
+        h = rm15[1]
+    elif case == "identity":
+        h = np.identity(9, dtype=int)                        # every error has its own syndrome: t = n
+    elif case == "r0":
+        h = np.zeros((0, 5), dtype=int)
+    elif case == "repetition":
+        h = np.array([[1, 1, 0, 0, 0, 0, 0], [0, 1, 1, 0, 0, 0, 0], [0, 0, 1, 1, 0, 0, 0], [0, 0, 0, 1, 1, 0, 0],
+                      [0, 0, 0, 0, 1, 1, 0], [0, 0, 0, 0, 0, 1, 1]])   # [7,1,7]: t = 3
+    elif case == "random_31_16":
+        h = rng.integers(0, 2, (15, 31))
+    elif case == "random_64_24":
+        h = rng.integers(0, 2, (24, 64))
+        cap = 2
+    elif case == "duplicate_columns":
+        h = rng.integers(0, 2, (6, 10))
+        h[:, 7] = h[:, 2]                                    # two weight-1 errors collide: t = 0
+    else:
+        h = rng.integers(0, 2, (6, 10))
+        h[:, 4] = 0                                          # a weight-1 error with the zero syndrome: t = 0
+    t, table = css_code.syndrome_table(h, max_weight=cap)
+    want_t, want = cpu_ref.syndrome_table(np.array(h, dtype=object) if h.shape[0] > 62 else h, max_weight=cap)
+    assert t == want_t
+    assert list(table.keys()) == [int(k) for k in want.keys()]
+    for k in table:
+        assert np.array_equal(table[k], np.asarray(want[k], dtype=int))
+    # the dense form through the C ABI: filled entries = sum of the accepted classes
+    from math import comb
+    r, n = h.shape
+    t2, dense = ctx.syndrome_table(_native.pack_rows(h), r, n, cap)
+    assert t2 == t and int((dense != ctx.TABLE_EMPTY).sum()) == sum(comb(n, w) for w in range(t + 1))
