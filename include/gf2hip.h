@@ -37,6 +37,7 @@ extern "C" {
 #define GF2_E_DEPENDENT  (-3)  /* InvalidCodeError("rows are not independent"), css_code.py:825  */
 #define GF2_E_HIP        (-4)  /* HIP runtime error / no device                                  */
 #define GF2_E_NOMEM      (-5)  /* allocation failure                                             */
+#define GF2_E_NOTCSS     (-6)  /* NotImplementedError("only handles CSS codes"), css_code.py:762-763 */
 
 #define GF2_LAYOUT_SAMPLE_MAJOR 0  /* E: B rows of lde words (one error per row); S: B rows of lds words */
 #define GF2_LAYOUT_BIT_SLICED   1  /* E: n rows of ceil(B/64) words (word b of row q = qubit q of samples
@@ -143,6 +144,16 @@ int gf2_matmul_abt(gf2_ctx* ctx, const uint64_t* a, int64_t ra, int64_t lda,
  * = number of filled entries. */
 int gf2_syndrome_table(gf2_ctx* ctx, const uint64_t* h_rows, int64_t r, int64_t n, int64_t max_weight,
                        uint64_t* table_out, int64_t* t_out, int64_t* entries_out);
+
+/* css_code.transform_stabilisers (css_code.py:737-781) [SURVEY.md 8f item 3].  mat: k rows of ld words holding the k x 2n
+ * stabiliser matrix [X | Z] (column j = bit j), rewritten in place.  gates: ngates rows of three int32 (kind, a, b):
+ * kind 0 = H on qubit a (conjugate_h_with_check_mat, :757-767), kind 1 = CNOT control a target b
+ * (conjugate_cnot_with_check_mat, :769-781).  Gates apply in order.  *stop_out = -1 and GF2_OK when all applied.
+ * Otherwise mat holds the result of gates[0 : *stop_out] and the call returns GF2_E_NOTCSS (that gate is an H on a
+ * qubit where some row has X and Z) or GF2_E_ARG (unknown kind / qubit outside [0, n): the reference's ValueErrors,
+ * :747-755).  2n <= 20480. */
+int gf2_conjugate_gates(gf2_ctx* ctx, uint64_t* mat, int64_t k, int64_t n, int64_t ld, const int32_t* gates,
+                        int64_t ngates, int64_t* stop_out);
 
 /* Row Hamming weights: np.sum(mat, axis=1) of css_code.is_doubly_even (css_code.py:846-850). */
 int gf2_row_weights(gf2_ctx* ctx, const uint64_t* a, int64_t m, int64_t n, int64_t ld, uint32_t* weights_out);

@@ -462,3 +462,81 @@ def decode_and_tally(code, seed, first_sample, num_samples, p_x, p_y, p_z):
         counts[1] += flips[1]
         counts[2] += 1 if (flips[0] or flips[1]) else 0
     return counts
+
+
+# --------------------------------------------------------------------------------------------
+# css_code.py -- encoder gate lists and stabiliser conjugation (pyquil-free forms)
+# --------------------------------------------------------------------------------------------
+# Gates are rows (kind, a, b) of an int array: kind 0 = H on qubit a, kind 1 = CNOT control a target b.
+# Pinned by tests/golden/conjugation_golden.npz (the reference's own conjugate_* functions run on seeded inputs) and
+# by the reference's known answers for the Steane encoders (test/test_css_code.py:61-106).
+
+GATE_H, GATE_CNOT = 0, 1
+
+
+def conjugate_h_with_check_mat(mat, qubit):
+    """css_code.py:757-767: H swaps the X and Z entry of the qubit in every row; a row with both set is refused."""
+    k, cols = mat.shape
+    n = cols // 2
+    for i in range(k):
+        if mat[i, qubit] == 1 and mat[i, n + qubit] == 1:
+            raise NotImplementedError("only handles CSS codes")
+        mat[i, qubit], mat[i, n + qubit] = mat[i, n + qubit], mat[i, qubit]
+
+
+def conjugate_cnot_with_check_mat(mat, control, target):
+    """css_code.py:769-781: X spreads from control to target, Z from target to control."""
+    k, cols = mat.shape
+    n = cols // 2
+    for i in range(k):
+        if mat[i, control] == 1:
+            mat[i, target] = (mat[i, target] + 1) % 2
+        if mat[i, n + target] == 1:
+            mat[i, n + control] = (mat[i, n + control] + 1) % 2
+
+
+def transform_stabilisers(mat, gates):
+    """css_code.py:737-755 on a gate array: in place, in order; ValueError for a qubit outside [0, n) or an unknown gate."""
+    _, cols = mat.shape
+    n = cols // 2
+    for kind, a, b in np.asarray(gates).reshape(-1, 3):
+        qubits = (a,) if kind == GATE_H else (a, b)
+        if any(q < 0 or q >= n for q in qubits):
+            raise ValueError("qubit index must be within [0, n)")
+        if kind == GATE_H:
+            conjugate_h_with_check_mat(mat, int(a))
+        elif kind == GATE_CNOT:
+            conjugate_cnot_with_check_mat(mat, int(a), int(b))
+        else:
+            raise ValueError("cannot conjugate gate {}".format(kind))
+
+
+def encode_zero_gates(code, qubits=None):
+    """Gate sequence of CSSCode.noisy_encode_zero (css_code.py:203-259): H on the first r_1 qubits, then
+    CNOT(i, j) for every 1 of parity_check_c1[i, j], j >= r_1, rows in order, columns in order."""
+    n, r_1 = code.n, code.r_1
+    qubits = list(range(n)) if qubits is None else list(qubits)
+    gates = [(GATE_H, qubits[i], 0) for i in range(r_1)]
+    for i in range(r_1):
+        for j in range(r_1, n):
+            if code.parity_check_c1[i, j] == 1:
+                gates.append((GATE_CNOT, qubits[i], qubits[j]))
+    return np.array(gates, dtype=np.int32).reshape(-1, 3)
+
+
+def encode_plus_gates(code, qubits=None):
+    """Gate sequence of CSSCode.noisy_encode_plus (css_code.py:261-312): H on the first r_1 and the last n - r_1 - r_2
+    qubits, CNOT(j, i) for every 1 of parity_check_c2[i - r_1, j] with j >= r_1 + r_2, then the CNOTs of encode_zero."""
+    n, r_1, r_2 = code.n, code.r_1, code.r_2
+    qubits = list(range(n)) if qubits is None else list(qubits)
+    gates = [(GATE_H, qubits[i], 0) for i in range(r_1)]
+    gates += [(GATE_H, qubits[i], 0) for i in range(r_1 + r_2, n)]
+    for i in range(r_1, r_1 + r_2):
+        for j in range(r_1 + r_2, n):
+            if code.parity_check_c2[i - r_1, j] == 1:
+                gates.append((GATE_CNOT, qubits[j], qubits[i]))
+    for i in range(r_1):
+        for j in range(r_1, n):
+            if code.parity_check_c1[i, j] == 1:
+                gates.append((GATE_CNOT, qubits[i], qubits[j]))
+    return np.array(gates, dtype=np.int32).reshape(-1, 3)

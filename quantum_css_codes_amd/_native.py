@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgf2hip.so")
 
-GF2_OK, GF2_E_ARG, GF2_E_COLUMNS, GF2_E_DEPENDENT, GF2_E_HIP, GF2_E_NOMEM = 0, -1, -2, -3, -4, -5
+GF2_OK, GF2_E_ARG, GF2_E_COLUMNS, GF2_E_DEPENDENT, GF2_E_HIP, GF2_E_NOMEM, GF2_E_NOTCSS = 0, -1, -2, -3, -4, -5, -6
 LAYOUT_SAMPLE_MAJOR, LAYOUT_BIT_SLICED, LAYOUT_TILED = 0, 1, 2
 HIST_FULL, HIST_WEIGHT = 0, 1
 K_SYNDROME, K_HIST, K_SAMPLER, K_ELIM = 0, 1, 2, 3
@@ -65,6 +65,7 @@ SIGNATURES = {
     "gf2_swap_columns": [_p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64],
     "gf2_matmul_abt": [_p, _p, _c_i64, _c_i64, _p, _c_i64, _c_i64, _c_i64, _p, _c_i64],
     "gf2_row_weights": [_p, _p, _c_i64, _c_i64, _c_i64, _p],
+    "gf2_conjugate_gates": [_p, _p, _c_i64, _c_i64, _c_i64, _p, _c_i64, ctypes.POINTER(_c_i64)],
     "gf2_syndrome_table": [_p, _p, _c_i64, _c_i64, _c_i64, _p, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)],
     "gf2_check_create": [_p, _p, _c_i64, _c_i64, _c_i64, _pp],
     "gf2_check_destroy": [_p, _p],
@@ -345,6 +346,19 @@ class Context(object):
         ld = packed.shape[1] if m else max(1, words_for(n))
         check(lib().gf2_row_weights(self.handle, _ptr(packed), m, n, ld, _ptr(out)))
         return out[:m]
+
+    def conjugate_gates(self, packed, k, n, gates):
+        """css_code.transform_stabilisers on a packed k x 2n matrix, in place.  gates: (g, 3) int32 rows (kind, a, b).
+        Returns (code, stop): (GF2_OK, -1), or (GF2_E_NOTCSS | GF2_E_ARG, index of the gate that stopped the walk) with
+        `packed` holding the result of the gates before it."""
+        gates = np.ascontiguousarray(gates, dtype=np.int32).reshape(-1, 3)
+        stop = _c_i64(-1)
+        ld = packed.shape[1] if k else max(1, words_for(2 * n))
+        rc = lib().gf2_conjugate_gates(self.handle, _ptr(packed) if k else None, k, n, ld,
+                                       _ptr(gates) if len(gates) else None, len(gates), ctypes.byref(stop))
+        if rc not in (GF2_OK, GF2_E_NOTCSS, GF2_E_ARG) or (rc == GF2_E_ARG and stop.value < 0):
+            check(rc)
+        return rc, int(stop.value)
 
     TABLE_MAX_N, TABLE_MAX_R = 64, 24
     TABLE_EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)

@@ -1,0 +1,139 @@
+// css_code.transform_stabilisers (css_code.py:737-781) on packed stabiliser matrices (gfx950).
+//
+// The reference walks a gate list and rewrites a k x 2n matrix [X | Z] column by column: H on qubit q swaps the X and Z
+// entry of q in every row (and refuses a row that has both: css_code.py:762-763), CNOT(c, t) adds X_c into X_t and Z_t
+// into Z_c in every row (css_code.py:775-781).  Gates depend on each other, rows do not.  So: lane = row, a wavefront
+// owns 64 rows for the whole gate list and keeps them in LDS as [word][row] (consecutive lanes on consecutive banks,
+// every access conflict-free, 64 KiB at n = 4096); the gate stream is wave-uniform (scalar loads), each gate is two to
+// four LDS word accesses and a few bit operations.  One block per 64 rows; nothing else is shared.
+//
+// A gate the reference would refuse ends the walk: the lowest such gate index over all blocks is reported, and the
+// host reruns the accepted prefix so that the matrix it hands back is the state the reference leaves behind before
+// the refused gate.
+#include "gf2_internal.h"
+
+#define CNJ_MAX_WORDS 320                      // words of 2n bits: 320 * 64 lanes * 8 bytes = 160 KiB of LDS
+
+// gates: ngates rows (kind, a, b), kind 0 = H on a, 1 = CNOT control a target b; all indices already validated.
+__global__ __launch_bounds__(64) void conjugate_kernel(u64* __restrict__ mat, int64_t k, int n, int64_t ld, int words,
+                                                       const int* __restrict__ gates, int64_t ngates,
+                                                       unsigned long long* __restrict__ first_refused) {
+    extern __shared__ u64 rows_lds[];                               // [word][lane]
+    const int lane = threadIdx.x;
+    const int64_t row = (int64_t)blockIdx.x * 64 + lane;
+    for (int w = 0; w < words; ++w) rows_lds[w * 64 + lane] = row < k ? mat[row * ld + w] : 0ull;
+    for (int64_t g = 0; g < ngates; ++g) {
+        const int kind = gates[3 * g], a = gates[3 * g + 1], b = gates[3 * g + 2];
+        if (kind == 0) {
+            const int zq = n + a;
+            const int wx = a >> 6, bx = a & 63, wz = zq >> 6, bz = zq & 63;
+            const u64 x = rows_lds[wx * 64 + lane], z = rows_lds[wz * 64 + lane];
+            const u64 xb = (x >> bx) & 1ull, zb = (z >> bz) & 1ull;
+            if (__ballot(xb & zb)) {                                // some row carries a Y on this qubit
+                if (lane == 0) atomicMin(first_refused, (unsigned long long)g);
+                break;
+            }
+            const u64 d = xb ^ zb;
+            if (wx != wz) {
+                rows_lds[wx * 64 + lane] = x ^ (d << bx);
+                rows_lds[wz * 64 + lane] = z ^ (d << bz);
+            } else {
+                rows_lds[wx * 64 + lane] = x ^ (d << bx) ^ (d << bz);
+            }
+        } else {
+            const int zc = n + a, zt = n + b;
+            const u64 xc = (rows_lds[(a >> 6) * 64 + lane] >> (a & 63)) & 1ull;      // X: control -> target
+            rows_lds[(b >> 6) * 64 + lane] ^= xc << (b & 63);
+            const u64 ztb = (rows_lds[(zt >> 6) * 64 + lane] >> (zt & 63)) & 1ull;   // Z: target -> control
+            rows_lds[(zc >> 6) * 64 + lane] ^= ztb << (zc & 63);
+        }
+    }
+    if (row < k)
+        for (int w = 0; w < words; ++w) mat[row * ld + w] = rows_lds[w * 64 + lane];
+}
+
+extern "C" int gf2_conjugate_gates(gf2_ctx* ctx, uint64_t* mat, int64_t k, int64_t n, int64_t ld, const int32_t* gates,
+                                   int64_t ngates, int64_t* stop_out) {
+    if (!ctx || !stop_out) GF2_FAIL(GF2_E_ARG, "gf2_conjugate_gates: null argument");
+    *stop_out = -1;
+    if (k < 0 || n < 0 || ngates < 0) GF2_FAIL(GF2_E_ARG, "gf2_conjugate_gates: negative size");
+    const int64_t words = gf2_words(2 * n);
+    if (ld < words) GF2_FAIL(GF2_E_ARG, "gf2_conjugate_gates: ld too small for 2n = %lld columns", (long long)(2 * n));
+    if (words > CNJ_MAX_WORDS) GF2_FAIL(GF2_E_ARG, "gf2_conjugate_gates: 2n = %lld columns exceed %d", (long long)(2 * n), CNJ_MAX_WORDS * 64);
+    if ((k > 0 && !mat) || (ngates > 0 && !gates)) GF2_FAIL(GF2_E_ARG, "gf2_conjugate_gates: null data");
+    // the reference checks a gate when it reaches it (css_code.py:747-755): everything before the first bad one applies
+    int64_t limit = ngates;
+    for (int64_t g = 0; g < ngates; ++g) {
+        const int32_t kind = gates[3 * g], a = gates[3 * g + 1], b = gates[3 * g + 2];
+        const bool bad = (kind != 0 && kind != 1) || a < 0 || a >= n || (kind == 1 && (b < 0 || b >= n));
+        if (bad) {
+            limit = g;
+            break;
+        }
+    }
+    int rc = GF2_OK;
+    int64_t refused = -1;
+    if (k > 0 && words > 0 && limit > 0) {
+        GF2_TRY(gf2_ctx_activate(ctx));
+        if (!ctx->lds_optin[3]) {
+            GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conjugate_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, CNJ_MAX_WORDS * 512));
+            ctx->lds_optin[3] = true;
+        }
+        const size_t mat_bytes = (size_t)k * ld * 8, gate_bytes = (size_t)limit * 12;
+        u64 *work = nullptr, *orig = nullptr;
+        int* gates_dev = nullptr;
+        unsigned long long* flag_dev = nullptr;
+        rc = gf2_dev_alloc(ctx, mat_bytes, (void**)&work);
+        if (rc == GF2_OK) rc = gf2_dev_alloc(ctx, mat_bytes, (void**)&orig);
+        if (rc == GF2_OK) rc = gf2_dev_alloc(ctx, gate_bytes, (void**)&gates_dev);
+        if (rc == GF2_OK) rc = gf2_dev_alloc(ctx, 8, (void**)&flag_dev);
+        if (rc == GF2_OK) {
+            const unsigned long long none = ~0ull;
+            unsigned long long flag = none;
+            const dim3 grid((unsigned)gf2_cdiv(k, 64)), block(64);
+            const size_t lds = (size_t)words * 512;
+            bool ok = hipMemcpyAsync(orig, mat, mat_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                      hipMemcpyAsync(work, orig, mat_bytes, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+                      hipMemcpyAsync(gates_dev, gates, gate_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+                      hipMemcpyAsync(flag_dev, &none, 8, hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(conjugate_kernel, grid, block, lds, ctx->stream, work, k, (int)n, ld, (int)words, gates_dev,
+                                   limit, flag_dev);
+                ok = hipGetLastError() == hipSuccess &&
+                     hipMemcpyAsync(&flag, flag_dev, 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                     hipStreamSynchronize(ctx->stream) == hipSuccess;
+            }
+            if (ok && flag != none) {                               // replay the accepted prefix on the original
+                refused = (int64_t)flag;
+                ok = hipMemcpyAsync(work, orig, mat_bytes, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess;
+                if (ok && refused > 0) {
+                    hipLaunchKernelGGL(conjugate_kernel, grid, block, lds, ctx->stream, work, k, (int)n, ld, (int)words,
+                                       gates_dev, refused, flag_dev);
+                    ok = hipGetLastError() == hipSuccess;
+                }
+            }
+            if (ok)
+                ok = hipMemcpyAsync(mat, work, mat_bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+                     hipStreamSynchronize(ctx->stream) == hipSuccess;
+            if (!ok) {
+                gf2_set_error("gf2_conjugate_gates: HIP call failed: %s", hipGetErrorString(hipGetLastError()));
+                rc = GF2_E_HIP;
+            }
+        }
+        (void)gf2_dev_free(ctx, work);
+        (void)gf2_dev_free(ctx, orig);
+        (void)gf2_dev_free(ctx, gates_dev);
+        (void)gf2_dev_free(ctx, flag_dev);
+        if (rc != GF2_OK) return rc;
+    }
+    if (refused >= 0) {
+        *stop_out = refused;
+        GF2_FAIL(GF2_E_NOTCSS, "gf2_conjugate_gates: gate %lld is an H on a qubit where a row has both X and Z", (long long)refused);
+    }
+    if (limit < ngates) {
+        *stop_out = limit;
+        GF2_FAIL(GF2_E_ARG, "gf2_conjugate_gates: gate %lld has an unknown kind or a qubit outside [0, n)", (long long)limit);
+    }
+    return GF2_OK;
+}

@@ -55,8 +55,8 @@ struct gf2_ctx {
     void* ws[3];
     size_t ws_bytes[3];
     // large dynamic-LDS opt-in (hipFuncSetAttribute) done for this context's device: [0] syndrome_tiled_kernel,
-    // [1] rref_update_kernel, [2] syndrome_slabs_kernel
-    bool lds_optin[3];
+    // [1] rref_update_kernel, [2] slab_gather_kernel, [3] conjugate_kernel
+    bool lds_optin[4];
 };
 
 int gf2_ctx_activate(gf2_ctx* ctx);

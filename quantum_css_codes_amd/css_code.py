@@ -11,7 +11,12 @@ Drop-in surface (same names, arguments, mutation and exception behaviour):
     syndrome_table, normalize_parity_check, swap_columns, codes_equal, is_doubly_even,
     pauli_term_for_row                                css_code.py:715-735, 783-850
 
-Quil program emission (encode_*, error_correct, measure, ...) is out of scope.
+    CSSCode.noisy_encode_zero / noisy_encode_plus    css_code.py:203-312   (gate arrays, see below)
+    transform_stabilisers, conjugate_h_with_check_mat, conjugate_cnot_with_check_mat   css_code.py:737-781
+
+Other Quil program emission (error_correct, measure, ...) is out of scope.  The two encoders
+are returned as gate arrays -- rows (kind, a, b), GATE_H on qubit a or GATE_CNOT control a target b, in the
+reference's instruction order -- which is what transform_stabilisers takes here [SURVEY.md 8f item 3].
 pyQuil is not required: Pauli operators are returned as text labels ("X0*X3*X4*X5") unless pyQuil is
 importable, in which case PauliTerm objects are returned as in the reference.
 
@@ -32,6 +37,9 @@ try:                                                # optional, as in SURVEY.md 
     _HAVE_PYQUIL = True
 except Exception:                                   # pragma: no cover - pyquil is absent in this image
     _HAVE_PYQUIL = False
+
+
+GATE_H, GATE_CNOT = 0, 1                            # kinds of a gate-array row (kind, a, b)
 
 
 class CSSCode(QECC):
@@ -164,6 +172,45 @@ class CSSCode(QECC):
         return frozenset(names)
 
     # -- build-defined: batched syndromes and Monte-Carlo ---------------------------------------------------
+    def encode_zero_gates(self, qubits=None):
+        """
+        The instruction sequence of noisy_encode_zero (css_code.py:203-259) as an (g, 3) int32 array: H on the first
+        r_1 qubits, then CNOT(i, j) for every 1 of parity_check_c1[i, j] with j >= r_1, rows in order, columns in order.
+        """
+        n, r_1 = self.n, self.r_1
+        qubits = np.arange(n, dtype=np.int32) if qubits is None else np.asarray(list(qubits), dtype=np.int32)
+        ctrl, targ = np.nonzero(self.parity_check_c1[:, r_1:] == 1)          # row-major: i ascending, then j
+        gates = np.zeros((r_1 + len(ctrl), 3), dtype=np.int32)
+        gates[:r_1, 0], gates[:r_1, 1] = GATE_H, qubits[:r_1]
+        gates[r_1:, 0], gates[r_1:, 1], gates[r_1:, 2] = GATE_CNOT, qubits[ctrl], qubits[targ + r_1]
+        return gates
+
+    def encode_plus_gates(self, qubits=None):
+        """
+        The instruction sequence of noisy_encode_plus (css_code.py:261-312): H on the first r_1 and on the last
+        n - r_1 - r_2 qubits, CNOT(j, i) for every 1 of parity_check_c2[i - r_1, j] with j >= r_1 + r_2, then the CNOTs of
+        noisy_encode_zero.
+        """
+        n, r_1, r_2 = self.n, self.r_1, self.r_2
+        qubits = np.arange(n, dtype=np.int32) if qubits is None else np.asarray(list(qubits), dtype=np.int32)
+        had = np.concatenate((qubits[:r_1], qubits[r_1 + r_2:]))
+        rows, cols = np.nonzero(self.parity_check_c2[:, r_1 + r_2:] == 1)
+        ctrl, targ = np.nonzero(self.parity_check_c1[:, r_1:] == 1)
+        gates = np.zeros((len(had) + len(rows) + len(ctrl), 3), dtype=np.int32)
+        a, b = len(had), len(had) + len(rows)
+        gates[:a, 0], gates[:a, 1] = GATE_H, had
+        gates[a:b, 0], gates[a:b, 1], gates[a:b, 2] = GATE_CNOT, qubits[cols + r_1 + r_2], qubits[rows + r_1]
+        gates[b:, 0], gates[b:, 1], gates[b:, 2] = GATE_CNOT, qubits[ctrl], qubits[targ + r_1]
+        return gates
+
+    def noisy_encode_zero(self, qubits):
+        """css_code.py:203-259 as a gate array (see encode_zero_gates); qubits must be integers."""
+        return self.encode_zero_gates(qubits)
+
+    def noisy_encode_plus(self, qubits):
+        """css_code.py:261-312 as a gate array (see encode_plus_gates); qubits must be integers."""
+        return self.encode_plus_gates(qubits)
+
     def _device_checks(self):
         if self._checks is None:
             ctx = _native.default_context()
@@ -308,6 +355,68 @@ def _syndromes_of(ctx, chk, packed_h, r, n, packed_e, count):
     e_buf.free()
     s_buf.free()
     return out
+
+
+def _gate_array(prog):
+    """Gate array of a program: an (g, 3) array as is; a pyQuil Program (when pyQuil is importable) or any sequence
+    of (name, qubits...) tuples is converted, with the reference's checks (css_code.py:741-755)."""
+    if isinstance(prog, np.ndarray):
+        return np.ascontiguousarray(prog, dtype=np.int32).reshape(-1, 3)
+    gates = []
+    for inst in getattr(prog, "instructions", prog):
+        if isinstance(inst, (tuple, list)):
+            name, qubits = inst[0], [int(q) for q in inst[1:]]
+        else:
+            if not hasattr(inst, "qubits") or not hasattr(inst, "name"):
+                raise ValueError("program must only contain gates")
+            if any(not hasattr(qubit, "index") for qubit in inst.qubits):
+                raise ValueError("gate cannot have placeholders")
+            name, qubits = inst.name, [qubit.index for qubit in inst.qubits]
+        if name in ('H', GATE_H) and len(qubits) == 1:
+            gates.append((GATE_H, qubits[0], 0))
+        elif name in ('CNOT', GATE_CNOT) and len(qubits) == 2:
+            gates.append((GATE_CNOT, qubits[0], qubits[1]))
+        else:
+            gates.append((-1, qubits[0] if qubits else 0, 0))        # refused when the walk reaches it
+    return np.array(gates, dtype=np.int32).reshape(-1, 3)
+
+
+def transform_stabilisers(mat, prog):
+    """
+    Conjugate the k x 2n stabiliser matrix [X | Z] through a Clifford program of H and CNOT gates, in place
+    (css_code.py:737-755).  prog is a gate array as returned by CSSCode.noisy_encode_zero / noisy_encode_plus (or a
+    pyQuil Program, or tuples ('H', q) / ('CNOT', c, t)).  Gates apply in order on the GPU (gf2_conjugate_gates).
+    As in the reference, a gate is checked when it is reached: ValueError for a qubit outside [0, n) or a gate other
+    than H / CNOT, NotImplementedError("only handles CSS codes") for an H on a qubit where a row has both X and Z; mat
+    then holds what the reference leaves behind (all earlier gates, and the rows before the offending one swapped).
+    """
+    k, cols = mat.shape
+    n = cols // 2
+    gates = _gate_array(prog)
+    packed = _native.pack_rows(mat)
+    rc, stop = _native.default_context().conjugate_gates(packed, k, n, gates)
+    mat[...] = _native.unpack_rows(packed, cols, dtype=mat.dtype)
+    if rc == _native.GF2_E_NOTCSS:
+        q = int(gates[stop, 1])
+        bad = int(np.flatnonzero((mat[:, q] == 1) & (mat[:, n + q] == 1))[0])
+        upper = mat[:bad, [q, n + q]].copy()                       # css_code.py:761-767: rows above were swapped already
+        mat[:bad, q], mat[:bad, n + q] = upper[:, 1], upper[:, 0]
+        raise NotImplementedError("only handles CSS codes")
+    if rc == _native.GF2_E_ARG:
+        kind, a, b = (int(v) for v in gates[stop])
+        if kind in (GATE_H, GATE_CNOT):
+            raise ValueError("qubit index must be within [0, n)")
+        raise ValueError("cannot conjugate gate {}".format(kind))
+
+
+def conjugate_h_with_check_mat(mat, qubit):
+    """css_code.py:757-767."""
+    transform_stabilisers(mat, np.array([[GATE_H, qubit, 0]], dtype=np.int32))
+
+
+def conjugate_cnot_with_check_mat(mat, control, target):
+    """css_code.py:769-781."""
+    transform_stabilisers(mat, np.array([[GATE_CNOT, control, target]], dtype=np.int32))
 
 
 def swap_columns(mat, indices):

@@ -3,6 +3,7 @@ Parity of the HIP path (through the C ABI) against the oracle and the reference-
 Needs a real MI355X: run with `pytest -m gpu`.  Bit-exact everywhere (integer work only).
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -759,3 +760,102 @@ def test_syndrome_table_device_search(case, ctx, steane_h, rm15):
     r, n = h.shape
     t2, dense = ctx.syndrome_table(_native.pack_rows(h), r, n, cap)
     assert t2 == t and int((dense != ctx.TABLE_EMPTY).sum()) == sum(comb(n, w) for w in range(t + 1))
+
+
+# ---- encoder gate lists and stabiliser conjugation --------------------------------------------------
+
+def test_transform_stabilisers_golden_sequences():
+    # the reference's own conjugate_h / conjugate_cnot outputs on seeded matrices and gate lists
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "conjugation_golden.npz"))
+    for i in range(8):
+        mat, gates, stop = np.array(g["conj_in_%d" % i]), g["conj_gates_%d" % i], int(g["conj_stop_%d" % i])
+        if stop < 0:
+            css_code.transform_stabilisers(mat, gates)
+            assert np.array_equal(mat, g["conj_out_%d" % i])
+        else:
+            # the reference refuses gate `stop`: everything before it applies, then its partial row swaps
+            want = np.array(g["conj_in_%d" % i])
+            with pytest.raises(NotImplementedError):
+                cpu_ref.transform_stabilisers(want, gates)
+            with pytest.raises(NotImplementedError, match="only handles CSS codes"):
+                css_code.transform_stabilisers(mat, gates)
+            assert np.array_equal(mat, want)
+            prefix = np.array(g["conj_in_%d" % i])
+            css_code.transform_stabilisers(prefix, gates[:stop])
+            assert np.array_equal(prefix, g["conj_out_%d" % i])
+    for i in range(4):
+        mat = np.array(g["enc_in_%d" % i])
+        css_code.transform_stabilisers(mat, g["enc_gates_%d" % i])
+        assert np.array_equal(mat, g["enc_out_%d" % i])
+    rows = np.array(g["cnot_truth_in"])
+    css_code.conjugate_cnot_with_check_mat(rows, 0, 1)
+    assert np.array_equal(rows, g["cnot_truth_out"])
+    rows = np.array(g["h_truth_in"])
+    css_code.conjugate_h_with_check_mat(rows, 0)
+    assert np.array_equal(rows, g["h_truth_out"])
+
+
+def test_steane_encoders_known_answers(steane_h):
+    # test/test_css_code.py:61-106
+    code = css_code.CSSCode(steane_h, steane_h)
+    n = 7
+    prog = code.noisy_encode_zero(range(n))
+    assert np.array_equal(prog, cpu_ref.encode_zero_gates(cpu_ref.CSSCode(steane_h, steane_h)))
+    mat = np.concatenate((np.zeros((n, n), dtype='int'), np.identity(n, dtype='int')), axis=1)
+    for i in range(3):
+        if code.parity_check_c2[i, 6] == 1:
+            mat[3 + i, :] += mat[6, :]
+    mat = np.mod(mat, 2)
+    css_code.transform_stabilisers(mat, prog)
+    expected = np.zeros((n, 2 * n), dtype='int')
+    expected[0:3, 0:7] = code.parity_check_c1
+    expected[3:6, 7:14] = code.parity_check_c2
+    expected[6, 7:10] = np.transpose(code.parity_check_c1[:, 6:7])
+    expected[6, 13:14] = np.identity(1, dtype='int')
+    assert np.array_equal(mat, expected)
+
+    prog = code.noisy_encode_plus(range(n))
+    assert np.array_equal(prog, cpu_ref.encode_plus_gates(cpu_ref.CSSCode(steane_h, steane_h)))
+    mat = np.concatenate((np.zeros((n, n), dtype='int'), np.identity(n, dtype='int')), axis=1)
+    css_code.transform_stabilisers(mat, prog)
+    expected = np.zeros((n, 2 * n), dtype='int')
+    expected[0:3, 0:7] = code.parity_check_c1
+    expected[3:6, 7:14] = code.parity_check_c2
+    expected[6, 3:6] = np.transpose(code.parity_check_c2[:, 6:7])
+    expected[6, 6] = 1
+    assert np.array_equal(mat, expected)
+
+
+def test_transform_stabilisers_argument_errors(steane_h):
+    mat = np.concatenate((np.zeros((3, 7), dtype='int'), steane_h), axis=1)
+    before = mat.copy()
+    with pytest.raises(ValueError, match="qubit index must be within"):
+        css_code.transform_stabilisers(mat, [('H', 0), ('CNOT', 1, 7)])
+    want = before.copy()
+    cpu_ref.transform_stabilisers(want, [(0, 0, 0)])
+    assert np.array_equal(mat, want)                         # the H before the bad gate was applied
+    with pytest.raises(ValueError, match="cannot conjugate gate"):
+        css_code.transform_stabilisers(mat, [('X', 0)])
+    css_code.transform_stabilisers(mat, np.zeros((0, 3), dtype=np.int32))
+    assert np.array_equal(mat, want)
+    empty = np.zeros((0, 14), dtype='int')
+    css_code.transform_stabilisers(empty, [('H', 1)])
+
+
+def test_encoders_of_the_n4096_code_prepare_its_stabilisers(ctx):
+    # config 4 of BASELINE.json: the |+> encoder of the random dual code (about 2 million CNOTs) conjugates
+    # Z_1 .. Z_n into [H1 | 0], [0 | H2] and the logical X row -- the reference's Steane assertion
+    # (test/test_css_code.py:89-106) at full size, where its Python loop over gates x rows cannot finish
+    import bench
+    code, _, _ = bench.build_code()
+    n, r_1, r_2 = code.n, code.r_1, code.r_2
+    prog = code.noisy_encode_plus(range(n))
+    assert prog.shape[0] > 10 ** 6
+    mat = np.concatenate((np.zeros((n, n), dtype=np.uint8), np.identity(n, dtype=np.uint8)), axis=1)
+    css_code.transform_stabilisers(mat, prog)
+    expected = np.zeros((n, 2 * n), dtype=np.uint8)
+    expected[0:r_1, 0:n] = code.parity_check_c1
+    expected[r_1:r_1 + r_2, n:2 * n] = code.parity_check_c2
+    expected[r_1 + r_2:, r_1:r_1 + r_2] = np.transpose(code.parity_check_c2[:, r_1 + r_2:])
+    expected[r_1 + r_2:, r_1 + r_2:n] = np.identity(n - r_1 - r_2, dtype=np.uint8)
+    assert np.array_equal(mat, expected)

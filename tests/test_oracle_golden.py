@@ -3,6 +3,7 @@ Pins the oracle (oracle/cpu_ref.py) to the reference: its own known-answer tests
 of the reference itself on fixed inputs (tests/golden/reference_golden.npz).  CPU only.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -237,3 +238,52 @@ def test_decode_tally_c_vs_numpy(steane_h, rm15):
     # error-free channel: nothing flips, every syndrome (zero) is in the table
     code = ref.CSSCode(steane_h, steane_h)
     assert ref.decode_and_tally(code, 1, 0, 20, 0.0, 0.0, 0.0) == [0, 0, 0, 0, 0]
+
+
+def test_conjugation_rules_vs_reference_outputs():
+    # oracle restatement of css_code.py:737-781 against the reference's own conjugate_h / conjugate_cnot outputs
+    # (tests/golden/make_golden_conjugation.py), incl. the gate at which the reference refuses a non-CSS row
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "conjugation_golden.npz"))
+    for i in range(8):
+        mat, gates, stop = np.array(g["conj_in_%d" % i]), g["conj_gates_%d" % i], int(g["conj_stop_%d" % i])
+        ref.transform_stabilisers(mat, gates if stop < 0 else gates[:stop])
+        assert np.array_equal(mat, g["conj_out_%d" % i])
+        if stop >= 0:
+            with pytest.raises(NotImplementedError):
+                ref.transform_stabilisers(mat, gates[stop:stop + 1])
+    for i in range(4):
+        mat = np.array(g["enc_in_%d" % i])
+        ref.transform_stabilisers(mat, g["enc_gates_%d" % i])
+        assert np.array_equal(mat, g["enc_out_%d" % i])
+    rows = np.array(g["cnot_truth_in"])
+    ref.conjugate_cnot_with_check_mat(rows, 0, 1)
+    assert np.array_equal(rows, g["cnot_truth_out"])
+    rows = np.array(g["h_truth_in"])
+    ref.conjugate_h_with_check_mat(rows, 0)
+    assert np.array_equal(rows, g["h_truth_out"])
+
+
+def test_encoder_gate_lists_known_answers(steane_h):
+    # test/test_css_code.py:61-106 through the oracle: the encoders turn Z_1..Z_n into the code's stabilisers
+    code = ref.CSSCode(steane_h, steane_h)
+    n = 7
+    mat = np.concatenate((np.zeros((n, n), dtype='int'), np.identity(n, dtype='int')), axis=1)
+    for i in range(3):
+        if code.parity_check_c2[i, 6] == 1:
+            mat[3 + i, :] += mat[6, :]
+    mat = np.mod(mat, 2)
+    ref.transform_stabilisers(mat, ref.encode_zero_gates(code))
+    expected = np.zeros((n, 2 * n), dtype='int')
+    expected[0:3, 0:7] = code.parity_check_c1
+    expected[3:6, 7:14] = code.parity_check_c2
+    expected[6, 7:10] = np.transpose(code.parity_check_c1[:, 6:7])
+    expected[6, 13:14] = 1
+    assert np.array_equal(mat, expected)
+    mat = np.concatenate((np.zeros((n, n), dtype='int'), np.identity(n, dtype='int')), axis=1)
+    ref.transform_stabilisers(mat, ref.encode_plus_gates(code))
+    expected = np.zeros((n, 2 * n), dtype='int')
+    expected[0:3, 0:7] = code.parity_check_c1
+    expected[3:6, 7:14] = code.parity_check_c2
+    expected[6, 3:6] = np.transpose(code.parity_check_c2[:, 6:7])
+    expected[6, 6] = 1
+    assert np.array_equal(mat, expected)
