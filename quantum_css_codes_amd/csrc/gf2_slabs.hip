@@ -249,10 +249,18 @@ __device__ __forceinline__ unsigned int entry_addr_hi(unsigned int part_base, un
     return out;
 }
 
-// Record at position `pos` (all four lanes of a record load the same 64 bytes); positions past the end read zeros.
-__device__ __forceinline__ void fetch_record(__amdgpu_buffer_rsrc_t rec_rsrc, unsigned int pos, u32x4 (&R)[4]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) R[q] = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, pos << 6, q * 16, 0);
+// Quarter `part` (16 bytes = 8 slots) of the record at position `pos`: the four lanes of a record load one quarter each
+// and hand the slots to each other with DPP quad broadcasts -- one memory instruction per step instead of four (address
+// processing of a wave-wide load with scattered addresses costs about as much as the whole lookup loop).  Positions past
+// the end read zeros.
+__device__ __forceinline__ u32x4 fetch_record(__amdgpu_buffer_rsrc_t rec_rsrc, unsigned int pos, unsigned int part16) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, (pos << 6) | part16, 0, 0);
+}
+
+// Value of `v` in lane Q of this lane's quad.
+template <int Q>
+__device__ __forceinline__ unsigned int quad_bcast(unsigned int v) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, Q * 0x55, 0xF, 0xF, false);
 }
 
 // The five error dwords that hold the identity-block bits of this lane's 128 rows of sample `sample`; addresses clamped into
@@ -340,22 +348,24 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
     // Software pipeline, two stages: the records of step i + 2 and the identity words of step i + 1 (their address needs
     // the record) are in flight while the lookups of step i run.  Three record and three identity buffers take turns
     // (the loop is unrolled by three), so nothing is copied between stages.
-    u32x4 RA[4], RB[4], RC[4];
+    u32x4 RA, RB, RC;
     unsigned int iwA[5], iwB[5], iwC[5];
+    const unsigned int part16 = (unsigned int)part * 16u;
     unsigned int grp = (unsigned int)share * GAT_WAVES + wave;
-    fetch_record(rec_rsrc, grp * 16 + lane_rec, RA);
-    fetch_record(rec_rsrc, (grp + stride) * 16 + lane_rec, RB);
-    fetch_ident(a, record_sample(grp * 16 + lane_rec, RA[0].x), row_bytes, dw0, row_dwords, aligned16, id_sh, part == 3, iwA);
+    RA = fetch_record(rec_rsrc, grp * 16 + lane_rec, part16);
+    RB = fetch_record(rec_rsrc, (grp + stride) * 16 + lane_rec, part16);
+    fetch_ident(a, record_sample(grp * 16 + lane_rec, quad_bcast<0>(RA.x)), row_bytes, dw0, row_dwords, aligned16, id_sh,
+                part == 3, iwA);
 
-    auto step = [&](u32x4 (&R)[4], unsigned int (&iw)[5], u32x4 (&Rnext)[4], u32x4 (&Rfar)[4], unsigned int (&iwnext)[5]) {
+    auto step = [&](const u32x4& R, unsigned int (&iw)[5], const u32x4& Rnext, u32x4& Rfar, unsigned int (&iwnext)[5]) {
         const unsigned int pos = grp * 16 + lane_rec;
-        fetch_record(rec_rsrc, pos + 2 * stride * 16, Rfar);
-        fetch_ident(a, record_sample(pos + stride * 16, Rnext[0].x), row_bytes, dw0, row_dwords, aligned16, id_sh, part == 3,
-                    iwnext);
-        const unsigned int slot0 = R[0].x & 0xFFFFu;
+        Rfar = fetch_record(rec_rsrc, pos + 2 * stride * 16, part16);
+        fetch_ident(a, record_sample(pos + stride * 16, quad_bcast<0>(Rnext.x)), row_bytes, dw0, row_dwords, aligned16, id_sh,
+                    part == 3, iwnext);
+        const unsigned int head = quad_bcast<0>(R.x);               // slot 0 (count, tile-local sample) and slot 1
+        const unsigned int slot0 = head & 0xFFFFu;
         const bool flagged = (slot0 & 0xFFu) == REC_OVER;
-        const unsigned int sample = record_sample(pos, slot0);
-        const bool valid = sample < (unsigned int)a.batch;
+        const bool valid = record_sample(pos, slot0) < (unsigned int)a.batch;
         const unsigned int c = flagged || !valid ? 0u : (slot0 & 0xFFu);
         if (from_neighbour) {                                       // quad_perm [1,2,3,3]: lane p takes lane p + 1's first dword
             const unsigned int nb = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)iw[0], 0xF9, 0xF, 0xF, false);
@@ -374,12 +384,7 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
         }
         // the tile is sorted by count (finished and out-of-batch samples first, as 0): the last record has the most slots
         const unsigned int mx = (unsigned int)__builtin_amdgcn_readlane((int)c, 63) + 1u;
-        const unsigned int first_pair = (R[0].x & 0xFFFF0000u) | null_ent;    // slot 0 becomes a zero entry
-#pragma unroll
-        for (int k0 = 0; k0 < REC_SLOTS; k0 += 4) {
-            if ((unsigned int)k0 >= mx) break;
-            const unsigned int lo = k0 == 0 ? first_pair : (k0 & 4 ? R[k0 >> 3].z : R[k0 >> 3].x);
-            const unsigned int hi = k0 & 4 ? R[k0 >> 3].w : R[k0 >> 3].y;
+        auto lookups = [&](unsigned int lo, unsigned int hi) {      // four slots = two record dwords
             const u32x4 v0 = *(lds_u32x4_ptr)(uintptr_t)entry_addr_lo(part_base, lo);
             const u32x4 v1 = *(lds_u32x4_ptr)(uintptr_t)entry_addr_hi(part_base, lo);
             const u32x4 v2 = *(lds_u32x4_ptr)(uintptr_t)entry_addr_lo(part_base, hi);
@@ -388,11 +393,21 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
             X[1] ^= v0.y ^ v1.y ^ v2.y ^ v3.y;
             X[2] ^= v0.z ^ v1.z ^ v2.z ^ v3.z;
             X[3] ^= v0.w ^ v1.w ^ v2.w ^ v3.w;
-        }
+        };
+        // slots 4g .. 4g + 3 are dwords (x, y) or (z, w) of quarter g / 2; slot 0 becomes a zero entry
+        lookups((head & 0xFFFF0000u) | null_ent, quad_bcast<0>(R.y));
+        if (mx > 4) lookups(quad_bcast<0>(R.z), quad_bcast<0>(R.w));
+        if (mx > 8) lookups(quad_bcast<1>(R.x), quad_bcast<1>(R.y));
+        if (mx > 12) lookups(quad_bcast<1>(R.z), quad_bcast<1>(R.w));
+        if (mx > 16) lookups(quad_bcast<2>(R.x), quad_bcast<2>(R.y));
+        if (mx > 20) lookups(quad_bcast<2>(R.z), quad_bcast<2>(R.w));
+        if (mx > 24) lookups(quad_bcast<3>(R.x), quad_bcast<3>(R.y));
+        if (mx > 28) lookups(quad_bcast<3>(R.z), quad_bcast<3>(R.w));
         unsigned int wt = __popc(X[0]) + __popc(X[1]) + __popc(X[2]) + __popc(X[3]);
         wt += __builtin_amdgcn_update_dpp(0u, wt, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
         wt += __builtin_amdgcn_update_dpp(0u, wt, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-        if (part == 0 && valid) pw[sample] = (unsigned short)(flagged ? REC_FLAG : wt);
+        // partial weights are stored by record position (contiguous), which is all the histogram needs
+        if (part == 0) pw[pos] = (unsigned short)(flagged || !valid ? REC_FLAG : wt);
     };
 #pragma unroll 1
     while (grp < ngroups) {
@@ -409,22 +424,22 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
 
 // ---- combine ---------------------------------------------------------------------------------------------------------
 
-// Four consecutive samples per lane and step: one 8-byte load per slab (at most four slabs: r <= 2048), all issued before
+// Four consecutive record positions per lane and step: one 8-byte load per slab (at most four slabs: r <= 2048), all issued before
 // any is used.
-__global__ __launch_bounds__(256) void slab_combine_kernel(const unsigned short* __restrict__ pw, int64_t batch, int64_t batch_pad,
+__global__ __launch_bounds__(256) void slab_combine_kernel(const unsigned short* __restrict__ pw, int64_t positions, int64_t batch_pad,
                                                           int nslabs, u64* __restrict__ hist, int nbins) {
     __shared__ unsigned int bins[SLAB_MAX_BINS];
     for (int i = threadIdx.x; i < nbins; i += blockDim.x) bins[i] = 0;
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
-    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; s < batch; s += stride) {
+    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; s < positions; s += stride) {
         u64 four[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) four[k] = *reinterpret_cast<const u64*>(pw + (int64_t)(k < nslabs ? k : 0) * batch_pad + s);
         unsigned int w[4] = {0, 0, 0, 0};
         bool skip[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) skip[t] = s + t >= batch;
+        for (int t = 0; t < 4; ++t) skip[t] = false;            // finished and out-of-batch records carry REC_FLAG
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k < nslabs) {
@@ -547,7 +562,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
 
         int64_t mblocks = gf2_cdiv(count, 1024);
         if (mblocks > (int64_t)ctx->num_cus) mblocks = ctx->num_cus;
-        hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3(256), 0, ctx->stream, pw, count, pad,
+        hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3(256), 0, ctx->stream, pw, gf2_cdiv(count, 64) * 64, pad,
                            ck->nslabs512, (u64*)hist_dev, nbins);
         GF2_HIP(hipGetLastError());
     }
