@@ -1,4 +1,5 @@
-"""Times the LDS row-slab sparse kernel on the benchmark workload (and, with GF2_SLAB_DBG, with phases switched off)."""
+"""Times the LDS row-slab sparse pipeline (gf2_slabs.hip) on the two check shapes of the benchmark; GF2_SPARSE_GATHER=1 times
+the column-gather kernel instead.  Used under rocprofv3 --kernel-trace for the per-kernel split."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -24,6 +25,6 @@ def main():
             ctx.syndrome_sparse_dev(chk, ex, batch, 64, None, 0, hist, rr + 1)
         ms = ctx.timer_stop() / 20
         results.append("r=%d off=%d: %.4f ms/launch (%.0f GB/s)" % (rr, ioff, ms, batch * 512 / ms / 1e6))
-    print("DBG=%s  " % os.environ.get("GF2_SLAB_DBG", "0") + " | ".join(results))
+    print(("gather kernel: " if os.environ.get("GF2_SPARSE_GATHER") else "slab pipeline: ") + " | ".join(results))
 
 main()

@@ -260,7 +260,7 @@ __device__ __forceinline__ u32x4 fetch_record(__amdgpu_buffer_rsrc_t rec_rsrc, u
 // Value of `v` in lane Q of this lane's quad.
 template <int Q>
 __device__ __forceinline__ unsigned int quad_bcast(unsigned int v) {
-    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, Q * 0x55, 0xF, 0xF, false);
+    return (unsigned int)__builtin_amdgcn_mov_dpp((int)v, Q * 0x55, 0xF, 0xF, true);
 }
 
 // The five error dwords that hold the identity-block bits of this lane's 128 rows of sample `sample`; addresses clamped into
