@@ -859,3 +859,48 @@ def test_encoders_of_the_n4096_code_prepare_its_stabilisers(ctx):
     expected[r_1 + r_2:, r_1:r_1 + r_2] = np.transpose(code.parity_check_c2[:, r_1 + r_2:])
     expected[r_1 + r_2:, r_1 + r_2:n] = np.identity(n - r_1 - r_2, dtype=np.uint8)
     assert np.array_equal(mat, expected)
+
+
+def test_slab_pipeline_padded_rows_and_several_workspace_passes(ctx, monkeypatch):
+    # (a) rows padded to lde = 71 words (odd: the identity words are not 16-byte aligned) with garbage-free padding,
+    # (b) a batch above the 2^21-sample workspace pass, so the pipeline runs twice and carries on at the right row;
+    # both against the column-gather kernel on the same resident errors
+    r, n, ioff = 1024, 3000, 1900
+    rng = np.random.default_rng(2)
+    hm = rng.integers(0, 2, (r, n), dtype=np.uint8)
+    hm[:, ioff:ioff + r] = np.identity(r, dtype=np.uint8)
+    chk = ctx.check_create(_native.pack_rows(hm), r, n)
+    words, lde, batch = _native.words_for(n), 71, 40000
+    em = (rng.random((batch, n)) < 0.004).astype(np.uint8)
+    e = np.zeros((batch, lde), dtype="<u8")
+    e[:, :words] = _native.pack_rows(em)
+    e_buf = ctx.alloc(e.nbytes).upload(e)
+    want = c_oracle.histogram(c_oracle.syndrome_batch(_native.pack_rows(hm), r, n, _native.pack_rows(em)[:5000].copy(), 5000),
+                              5000, r, 1, r + 1)
+    for count in (batch, 5000):
+        hists = []
+        for force_gather in (False, True):
+            monkeypatch.setenv("GF2_SPARSE_GATHER" if force_gather else "GF2_SPARSE_SLABS", "1")
+            hist = ctx.alloc((r + 1) * 8).zero()
+            ctx.syndrome_sparse_dev(chk, e_buf, count, lde, None, 0, hist, r + 1)
+            hists.append(hist.download((r + 1,), np.uint64))
+            monkeypatch.delenv("GF2_SPARSE_GATHER" if force_gather else "GF2_SPARSE_SLABS")
+        assert np.array_equal(hists[0], hists[1]) and int(hists[0].sum()) == count
+        if count == 5000:
+            assert np.array_equal(hists[0], want)
+    # (b)
+    r, n, batch = 2048, 4096, (1 << 21) + 12345
+    hm = rng.integers(0, 2, (r, n), dtype=np.uint8)
+    hm[:, :r] = np.identity(r, dtype=np.uint8)
+    chk = ctx.check_create(_native.pack_rows(hm), r, n)
+    ex, ez = ctx.alloc(batch * 512), ctx.alloc(batch * 512)
+    ctx.sample_errors_dev(n, 9, 0, batch, 0.003, 0.003, 0.003, ex, ez, 64)
+    hists = []
+    for force_gather in (False, True):
+        if force_gather:
+            monkeypatch.setenv("GF2_SPARSE_GATHER", "1")
+        hist = ctx.alloc((r + 1) * 8).zero()
+        ctx.syndrome_sparse_dev(chk, ez, batch, 64, None, 0, hist, r + 1)
+        hists.append(hist.download((r + 1,), np.uint64))
+    assert np.array_equal(hists[0], hists[1]) and int(hists[0].sum()) == batch
+    ex.free(), ez.free()
