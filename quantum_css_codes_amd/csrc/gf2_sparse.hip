@@ -19,6 +19,8 @@
 // L2-resident row gathers).  A 16-lanes-per-sample variant (4 samples per wavefront, 1 KiB per wavefront load,
 // 2.3 instead of 5 instructions per column) measured the same time, which is how the bound was identified.
 // The dense Four-Russians kernel (gf2_syndrome.hip) remains the data-independent path; DESIGN.md gives the crossover.
+// Histogram-only calls on large batches go to the LDS-slab pipeline instead (gf2_slabs.hip), which uses this file's
+// wavefront-per-sample routine only for the rare samples that do not fit a record.
 #include "gf2_internal.h"
 #include "gf2_sampler.h"
 #include "gf2_sparse_dev.h"
