@@ -31,7 +31,7 @@ The JSON line also carries
   cpu_baseline  the reference's NumPy path (oracle/cpu_ref.py restatement of css_code.py:728) timed on this
                 host, 1 core, on a bounded sample of the same workload.
   secondary     (rank 0, N = 1) the end-to-end Monte-Carlo (sampler included), the other syndrome kernels (column gather,
-                dense table) on the same workload, and RREF GB/s
+                dense table) on the same workload, configs[1] and configs[2] (Steane, Reed-Muller), and RREF GB/s
                 (2 * m * ceil(n/64) * 8 bytes / time) for one and for 256 resident 2048 x 4096 matrices and for one
                 32768 x 65536 matrix.
 """
@@ -242,6 +242,60 @@ def rref_numbers(ctx):
     return res
 
 
+def small_code_numbers(ctx):
+    """BASELINE.json configs[1], configs[2]: the Steane code on 10^6 and the Reed-Muller [[15,1,3]] code on 10^7 Pauli
+    errors (sampler + both syndromes + full histograms, one fused kernel, checked against the C oracle on a prefix), and
+    the streaming syndrome kernel on 2^31 resident bit-sliced errors (working set beyond the Infinity Cache): exactly
+    (n + r) / 8 bytes per sample and component move, so moved bytes = algorithmic bytes."""
+    from oracle import c_oracle
+    from quantum_css_codes_amd import _native
+    from quantum_css_codes_amd.css_code import CSSCode
+    steane = np.array([[0, 0, 0, 1, 1, 1, 1], [0, 1, 1, 0, 0, 1, 1], [1, 0, 1, 0, 1, 0, 1]])
+    cols = np.arange(1, 16)
+    rm_h1 = np.array([(cols >> b) & 1 for b in range(4)])
+    rm_h2 = np.vstack([rm_h1] + [rm_h1[a] & rm_h1[b] for a in range(4) for b in range(a + 1, 4)])
+    res = {}
+    p = P_TOTAL / 3
+    for name, code, count in (("steane_7_1_3", CSSCode(steane, steane), 10**6), ("reed_muller_15_1_3", CSSCode(rm_h1, rm_h2), 10**7)):
+        n, r1, r2 = code.n, code.r_1, code.r_2
+        h1p, h2p = _native.pack_rows(code.parity_check_c1), _native.pack_rows(code.parity_check_c2)
+        want_z, want_x = c_oracle.mc(h1p, r1, h2p, r2, n, SEED, 0, 20000, p, p, p, 0)
+        got = code.monte_carlo(20000, p, p, p, seed=SEED)
+        assert np.array_equal(got['hist_z'], want_z) and np.array_equal(got['hist_x'], want_x), name + " differs from the oracle"
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            out = code.monte_carlo(count, p, p, p, seed=SEED)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        assert int(out['hist_z'].sum()) == count
+        chk = ctx.check_create(h2p, r2, n)
+        big = 1 << 31
+        bw = big // 64
+        eb, sb = ctx.alloc(n * bw * 8), ctx.alloc(r2 * bw * 8)
+        chunk = np.random.default_rng(1).integers(0, 2**63, 1 << 22, dtype=np.int64).view(np.uint64)
+        for off in range(0, n * bw, chunk.size):                  # any bits will do for a bandwidth measurement
+            _native.check(_native.lib().gf2_h2d(ctx.handle, eb.ptr + off * 8, chunk.ctypes.data,
+                                                min(chunk.size, n * bw - off) * 8))
+        ctx.syndrome_dev(chk, eb, big, bw, sb, bw, _native.LAYOUT_BIT_SLICED)
+        ctx.sync()
+        ctx.timer_start()
+        for _ in range(5):
+            ctx.syndrome_dev(chk, eb, big, bw, sb, bw, _native.LAYOUT_BIT_SLICED)
+        ms = ctx.timer_stop() / 5
+        moved = (n + r2) * bw * 8
+        eb.free(), sb.free()
+        res[name] = {"monte_carlo": {"samples": count, "value": count / best, "unit": "syndromes/s",
+                                     "what": "CSSCode.monte_carlo: fused sampler + both syndromes + full histograms, host "
+                                             "wall time incl. histogram download"},
+                     "bit_sliced_stream": {"samples": big, "value": big / (ms / 1e3), "unit": "syndromes/s",
+                                           "bytes_per_syndrome": (n + r2) / 8.0,
+                                           "roofline": {"bound": "hbm", "kernel": "syndrome_sliced_kernel",
+                                                        "achieved": moved / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                        "frac": moved / ms / 1e6 / HBM_PEAK_GBS}}}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -375,6 +429,7 @@ def main():
                 "rref": rref_numbers(ctx)}
             if gather is not None:
                 out["secondary"]["column_gather_kernel"] = gather
+            out["secondary"]["small_codes"] = small_code_numbers(ctx)
             other.free()
         print(json.dumps(out))
     if world > 1:
