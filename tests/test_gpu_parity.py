@@ -904,3 +904,43 @@ def test_slab_pipeline_padded_rows_and_several_workspace_passes(ctx, monkeypatch
         hists.append(hist.download((r + 1,), np.uint64))
     assert np.array_equal(hists[0], hists[1]) and int(hists[0].sum()) == batch
     ex.free(), ez.free()
+
+
+# ---- randomised sweep over shapes around the word, slab and panel boundaries -----------------------------------------------
+
+def _boundary_dim(rng, top):
+    pool = [0, 1, 2, 31, 32, 33, 63, 64, 65, 127, 128, 129, 191, 192, 255, 256, 257, 511, 512, 513]
+    return int(rng.choice([d for d in pool if d <= top] + [int(rng.integers(0, top + 1))]))
+
+
+def test_randomised_shapes_rref_nullspace_normalize_syndromes(ctx):
+    # 60 seeded draws of (m, n, density, batch): RREF + pivots, nullspace, normalisation (swap list, result or the
+    # reference's two exceptions), syndromes with the histogram of weights -- everything against the C oracle
+    rng = np.random.default_rng(20261004)
+    for trial in range(60):
+        m, n = _boundary_dim(rng, 300), _boundary_dim(rng, 600)
+        density = float(rng.choice([0.02, 0.1, 0.5, 0.9]))
+        a = (rng.random((m, n)) < density).astype(np.uint8)
+        if m > 3 and rng.random() < 0.3:
+            a[m // 2] = a[0] ^ a[m - 1]                       # a dependent row
+        packed = _native.pack_rows(a)
+        want, want_piv, want_rank = c_oracle.rref(packed, m, n)
+        got = packed.copy()
+        piv, rank = ctx.rref(got, m, n)
+        assert rank == want_rank and np.array_equal(piv, want_piv) and np.array_equal(got, want), (trial, m, n)
+        assert np.array_equal(ctx.nullspace(packed.copy(), m, n), c_oracle.nullspace(packed, m, n)), (trial, m, n)
+        if m and n:
+            offset = int(rng.integers(0, n))
+            rc, want_h, want_swaps = c_oracle.normalize(packed, m, n, offset)
+            work = packed.copy()
+            if rc == 0:
+                assert ctx.normalize(work, m, n, offset) == want_swaps and np.array_equal(work, want_h), (trial, m, n, offset)
+            else:
+                with pytest.raises(_native.GF2Error) as err:
+                    ctx.normalize(work, m, n, offset)
+                assert err.value.code == rc, (trial, m, n, offset)
+            batch = int(rng.integers(1, 200))
+            e = _native.pack_rows((rng.random((batch, n)) < float(rng.choice([0.01, 0.3]))).astype(np.uint8))
+            syn = ctx.syndrome_batch(packed, m, n, e, batch)
+            want_syn = c_oracle.syndrome_batch(packed, m, n, e, batch)
+            assert np.array_equal(syn, want_syn), (trial, m, n, batch)
