@@ -80,24 +80,33 @@ struct CompactWaveLds {
     unsigned int cnt[64];
 };
 
-// Word `lane` of the 16 error rows that start at sample s_first (lanes whose word lies inside the identity block load
-// nothing; rows past the batch are clamped and masked by the caller).
-__device__ __forceinline__ void load_rows(const CompactArgs& a, int64_t s_first, u64 amask, int lane, u64 (&w)[CMP_SUB]) {
+// A sub-pass scans 8 samples.  Only the words that hold non-identity columns matter (half of them in a standard form), so
+// the (sample, word) pairs of a sub-pass are dealt out densely: pair p = t * 64 + lane of round t is word
+// wlist[p % NW] of sample p / NW, NW = number of such words.  T = ceil(8 * NW / 64) rounds instead of 8 (4 for
+// H = [I | A] at n = 4096).  Lanes beyond the last pair get mask 0 and a harmless address, so no load is predicated.
+template <int T>
+struct PairMap {
+    unsigned int jw[T];        // (sample in sub-pass) << 6 | word
+    u64 mask[T];               // the word's non-identity columns
+};
+
+template <int T>
+__device__ __forceinline__ void load_pairs(const CompactArgs& a, int64_t s_first, const PairMap<T>& pm, u64 (&w)[T]) {
 #pragma unroll
-    for (int j = 0; j < CMP_SUB; ++j) w[j] = 0;
-    if (amask) {
-#pragma unroll
-        for (int j = 0; j < CMP_SUB; ++j) {
-            const int64_t sample = s_first + j;
-            w[j] = a.e[(sample < a.batch ? sample : a.batch - 1) * a.lde + lane];
-        }
+    for (int t = 0; t < T; ++t) {
+        const int64_t sample = s_first + (pm.jw[t] >> 6);
+        w[t] = a.e[(sample < a.batch ? sample : a.batch - 1) * a.lde + (pm.jw[t] & 63u)];
     }
 }
 
 static_assert(2304 >= (SPARSE_LIST_CAP + 8) * 4, "item region too small for the slow routine's list");
 
+template <int T>
 __global__ __launch_bounds__(CMP_THREADS, 5) void slab_compact_kernel(CompactArgs a) {
     __shared__ CompactWaveLds lds_all[CMP_WAVES];
+    __shared__ unsigned int wlist[64];
+    __shared__ u64 wmask[64];
+    __shared__ unsigned int nw_shared;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     CompactWaveLds& L = lds_all[wave];
@@ -108,6 +117,23 @@ __global__ __launch_bounds__(CMP_THREADS, 5) void slab_compact_kernel(CompactArg
         amask = ~ident_mask(a.ident_off, a.r, lane);
         if (lane == words - 1 && (a.n & 63)) amask &= ~(~0ull << (a.n & 63));
     }
+    if (wave == 0) {
+        const u64 act = __ballot(amask != 0);
+        if (amask) wlist[__builtin_amdgcn_mbcnt_hi((unsigned int)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)act, 0u))] = lane;
+        wmask[lane] = amask;
+        if (lane == 0) nw_shared = (unsigned int)__popcll(act);
+    }
+    __syncthreads();
+    const unsigned int nw = nw_shared;
+    PairMap<T> pm;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const unsigned int p = t * 64 + lane;
+        const bool live = nw && p < CMP_SUB * nw;
+        const unsigned int j = live ? p / nw : 0u, wi = live ? wlist[p - j * nw] : 0u;
+        pm.jw[t] = (j << 6) | wi;
+        pm.mask[t] = live ? wmask[wi] : 0ull;
+    }
     const unsigned int null_ent = (unsigned int)a.null_ord << 4;        // entries are LDS byte offsets inside a row-part plane
     const unsigned int null2 = null_ent | (null_ent << 16);
     const u32x4 null4 = {null2, null2, null2, null2};
@@ -115,10 +141,10 @@ __global__ __launch_bounds__(CMP_THREADS, 5) void slab_compact_kernel(CompactArg
 
     const int64_t ntiles = (a.batch + 63) >> 6;
     const int64_t total_waves = (int64_t)gridDim.x * CMP_WAVES;
-    // The 16 row loads of a sub-pass issue back to back (one branch around them, rows clamped into the batch), and the
-    // loads of the next sub-pass are in flight while this one is compacted.
-    u64 wn[CMP_SUB];
-    load_rows(a, ((int64_t)blockIdx.x * CMP_WAVES + wave) * 64, amask, lane, wn);
+    // The row loads of a sub-pass issue back to back (rows clamped into the batch), and the loads of the next sub-pass are
+    // in flight while this one is compacted.
+    u64 wn[T];
+    load_pairs<T>(a, ((int64_t)blockIdx.x * CMP_WAVES + wave) * 64, pm, wn);
 #pragma unroll 1
     for (int64_t tile = (int64_t)blockIdx.x * CMP_WAVES + wave; tile < ntiles; tile += total_waves) {
         const int64_t s0 = tile * 64;
@@ -127,24 +153,25 @@ __global__ __launch_bounds__(CMP_THREADS, 5) void slab_compact_kernel(CompactArg
         L.cnt[lane] = 0;
 #pragma unroll 1
         for (int sub = 0; sub < 64 / CMP_SUB; ++sub) {
-            u64 w[CMP_SUB];
+            u64 w[T];
 #pragma unroll
-            for (int j = 0; j < CMP_SUB; ++j) w[j] = s0 + sub * CMP_SUB + j < a.batch ? wn[j] & amask : 0ull;
+            for (int t = 0; t < T; ++t)
+                w[t] = s0 + sub * CMP_SUB + (pm.jw[t] >> 6) < a.batch ? wn[t] & pm.mask[t] : 0ull;
             {
                 const int64_t nxt = sub + 1 < 64 / CMP_SUB ? s0 + (sub + 1) * CMP_SUB : (tile + total_waves) * 64;
-                load_rows(a, nxt, amask, lane, wn);
+                load_pairs<T>(a, nxt, pm, wn);
             }
             unsigned int base = 0;
 #pragma unroll
-            for (int j = 0; j < CMP_SUB; ++j) {
-                const bool nz = w[j] != 0;
+            for (int t = 0; t < T; ++t) {
+                const bool nz = w[t] != 0;
                 const u64 act = __ballot(nz);
                 if (nz) {
                     const unsigned int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(act >> 32),
                                                         __builtin_amdgcn_mbcnt_lo((unsigned int)act, 0u));
                     if (pos < CMP_ITEM_CAP) {
-                        L.item_v[pos] = w[j];
-                        L.item_m[pos] = (unsigned short)(((sub * CMP_SUB + j) << 6) | lane);
+                        L.item_v[pos] = w[t];
+                        L.item_m[pos] = (unsigned short)(pm.jw[t] + ((unsigned int)(sub * CMP_SUB) << 6));
                     }
                 }
                 base += (unsigned int)__popcll(act);
@@ -536,7 +563,25 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
         ca.null_ord = ck->slab_null;
         int64_t cblocks = gf2_cdiv(gf2_cdiv(count, 64), CMP_WAVES);
         if (cblocks > (int64_t)ctx->num_cus * 5) cblocks = (int64_t)ctx->num_cus * 5;
-        hipLaunchKernelGGL(slab_compact_kernel, dim3((unsigned)cblocks), dim3(CMP_THREADS), 0, ctx->stream, ca);
+        // rounds per sub-pass: ceil(8 * words with non-identity columns / 64)
+        {
+            int nw = 0;
+            for (int64_t wd = 0; wd < gf2_words(ck->n); ++wd) {
+                const int64_t lo = wd * 64, hi = lo + 64 < ck->n ? lo + 64 : ck->n;
+                const bool inside = ck->ident_off >= 0 && lo >= ck->ident_off && hi <= ck->ident_off + ck->r;
+                nw += inside ? 0 : 1;
+            }
+            const int rounds = (CMP_SUB * nw + 63) / 64;
+            const dim3 cgrid((unsigned)cblocks), cblock(CMP_THREADS);
+            if (rounds <= 4)
+                hipLaunchKernelGGL(slab_compact_kernel<4>, cgrid, cblock, 0, ctx->stream, ca);
+            else if (rounds <= 5)
+                hipLaunchKernelGGL(slab_compact_kernel<5>, cgrid, cblock, 0, ctx->stream, ca);
+            else if (rounds <= 6)
+                hipLaunchKernelGGL(slab_compact_kernel<6>, cgrid, cblock, 0, ctx->stream, ca);
+            else
+                hipLaunchKernelGGL(slab_compact_kernel<8>, cgrid, cblock, 0, ctx->stream, ca);
+        }
         GF2_HIP(hipGetLastError());
 
         GatherArgs ga;
