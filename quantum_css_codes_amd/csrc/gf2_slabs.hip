@@ -295,9 +295,11 @@ __device__ __forceinline__ unsigned int quad_bcast(unsigned int v) {
 __device__ __forceinline__ void fetch_ident(const GatherArgs& a, unsigned int sample, unsigned int row_bytes, unsigned int dw0,
                                             unsigned int row_dwords, bool aligned16, int id_sh, bool last_part,
                                             unsigned int (&iw)[5]) {
+    if (a.ident_off < 0) {
 #pragma unroll
-    for (int t = 0; t < 5; ++t) iw[t] = 0;
-    if (a.ident_off < 0) return;
+        for (int t = 0; t < 5; ++t) iw[t] = 0;
+        return;
+    }
     const unsigned int* rowp32 = reinterpret_cast<const unsigned int*>(
         reinterpret_cast<const char*>(a.e) + (u64)(sample < (unsigned int)a.batch ? sample : 0u) * row_bytes);
     if (aligned16) {
@@ -308,8 +310,9 @@ __device__ __forceinline__ void fetch_ident(const GatherArgs& a, unsigned int sa
         iw[3] = x.w;
     } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) iw[t] = rowp32[dw0 + t < row_dwords ? dw0 + t : 0u];
+        for (int t = 0; t < 4; ++t) iw[t] = rowp32[dw0 + t < row_dwords ? dw0 + t : 0u];     // clamped; masked at use
     }
+    iw[4] = 0;
     if (id_sh) {
         // the fifth dword is the neighbouring row part's first one; only the last part of the slab loads it
         if (last_part || !aligned16) iw[4] = rowp32[dw0 + 4 < row_dwords ? dw0 + 4 : 0u];
