@@ -255,7 +255,7 @@ struct GatherArgs {
     const u64* e;
     const u32x4* rec;
     unsigned short* pw;        // nslabs x batch_pad partial weights
-    int64_t batch, batch_pad, lde;
+    int64_t batch, batch_pad, lde;   // batch_pad: stride of the partial weights; records exist for ceil(batch / 64) * 64 positions
     int tab_stride, nslabs, r, ident_off, null_ord;   // tab_stride: entries per row-part plane (= 4 mod 16)
 };
 
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
         __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.rec), 0, (int)(a.batch_pad * 64), 0x00020000);
     unsigned short* const pw = a.pw + (int64_t)slab * a.batch_pad;
 
-    const unsigned int ngroups = (unsigned int)(a.batch_pad >> 4);  // 16 records per wavefront step
+    const unsigned int ngroups = (unsigned int)(((a.batch + 63) >> 6) << 2);   // 16 records per wavefront step, whole tiles
     const unsigned int stride = (unsigned int)shares * GAT_WAVES;
     const unsigned int lane_rec = lane >> 2;
 
