@@ -87,15 +87,22 @@ struct CompactWaveLds {
 template <int T>
 struct PairMap {
     unsigned int jw[T];        // (sample in sub-pass) << 6 | word
+    unsigned int off[T];       // byte offset of that word from the sub-pass' first row
     u64 mask[T];               // the word's non-identity columns
 };
 
 template <int T>
 __device__ __forceinline__ void load_pairs(const CompactArgs& a, int64_t s_first, const PairMap<T>& pm, u64 (&w)[T]) {
+    if (s_first + CMP_SUB <= a.batch) {                             // uniform: all 8 rows exist, one scalar base for the loads
+        const char* base = reinterpret_cast<const char*>(a.e + s_first * a.lde);
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int64_t sample = s_first + (pm.jw[t] >> 6);
-        w[t] = a.e[(sample < a.batch ? sample : a.batch - 1) * a.lde + (pm.jw[t] & 63u)];
+        for (int t = 0; t < T; ++t) w[t] = *reinterpret_cast<const u64*>(base + pm.off[t]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int64_t sample = s_first + (pm.jw[t] >> 6);
+            w[t] = a.e[(sample < a.batch ? sample : a.batch - 1) * a.lde + (pm.jw[t] & 63u)];
+        }
     }
 }
 
@@ -132,6 +139,7 @@ __global__ __launch_bounds__(CMP_THREADS, 5) void slab_compact_kernel(CompactArg
         const bool live = nw && p < CMP_SUB * nw;
         const unsigned int j = live ? p / nw : 0u, wi = live ? wlist[p - j * nw] : 0u;
         pm.jw[t] = (j << 6) | wi;
+        pm.off[t] = (j * (unsigned int)a.lde + wi) * 8u;
         pm.mask[t] = live ? wmask[wi] : 0ull;
     }
     const unsigned int null_ent = (unsigned int)a.null_ord << 4;        // entries are LDS byte offsets inside a row-part plane
@@ -154,9 +162,14 @@ __global__ __launch_bounds__(CMP_THREADS, 5) void slab_compact_kernel(CompactArg
 #pragma unroll 1
         for (int sub = 0; sub < 64 / CMP_SUB; ++sub) {
             u64 w[T];
+            if (s0 + (sub + 1) * CMP_SUB <= a.batch) {              // uniform
 #pragma unroll
-            for (int t = 0; t < T; ++t)
-                w[t] = s0 + sub * CMP_SUB + (pm.jw[t] >> 6) < a.batch ? wn[t] & pm.mask[t] : 0ull;
+                for (int t = 0; t < T; ++t) w[t] = wn[t] & pm.mask[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < T; ++t)
+                    w[t] = s0 + sub * CMP_SUB + (pm.jw[t] >> 6) < a.batch ? wn[t] & pm.mask[t] : 0ull;
+            }
             {
                 const int64_t nxt = sub + 1 < 64 / CMP_SUB ? s0 + (sub + 1) * CMP_SUB : (tile + total_waves) * 64;
                 load_pairs<T>(a, nxt, pm, wn);
