@@ -12,6 +12,8 @@
 //   bit trick; the parity-check rows sit in SGPRs (kernel argument); the syndrome key is r AND + popcount parities; the
 //   table slot is claimed with a 64-bit atomicCAS.  A failed claim raises the collision flag and the class is swept out
 //   of the table again (its entries are the ones of popcount w).
+#include <vector>
+
 #include "gf2_internal.h"
 
 #define TBL_MAX_R 24
@@ -81,8 +83,10 @@ extern "C" int gf2_syndrome_table(gf2_ctx* ctx, const uint64_t* h_rows, int64_t 
     GF2_TRY(gf2_ctx_activate(ctx));
     TableRows rows;
     for (int i = 0; i < TBL_MAX_R; ++i) rows.row[i] = i < r ? h_rows[i] : 0ull;
-    // Pascal's triangle, saturated
-    static u64 binom_host[65 * 65];
+    // Pascal's triangle, saturated (on the heap: callers may run on several threads, and 33 KiB is a lot of stack)
+    std::vector<u64> binom_vec(65 * 65);
+    u64* const binom_host = binom_vec.data();
+    const size_t binom_bytes = binom_vec.size() * sizeof(u64);
     for (int c = 0; c <= 64; ++c)
         for (int k = 0; k <= 64; ++k) {
             u64 v;
@@ -100,13 +104,13 @@ extern "C" int gf2_syndrome_table(gf2_ctx* ctx, const uint64_t* h_rows, int64_t 
     u64 *table_dev = nullptr, *binom_dev = nullptr;
     int* collide_dev = nullptr;
     GF2_TRY(gf2_dev_alloc(ctx, entries * 8, (void**)&table_dev));
-    int rc = gf2_dev_alloc(ctx, sizeof(binom_host), (void**)&binom_dev);
+    int rc = gf2_dev_alloc(ctx, binom_bytes, (void**)&binom_dev);
     if (rc == GF2_OK) rc = gf2_dev_alloc(ctx, 4, (void**)&collide_dev);
     int64_t t = n, kept = 0;
     if (rc == GF2_OK) {
         hipLaunchKernelGGL(table_fill_kernel, dim3((unsigned)gf2_cdiv((int64_t)entries, 256)), dim3(256), 0, ctx->stream,
                            table_dev, entries);
-        if (hipMemcpyAsync(binom_dev, binom_host, sizeof(binom_host), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        if (hipMemcpyAsync(binom_dev, binom_host, binom_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
             hipMemsetAsync(collide_dev, 0, 4, ctx->stream) != hipSuccess)
             rc = GF2_E_HIP;
     }
@@ -116,12 +120,6 @@ extern "C" int gf2_syndrome_table(gf2_ctx* ctx, const uint64_t* h_rows, int64_t 
             break;
         }
         const u64 total = binom_host[n * 65 + w];
-        if (total > (1ull << 40)) {
-            gf2_set_error("gf2_syndrome_table: weight class %lld of n = %lld has more than 2^40 errors; pass max_weight",
-                          (long long)w, (long long)n);
-            rc = GF2_E_ARG;
-            break;
-        }
         bool collided = total > entries - (u64)kept;                // pigeonhole: more errors than free syndromes
         if (!collided) {
             const u64 lanes = (total + TBL_RUN - 1) / TBL_RUN;
