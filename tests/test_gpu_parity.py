@@ -945,3 +945,45 @@ def test_randomised_shapes_rref_nullspace_normalize_syndromes(ctx):
             syn = ctx.syndrome_batch(packed, m, n, e, batch)
             want_syn = c_oracle.syndrome_batch(packed, m, n, e, batch)
             assert np.array_equal(syn, want_syn), (trial, m, n, batch)
+
+
+# ---- the N > 1 product path on a GPU: two gloo ranks share the card, each runs its shard through the real kernels -----------
+
+def _sharded_gpu_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    from quantum_css_codes_amd import montecarlo
+    from quantum_css_codes_amd.css_code import CSSCode as Code
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["GF2_DEVICE"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    h = np.array([[0, 0, 0, 1, 1, 1, 1], [0, 1, 1, 0, 0, 1, 1], [1, 0, 1, 0, 1, 0, 1]])
+    code = Code(h, h)
+    res = montecarlo.run_sharded(code, 300001, 0.02, 0.01, 0.03, seed=5, first_sample=17)
+    dec = montecarlo.decode_sharded(code, 200001, 0.02, 0.01, 0.03, seed=6, first_sample=3)
+    np.savez(os.path.join(out_dir, "gpu_rank%d.npz" % rank), hist_z=res['hist_z'], hist_x=res['hist_x'],
+             shard=np.array(res['shard']), decode=np.array([dec[f] for f in montecarlo.DECODE_FIELDS]))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_monte_carlo_on_the_gpu(tmp_path, steane_h):
+    import socket
+    import torch.multiprocessing as mp
+    from quantum_css_codes_amd import montecarlo
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_sharded_gpu_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    code = CSSCode(steane_h, steane_h)
+    whole = code.monte_carlo(300001, 0.02, 0.01, 0.03, seed=5, first_sample=17)
+    whole_dec = code.logical_error_rates(200001, 0.02, 0.01, 0.03, seed=6, first_sample=3)
+    h1, h2 = c_oracle.pack_rows(code.parity_check_c1), c_oracle.pack_rows(code.parity_check_c2)
+    want_z, want_x = c_oracle.mc(h1, 3, h2, 3, 7, 5, 17, 300001, 0.02, 0.01, 0.03, 0)
+    r0, r1 = np.load(tmp_path / "gpu_rank0.npz"), np.load(tmp_path / "gpu_rank1.npz")
+    assert list(r0["shard"]) == [17, 150001] and list(r1["shard"]) == [150018, 150000]
+    for r in (r0, r1):                                        # every rank holds the global result
+        assert np.array_equal(r["hist_z"], want_z) and np.array_equal(r["hist_x"], want_x)
+        assert np.array_equal(r["hist_z"], whole['hist_z'])
+        assert list(r["decode"]) == [whole_dec[f] for f in montecarlo.DECODE_FIELDS]
