@@ -22,30 +22,60 @@ __global__ __launch_bounds__(64) void conjugate_kernel(u64* __restrict__ mat, in
     const int lane = threadIdx.x;
     const int64_t row = (int64_t)blockIdx.x * 64 + lane;
     for (int w = 0; w < words; ++w) rows_lds[w * 64 + lane] = row < k ? mat[row * ld + w] : 0ull;
-    for (int64_t g = 0; g < ngates; ++g) {
-        const int kind = gates[3 * g], a = gates[3 * g + 1], b = gates[3 * g + 2];
-        if (kind == 0) {
-            const int zq = n + a;
-            const int wx = a >> 6, bx = a & 63, wz = zq >> 6, bz = zq & 63;
-            const u64 x = rows_lds[wx * 64 + lane], z = rows_lds[wz * 64 + lane];
-            const u64 xb = (x >> bx) & 1ull, zb = (z >> bz) & 1ull;
-            if (__ballot(xb & zb)) {                                // some row carries a Y on this qubit
-                if (lane == 0) atomicMin(first_refused, (unsigned long long)g);
-                break;
-            }
-            const u64 d = xb ^ zb;
-            if (wx != wz) {
-                rows_lds[wx * 64 + lane] = x ^ (d << bx);
-                rows_lds[wz * 64 + lane] = z ^ (d << bz);
+    // Gates arrive 64 at a time through vector loads (lane l holds gate g0 + l; the next 64 are in flight meanwhile) and are
+    // handed out with readlane: scalar loads would share the LDS's wait counter and put a memory round trip into every
+    // step of what is already a chain of LDS round trips.
+    int kind_v = 1, a_v = 0, b_v = 0;
+    if (lane < ngates) {
+        kind_v = gates[3 * lane];
+        a_v = gates[3 * lane + 1];
+        b_v = gates[3 * lane + 2];
+    }
+    bool refused = false;
+    for (int64_t g0 = 0; g0 < ngates && !refused; g0 += 64) {
+        const int kind_c = kind_v, a_c = a_v, b_c = b_v;
+        if (g0 + 64 + lane < ngates) {
+            kind_v = gates[3 * (g0 + 64 + lane)];
+            a_v = gates[3 * (g0 + 64 + lane) + 1];
+            b_v = gates[3 * (g0 + 64 + lane) + 2];
+        }
+        const int cnt = ngates - g0 < 64 ? (int)(ngates - g0) : 64;
+        for (int i = 0; i < cnt; ++i) {
+            const int kind = __builtin_amdgcn_readlane(kind_c, i), a = __builtin_amdgcn_readlane(a_c, i),
+                      b = __builtin_amdgcn_readlane(b_c, i);
+            if (kind == 0) {
+                const int zq = n + a;
+                const int wx = a >> 6, bx = a & 63, wz = zq >> 6, bz = zq & 63;
+                const u64 x = rows_lds[wx * 64 + lane], z = rows_lds[wz * 64 + lane];
+                const u64 xb = (x >> bx) & 1ull, zb = (z >> bz) & 1ull;
+                if (__ballot(xb & zb)) {                            // some row carries a Y on this qubit
+                    if (lane == 0) atomicMin(first_refused, (unsigned long long)(g0 + i));
+                    refused = true;
+                    break;
+                }
+                const u64 d = xb ^ zb;
+                if (wx != wz) {
+                    rows_lds[wx * 64 + lane] = x ^ (d << bx);
+                    rows_lds[wz * 64 + lane] = z ^ (d << bz);
+                } else {
+                    rows_lds[wx * 64 + lane] = x ^ (d << bx) ^ (d << bz);
+                }
             } else {
-                rows_lds[wx * 64 + lane] = x ^ (d << bx) ^ (d << bz);
+                const int zc = n + a, zt = n + b;
+                const int w_xc = a >> 6, w_xt = b >> 6, w_zt = zt >> 6, w_zc = zc >> 6;
+                if (w_xt != w_zt && w_xt != w_zc && w_xc != w_zc) {
+                    // the X and the Z update touch different words: all four reads go out together
+                    const u64 xc = rows_lds[w_xc * 64 + lane], xt = rows_lds[w_xt * 64 + lane];
+                    const u64 ztw = rows_lds[w_zt * 64 + lane], zcw = rows_lds[w_zc * 64 + lane];
+                    rows_lds[w_xt * 64 + lane] = xt ^ (((xc >> (a & 63)) & 1ull) << (b & 63));     // X: control -> target
+                    rows_lds[w_zc * 64 + lane] = zcw ^ (((ztw >> (zt & 63)) & 1ull) << (zc & 63));  // Z: target -> control
+                } else {
+                    const u64 xc = (rows_lds[w_xc * 64 + lane] >> (a & 63)) & 1ull;
+                    rows_lds[w_xt * 64 + lane] ^= xc << (b & 63);
+                    const u64 ztb = (rows_lds[w_zt * 64 + lane] >> (zt & 63)) & 1ull;
+                    rows_lds[w_zc * 64 + lane] ^= ztb << (zc & 63);
+                }
             }
-        } else {
-            const int zc = n + a, zt = n + b;
-            const u64 xc = (rows_lds[(a >> 6) * 64 + lane] >> (a & 63)) & 1ull;      // X: control -> target
-            rows_lds[(b >> 6) * 64 + lane] ^= xc << (b & 63);
-            const u64 ztb = (rows_lds[(zt >> 6) * 64 + lane] >> (zt & 63)) & 1ull;   // Z: target -> control
-            rows_lds[(zc >> 6) * 64 + lane] ^= ztb << (zc & 63);
         }
     }
     if (row < k)
