@@ -4,8 +4,9 @@
 // entry of q in every row (and refuses a row that has both: css_code.py:762-763), CNOT(c, t) adds X_c into X_t and Z_t
 // into Z_c in every row (css_code.py:775-781).  Gates depend on each other, rows do not.  So: lane = row, a wavefront
 // owns 64 rows for the whole gate list and keeps them in LDS as [word][row] (consecutive lanes on consecutive banks,
-// every access conflict-free, 64 KiB at n = 4096); the gate stream is wave-uniform (scalar loads), each gate is two to
-// four LDS word accesses and a few bit operations.  One block per 64 rows; nothing else is shared.
+// every access conflict-free, 64 KiB at n = 4096); the gate stream is wave-uniform (64 gates per vector load, handed out
+// with readlane), each gate is two to four LDS word accesses and a few bit operations.  One block per 64 rows; nothing
+// else is shared.
 //
 // A gate the reference would refuse ends the walk: the lowest such gate index over all blocks is reported, and the
 // host reruns the accepted prefix so that the matrix it hands back is the state the reference leaves behind before
