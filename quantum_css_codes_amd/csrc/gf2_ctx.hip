@@ -204,7 +204,13 @@ int gf2_pack_rows_i64(const int64_t* src, int64_t m, int64_t n, int64_t src_stri
     for (int64_t i = 0; i < m; ++i) {                                                        \
         const uint64_t* row = src + i * ld;                                                  \
         T* out = dst + i * dst_stride;                                                       \
-        for (int64_t j = 0; j < n; ++j) out[j] = (T)((row[j >> 6] >> (j & 63)) & 1);         \
+        const int64_t full = n >> 6;                                                         \
+        for (int64_t w = 0; w < full; ++w) {                  /* whole words: a fixed-length loop the compiler vectorises */ \
+            const uint64_t v = row[w];                                                       \
+            T* o = out + w * 64;                                                             \
+            for (int b = 0; b < 64; ++b) o[b] = (T)((v >> b) & 1);                           \
+        }                                                                                    \
+        for (int64_t j = full * 64; j < n; ++j) out[j] = (T)((row[j >> 6] >> (j & 63)) & 1); \
     }                                                                                        \
     return GF2_OK;
 

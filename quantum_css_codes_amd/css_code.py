@@ -395,7 +395,7 @@ def transform_stabilisers(mat, prog):
     gates = _gate_array(prog)
     packed = _native.pack_rows(mat)
     rc, stop = _native.default_context().conjugate_gates(packed, k, n, gates)
-    mat[...] = _native.unpack_rows(packed, cols, dtype=mat.dtype)
+    _native.unpack_rows_into(packed, mat)
     if rc == _native.GF2_E_NOTCSS:
         q = int(gates[stop, 1])
         bad = int(np.flatnonzero((mat[:, q] == 1) & (mat[:, n + q] == 1))[0])
@@ -489,8 +489,8 @@ def normalize_parity_check(h, offset):
         if err.code == _native.GF2_E_COLUMNS:
             raise ValueError("not enough columns") from None
         raise
-    h[...] = _native.unpack_rows(packed, n, dtype=h.dtype)
-    return np.mod(h, 2), swaps
+    _native.unpack_rows_into(packed, h)                       # h is reduced from here on, so np.mod(h, 2) is a plain copy
+    return h.copy(), swaps
 
 
 def codes_equal(parity_check_1, parity_check_2):
