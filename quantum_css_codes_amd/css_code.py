@@ -328,7 +328,10 @@ def syndrome_table(parity_check, max_weight=None):
                 layer_seen = np.union1d(layer_seen, keys)
                 layer_keys.extend(int(k) for k in keys)
             else:
-                keys = [bin_matrix.vec_to_int(row) for row in syn]
+                # bin_matrix.vec_to_int of every row (bits, row 0 most significant), as exact Python ints
+                big = np.packbits(syn, axis=1, bitorder='big')
+                shift = (-r) % 8
+                keys = [int.from_bytes(row.tobytes(), 'big') >> shift for row in big]
                 fresh = set(keys)
                 if len(fresh) != count or any(k in table for k in keys) or not fresh.isdisjoint(layer_seen_big):
                     return w - 1, table
@@ -336,8 +339,7 @@ def syndrome_table(parity_check, max_weight=None):
                 layer_keys.extend(keys)
             layer_errs.append(errors)
         errs = np.concatenate(layer_errs) if layer_errs else np.zeros((0, n), dtype=np.uint8)
-        for key, err in zip(layer_keys, errs):
-            table[key] = err.astype('int')
+        table.update(zip(layer_keys, errs.astype('int')))
         if weights is not None:
             seen = np.union1d(seen, layer_seen)
     return n, table
