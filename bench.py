@@ -389,7 +389,7 @@ def main():
             "roofline": roofline(path, syn_ms / 1e3 / max(1, syn_n), syn_n),
             "kernel_ms": {"syndrome": syn_ms, "histogram": hist_ms, "stream_total": gpu_ms},
         }
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:               # timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(code)
         if world == 1 and not args.no_secondary:
             single_z = (hist_z // np.uint64(args.steps)).astype(np.uint64)      # same batch every step
