@@ -94,9 +94,12 @@ def cpu_baseline(code, seconds_target=20.0, sample=2048):
 class Path(object):
     """Resident buffers and the step function of one implementation of the hot path."""
 
-    def __init__(self, ctx, algo, chk1, chk2, batch, first):
+    def __init__(self, ctx, algo, chk1, chk2, batch, first, ctx2=None):
         from quantum_css_codes_amd import _native
         self.ctx, self.algo, self.batch = ctx, algo, batch
+        # second context = second HIP stream (own workspace): the sparse path issues H1.e_z on ctx and H2.e_x on ctx2, so
+        # that the two slab pipelines, which stress HBM and the SIMDs at different moments, overlap; None: one stream
+        self.ctx2 = ctx2 if (ctx2 is not None and algo == "sparse") else None
         self.ls1, self.ls2 = _native.words_for(R1), _native.words_for(R2)
         self.hz, self.hx = ctx.alloc((R1 + 1) * 8), ctx.alloc((R2 + 1) * 8)
         p = P_TOTAL / 3
@@ -107,10 +110,11 @@ class Path(object):
             ctx.sample_errors_dev(N_QUBITS, SEED, first, batch, p, p, p, self.ex, self.ez, lde)
             self.kernel = "slab_pipeline"                                # compact + gather + combine, gf2_slabs.hip
             self.alg_bytes_per_sample = N_QUBITS / 8.0                   # SURVEY.md 8d read-only variant, per component
+            side = self.ctx2 if self.ctx2 is not None else ctx
 
             def step():
                 ctx.syndrome_sparse_dev(chk1, self.ez, batch, lde, None, 0, self.hz, R1 + 1)
-                ctx.syndrome_sparse_dev(chk2, self.ex, batch, lde, None, 0, self.hx, R2 + 1)
+                side.syndrome_sparse_dev(chk2, self.ex, batch, lde, None, 0, self.hx, R2 + 1)
 
             def prefix_hist(count):
                 a, b = ctx.alloc((R1 + 1) * 8).zero(), ctx.alloc((R2 + 1) * 8).zero()
@@ -151,13 +155,22 @@ class Path(object):
         self.step, self.prefix = step, prefix
         ctx.sync()
 
+    def sync(self):
+        self.ctx.sync()
+        if self.ctx2 is not None:
+            self.ctx2.sync()
+
+    def contexts(self):
+        return [self.ctx] + ([self.ctx2] if self.ctx2 is not None else [])
+
     def check_against_oracle(self, h1, h2, first):
         """A prefix of the resident batch through this path against the C oracle."""
         from oracle import c_oracle
         p = P_TOTAL / 3
         self.hz.zero(), self.hx.zero()
-        self.step()
         self.ctx.sync()
+        self.step()
+        self.sync()
         want_z, want_x = c_oracle.mc(h1, R1, h2, R2, N_QUBITS, SEED, first, 512, p, p, p, 1)
         got1, got2 = self.prefix(512)
         assert np.array_equal(c_oracle.histogram(got1, 512, R1, 1, R1 + 1), want_z), "H1.e_z differs from the oracle"
@@ -184,18 +197,24 @@ def timed(ctx, path, steps, warmup):
     from quantum_css_codes_amd import _native
     for _ in range(warmup):
         path.step()
-    ctx.sync()
+    path.sync()
     path.hz.zero(), path.hx.zero()
-    ctx.sync()
-    ctx.profile(True)
-    ctx.profile_reset()
+    path.sync()
+    for c in path.contexts():
+        c.profile(True)
+        c.profile_reset()
     ctx.timer_start()
     for _ in range(steps):
         path.step()
+    if path.ctx2 is not None:
+        path.ctx2.sync()                                     # the side stream's work ends inside the timed interval
     gpu_ms = ctx.timer_stop()
-    syn_ms, syn_n = ctx.profile_get(_native.K_SYNDROME)
-    hist_ms, _ = ctx.profile_get(_native.K_HIST)
-    ctx.profile(False)
+    syn_ms, syn_n, hist_ms = 0.0, 0, 0.0
+    for c in path.contexts():
+        ms, cnt = c.profile_get(_native.K_SYNDROME)
+        syn_ms, syn_n = syn_ms + ms, syn_n + cnt
+        hist_ms += c.profile_get(_native.K_HIST)[0]
+        c.profile(False)
     return gpu_ms, syn_ms / 1e3 / max(1, syn_n), syn_n, hist_ms
 
 
@@ -209,6 +228,23 @@ def roofline(path, mean_launch_s, launches):
     return {"bound": "hbm", "kernel": path.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
             "mean_launch_ms": mean_launch_s * 1e3, "launches": launches}
+
+
+def roofline_of_steps(path, gpu_s, steps, per_call_s, calls):
+    """Two-stream steps: the two components' pipelines overlap, so the duration that means something is a step's (HIP
+    events on the main stream around the timed region, the side stream joined before the stop event).  A "launch" is one
+    step = both components; the per-call durations on each stream (overlapped, hence longer than alone) are kept beside it."""
+    alg_bytes = 2 * path.batch * path.alg_bytes_per_sample
+    achieved = alg_bytes / (gpu_s / steps) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and path.batch == 1 << 20:
+        one = json.load(open(tpath)).get(path.kernel + "_bytes_per_launch")
+        traffic = 2 * one if one else None
+    return {"bound": "hbm", "kernel": path.kernel + " x2: H1.e_z and H2.e_x on two HIP streams, one launch = one step",
+            "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": gpu_s / steps * 1e3, "launches": steps,
+            "mean_call_ms_on_its_stream": per_call_s * 1e3, "calls": calls}
 
 
 def rref_numbers(ctx):
@@ -308,6 +344,8 @@ def main():
                     help="gloo lets several ranks share one GPU to rehearse the multi-process path (histograms are "
                          "then all-reduced on the host); the driver's runs use nccl = RCCL")
     ap.add_argument("--algo", choices=("sparse", "dense"), default="sparse")
+    ap.add_argument("--one-stream", action="store_true",
+                    help="issue both components of a step on one HIP stream (default: H2.e_x goes to a second context)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -336,12 +374,13 @@ def main():
     batch = 1 << args.batch_log2
     first = rank * batch               # this rank's shard of the global sample stream: sample i = f(seed, i)
 
-    path = Path(ctx, args.algo, chk1, chk2, batch, first)
+    ctx2 = None if args.one_stream else _native.Context(ctx.device)
+    path = Path(ctx, args.algo, chk1, chk2, batch, first, ctx2)
     if rank == 0:
         path.check_against_oracle(h1, h2, first)        # correctness of what is about to be timed
 
     def fence():
-        ctx.sync()
+        path.sync()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -351,14 +390,18 @@ def main():
     if world > 1:
         # the first collective sets up the communicator: keep that out of the timed region
         all_reduce_histograms([path.hz.download((R1 + 1,), np.uint64), path.hx.download((R2 + 1,), np.uint64)])
+    path.sync()
     path.hz.zero(), path.hx.zero()
-    ctx.profile(True)
-    ctx.profile_reset()
+    for c in path.contexts():
+        c.profile(True)
+        c.profile_reset()
     fence()
     t0 = time.perf_counter()
     ctx.timer_start()
     for _ in range(args.steps):
         path.step()
+    if path.ctx2 is not None:
+        path.ctx2.sync()                                 # the side stream's work ends inside the timed interval
     gpu_ms = ctx.timer_stop()
     hist_z = path.hz.download((R1 + 1,), np.uint64)
     hist_x = path.hx.download((R2 + 1,), np.uint64)
@@ -372,9 +415,12 @@ def main():
         elapsed = float(t.item())
     total = world * args.steps * batch
     assert int(hist_z.sum()) == total and int(hist_x.sum()) == total
-    syn_ms, syn_n = ctx.profile_get(_native.K_SYNDROME)
-    hist_ms, _ = ctx.profile_get(_native.K_HIST)
-    ctx.profile(False)
+    syn_ms, syn_n, hist_ms = 0.0, 0, 0.0
+    for c in path.contexts():
+        ms, cnt = c.profile_get(_native.K_SYNDROME)
+        syn_ms, syn_n = syn_ms + ms, syn_n + cnt
+        hist_ms += c.profile_get(_native.K_HIST)[0]
+        c.profile(False)
 
     if rank == 0:
         out = {
@@ -385,27 +431,37 @@ def main():
             "config": {"workload": "configs[4]: n=4096 CSS Monte-Carlo, random dual code (H1 2048x4096, H2 2047x4096, "
                                    "standard form), depolarising p=0.01, errors resident in HBM",
                        "algo": args.algo, "samples_per_gpu_per_step": batch, "global_samples_per_step": batch * world,
+                       "streams": 2 if path.ctx2 is not None else 1,
                        "parallelism": "sample-range shards, 1 histogram all-reduce"},
-            "roofline": roofline(path, syn_ms / 1e3 / max(1, syn_n), syn_n),
+            "roofline": (roofline_of_steps(path, gpu_ms / 1e3, args.steps, syn_ms / 1e3 / max(1, syn_n), syn_n)
+                         if path.ctx2 is not None else roofline(path, syn_ms / 1e3 / max(1, syn_n), syn_n)),
             "kernel_ms": {"syndrome": syn_ms, "histogram": hist_ms, "stream_total": gpu_ms},
         }
         if world == 1 and not args.no_cpu_baseline:               # timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(code)
         if world == 1 and not args.no_secondary:
             single_z = (hist_z // np.uint64(args.steps)).astype(np.uint64)      # same batch every step
-            gather = None
+            gather, single = None, None
             if args.algo == "sparse":
-                # the same resident errors through the wavefront-per-sample column-gather kernel (gf2_sparse.hip)
+                # the same resident errors with both components on ONE stream: the slab pipeline by itself (per-call
+                # roofline), then the wavefront-per-sample column-gather kernel (gf2_sparse.hip)
+                plain = Path(ctx, "sparse", chk1, chk2, batch, first)
+                s_ms, s_launch, s_n, _ = timed(ctx, plain, 50, 5)
+                assert np.array_equal(plain.hz.download((R1 + 1,), np.uint64), single_z * np.uint64(50)), \
+                    "one-stream and two-stream steps disagree"
+                single = {"value": 50 * batch / (s_ms / 1e3), "unit": "syndromes/s", "ms_per_step": s_ms / 50,
+                          "roofline": roofline(plain, s_launch, s_n)}
                 os.environ["GF2_SPARSE_GATHER"] = "1"
                 try:
-                    g_ms, g_launch, g_n, _ = timed(ctx, path, 10, 2)
-                    assert np.array_equal(path.hz.download((R1 + 1,), np.uint64), single_z * np.uint64(10)), \
+                    g_ms, g_launch, g_n, _ = timed(ctx, plain, 10, 2)
+                    assert np.array_equal(plain.hz.download((R1 + 1,), np.uint64), single_z * np.uint64(10)), \
                         "column-gather kernel and slab pipeline disagree"
                 finally:
                     del os.environ["GF2_SPARSE_GATHER"]
-                path.kernel = "syndrome_sparse_kernel"
+                plain.kernel = "syndrome_sparse_kernel"
                 gather = {"value": 10 * batch / (g_ms / 1e3), "unit": "syndromes/s", "ms_per_step": g_ms / 10,
-                          "roofline": roofline(path, g_launch, g_n)}
+                          "roofline": roofline(plain, g_launch, g_n)}
+                plain.free()
             path.free()
             other = Path(ctx, "dense" if args.algo == "sparse" else "sparse", chk1, chk2, batch, first)
             other.check_against_oracle(h1, h2, first)
@@ -429,6 +485,8 @@ def main():
                 "rref": rref_numbers(ctx)}
             if gather is not None:
                 out["secondary"]["column_gather_kernel"] = gather
+            if single is not None:
+                out["secondary"]["one_stream"] = single
             out["secondary"]["small_codes"] = small_code_numbers(ctx)
             other.free()
         print(json.dumps(out))
