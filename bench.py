@@ -15,19 +15,23 @@ larger than the 256 MiB Infinity Cache, so every step streams from HBM).
 
 One step = one pass of the hot path over that batch: s_z = H1 . e_z and s_x = H2 . e_x for every sample and
 the two syndrome-weight histograms.  Two implementations, same results bit for bit:
-  --algo sparse (default)  one wavefront per sample XORs the transposed check's column for every set error
-                           bit; the weight histogram is fused, no syndromes are written.  Work ~ error weight
-                           (about 27 set bits per component at p = 0.01).
+  --algo sparse (default)  LDS-slab pipeline (gf2_slabs.hip): the samples' set bits are compacted into column
+                           records, every CU keeps one 512-row slab of the transposed check in LDS and XORs the
+                           listed columns, partial weights are combined into the histogram; no syndromes are
+                           written.  Work ~ error weight (about 27 set bits per component at p = 0.01).  The two
+                           components of a step go to two contexts = two HIP streams (--one-stream: one).
   --algo dense             Four-Russians table kernel on tiled errors, slab-major syndromes written, then the
                            histogram kernel.  Data-independent.
 Per-GPU work is fixed as N grows ("weak"); ranks never exchange data on the path; the histograms are summed
 once with one all-reduce (RCCL) inside the timed region.  value = N * K * batch / max-over-ranks time.
 
 The JSON line also carries
-  roofline      the dominant kernel against the HBM roofline: algorithmic bytes per launch (SURVEY.md 8d:
-                n/8 read [+ r/8 written when syndromes are stored] per sample and component) / its mean launch
-                time, measured live with HIP events on the kernel's stream; traffic = PMC HBM bytes per launch
-                from the committed rocprofv3 passes (profiles/traffic.json).
+  roofline      the path against the HBM roofline: algorithmic bytes per launch (n/8 read [+ r/8
+                written when syndromes are stored] per sample and component) / mean launch time, measured live
+                with HIP events; traffic = PMC HBM bytes per launch from the committed rocprofv3 passes
+                (profiles/traffic.json).  With two streams a launch is one step (both components; events on the
+                main stream around the timed region, the side stream joined before the stop event); with one
+                stream it is one library call, timed on the context's stream (secondary.one_stream).
   cpu_baseline  the reference's NumPy path (oracle/cpu_ref.py restatement of css_code.py:728) timed on this
                 host, 1 core, on a bounded sample of the same workload.
   secondary     (rank 0, N = 1) the end-to-end Monte-Carlo (sampler included), the other syndrome kernels (column gather,
