@@ -50,6 +50,8 @@ int gf2_ctx_create(int device, gf2_ctx** ctx_out) {
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
     GF2_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) GF2_HIP(hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
+    for (int k = 0; k < 7; ++k) GF2_HIP(hipEventCreateWithFlags(&ctx->side_ev[k], hipEventDisableTiming));
     GF2_HIP(hipEventCreate(&ctx->t0));
     GF2_HIP(hipEventCreate(&ctx->t1));
     for (int i = 0; i < gf2_ctx::kProfSlots; ++i) {
@@ -64,7 +66,8 @@ int gf2_ctx_destroy(gf2_ctx* ctx) {
     if (!ctx) return GF2_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (int k = 0; k < 3; ++k)
+    for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(ctx->side[k]);
+    for (int k = 0; k < 4; ++k)
         if (ctx->ws[k]) (void)hipFree(ctx->ws[k]);
     for (int i = 0; i < gf2_ctx::kProfSlots; ++i) {
         (void)hipEventDestroy(ctx->prof_ev[i][0]);
@@ -72,6 +75,8 @@ int gf2_ctx_destroy(gf2_ctx* ctx) {
     }
     (void)hipEventDestroy(ctx->t0);
     (void)hipEventDestroy(ctx->t1);
+    for (int k = 0; k < 7; ++k) (void)hipEventDestroy(ctx->side_ev[k]);
+    for (int k = 0; k < 2; ++k) (void)hipStreamDestroy(ctx->side[k]);
     (void)hipStreamDestroy(ctx->stream);
     free(ctx);
     return GF2_OK;
@@ -234,6 +239,7 @@ int gf2_ctx_activate(gf2_ctx* ctx) {
 int gf2_ws_reserve(gf2_ctx* ctx, int slot, size_t bytes) {
     if (ctx->ws_bytes[slot] >= bytes) return GF2_OK;
     GF2_HIP(hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 2; ++k) GF2_HIP(hipStreamSynchronize(ctx->side[k]));
     if (ctx->ws[slot]) GF2_HIP(hipFree(ctx->ws[slot]));
     ctx->ws[slot] = nullptr;
     ctx->ws_bytes[slot] = 0;

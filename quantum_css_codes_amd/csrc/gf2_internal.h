@@ -41,6 +41,8 @@ struct gf2_ctx {
     int device;
     int num_cus;
     hipStream_t stream;
+    hipStream_t side[2];          // side streams of the pipelined Monte-Carlo (gf2_mc_run): one per Pauli component
+    hipEvent_t side_ev[7];        // sampled[2], done_z[2], done_x[2], start
     hipEvent_t t0, t1;            // gf2_timer_*
     // per-kernel-family profiling: ring of event pairs resolved lazily
     int profile_on;
@@ -51,9 +53,9 @@ struct gf2_ctx {
     int prof_family[kProfSlots];
     int prof_used;
     // workspaces grown on demand: slot 0 = Monte-Carlo pipeline, slot 1 = re-tiling of sample-major errors,
-    // slot 2 = records and partial weights of the LDS-slab sparse pipeline
-    void* ws[3];
-    size_t ws_bytes[3];
+    // slot 2 = records and partial weights of the LDS-slab sparse pipeline, slot 3 = the same for the second side stream
+    void* ws[4];
+    size_t ws_bytes[4];
     // large dynamic-LDS opt-in (hipFuncSetAttribute) done for this context's device: [0] syndrome_tiled_kernel,
     // [1] rref_update_kernel, [2] slab_gather_kernel, [3] conjugate_kernel
     bool lds_optin[4];
@@ -98,8 +100,10 @@ struct gf2_check {
 int gf2_build_columns(gf2_ctx* ctx, gf2_check* ck);
 int gf2_build_slab_table(gf2_ctx* ctx, gf2_check* ck);
 bool gf2_slabs_ok(const gf2_check* ck);
+// stream: the context's stream or one of its side streams; ws_slot: 2 or 3 (one per stream that may run concurrently)
 int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde,
-                       uint64_t* hist_dev);
+                       uint64_t* hist_dev, hipStream_t stream, int ws_slot);
+int gf2_slabs_reserve(gf2_ctx* ctx, const gf2_check* ck, int64_t batch, int ws_slot);
 bool gf2_mc_sparse_fused_ok(const gf2_check* c1, const gf2_check* c2);
 int gf2_mc_sparse_fused(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t seed, int64_t first_sample,
                         int64_t count, double p_x, double p_y, double p_z, uint64_t* hz_dev, uint64_t* hx_dev);

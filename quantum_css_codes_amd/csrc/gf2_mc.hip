@@ -202,6 +202,57 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
     // Sparse-error pipeline: when few bits are set per error the column kernel wins: sampler writes
     // sample-major errors, the sparse kernel accumulates the weight histograms directly, no syndromes stored.
     const double dens = (p_x + p_y > p_z + p_y ? p_x + p_y : p_z + p_y) * (double)n;
+    if (mode == GF2_HIST_WEIGHT && dens <= 160.0 && gf2_slabs_ok(c1) && gf2_slabs_ok(c2) && getenv("GF2_MC_DENSE") == nullptr &&
+        getenv("GF2_MC_UNFUSED") == nullptr && getenv("GF2_MC_FUSED") == nullptr && count >= 65536) {
+        // Three streams: the sampler draws chunk k + 1 on the context's stream while the LDS-slab pipelines of the two
+        // components work on chunk k on the two side streams (double-buffered errors; events carry the hand-overs).
+        const int64_t lde_s = gf2_words(n);
+        const int64_t chunk_s = 1ll << 20;
+        auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t eb = (size_t)chunk_s * lde_s * 8, hzb = (size_t)nbins_z * 8, hxb = (size_t)nbins_x * 8;
+        GF2_TRY(gf2_ws_reserve(ctx, 0, 4 * al(eb) + al(hzb) + al(hxb)));
+        GF2_TRY(gf2_slabs_reserve(ctx, c1, chunk_s, 2));
+        GF2_TRY(gf2_slabs_reserve(ctx, c2, chunk_s, 3));
+        char* q = (char*)ctx->ws[0];
+        uint64_t* sx[2];
+        uint64_t* sz[2];
+        for (int b = 0; b < 2; ++b) {
+            sx[b] = (uint64_t*)q; q += al(eb);
+            sz[b] = (uint64_t*)q; q += al(eb);
+        }
+        uint64_t* dz = (uint64_t*)q; q += al(hzb);
+        uint64_t* dx = (uint64_t*)q;
+        hipEvent_t* sampled = ctx->side_ev;            // [2]
+        hipEvent_t* done_z = ctx->side_ev + 2;         // [2]
+        hipEvent_t* done_x = ctx->side_ev + 4;         // [2]
+        GF2_TRY(gf2_dev_zero(ctx, dz, hzb));
+        GF2_TRY(gf2_dev_zero(ctx, dx, hxb));
+        int64_t k = 0;
+        for (int64_t done = 0; done < count; done += chunk_s, ++k) {
+            const int64_t now = count - done < chunk_s ? count - done : chunk_s;
+            const int b = (int)(k & 1);
+            if (k >= 2) {                                          // the pipelines of chunk k - 2 are done with these buffers
+                GF2_HIP(hipStreamWaitEvent(ctx->stream, done_z[b], 0));
+                GF2_HIP(hipStreamWaitEvent(ctx->stream, done_x[b], 0));
+            }
+            GF2_TRY(gf2_sample_errors_dev(ctx, n, seed, first_sample + done, now, p_x, p_y, p_z, sx[b], sz[b], lde_s,
+                                          GF2_LAYOUT_SAMPLE_MAJOR));
+            GF2_HIP(hipEventRecord(sampled[b], ctx->stream));
+            GF2_HIP(hipStreamWaitEvent(ctx->side[0], sampled[b], 0));
+            GF2_HIP(hipStreamWaitEvent(ctx->side[1], sampled[b], 0));
+            GF2_TRY(gf2_syndrome_slabs(ctx, c1, sz[b], now, lde_s, dz, ctx->side[0], 2));
+            GF2_TRY(gf2_syndrome_slabs(ctx, c2, sx[b], now, lde_s, dx, ctx->side[1], 3));
+            GF2_HIP(hipEventRecord(done_z[b], ctx->side[0]));
+            GF2_HIP(hipEventRecord(done_x[b], ctx->side[1]));
+        }
+        for (int b = 0; b < 2 && b < k; ++b) {                     // join: the histograms are read on the context's stream
+            GF2_HIP(hipStreamWaitEvent(ctx->stream, done_z[b], 0));
+            GF2_HIP(hipStreamWaitEvent(ctx->stream, done_x[b], 0));
+        }
+        GF2_TRY(gf2_d2h(ctx, hist_z, dz, hzb));
+        GF2_TRY(gf2_d2h(ctx, hist_x, dx, hxb));
+        return GF2_OK;
+    }
     if (mode == GF2_HIST_WEIGHT && dens <= 160.0 && gf2_mc_sparse_fused_ok(c1, c2) && getenv("GF2_MC_DENSE") == nullptr &&
         getenv("GF2_MC_UNFUSED") == nullptr) {
         // one kernel: every lane draws its own error words, nothing but the histograms touches memory

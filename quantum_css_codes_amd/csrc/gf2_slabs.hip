@@ -549,7 +549,7 @@ bool gf2_slabs_ok(const gf2_check* ck) { return ck->slab_tab_dev != nullptr; }
 
 // Weight histogram of batch resident sample-major errors (hist: r + 1 bins, accumulated into).
 int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde,
-                       uint64_t* hist_dev) {
+                       uint64_t* hist_dev, hipStream_t stream, int ws_slot) {
     const int nbins = (int)ck->r + 1;
     const size_t lds_bytes = (size_t)ck->slab_cols * 64;
     if (!ctx->lds_optin[2]) {
@@ -560,9 +560,9 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
     const int64_t pass = batch < SLAB_MAX_BATCH ? batch : SLAB_MAX_BATCH;
     const int64_t pad = gf2_cdiv(pass, 64) * 64;
     const size_t rec_bytes = (size_t)pad * 64, pw_bytes = (size_t)ck->nslabs512 * pad * 2;
-    GF2_TRY(gf2_ws_reserve(ctx, 2, rec_bytes + pw_bytes));
-    u32x4* rec = (u32x4*)ctx->ws[2];
-    unsigned short* pw = (unsigned short*)((char*)ctx->ws[2] + rec_bytes);
+    GF2_TRY(gf2_ws_reserve(ctx, ws_slot, rec_bytes + pw_bytes));
+    u32x4* rec = (u32x4*)ctx->ws[ws_slot];
+    unsigned short* pw = (unsigned short*)((char*)ctx->ws[ws_slot] + rec_bytes);
     for (int64_t first = 0; first < batch; first += pass) {
         const int64_t count = batch - first < pass ? batch - first : pass;
         const uint64_t* e = e_dev + first * lde;
@@ -590,13 +590,13 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
             const int rounds = (CMP_SUB * nw + 63) / 64;
             const dim3 cgrid((unsigned)cblocks), cblock(CMP_THREADS);
             if (rounds <= 4)
-                hipLaunchKernelGGL(slab_compact_kernel<4>, cgrid, cblock, 0, ctx->stream, ca);
+                hipLaunchKernelGGL(slab_compact_kernel<4>, cgrid, cblock, 0, stream, ca);
             else if (rounds <= 5)
-                hipLaunchKernelGGL(slab_compact_kernel<5>, cgrid, cblock, 0, ctx->stream, ca);
+                hipLaunchKernelGGL(slab_compact_kernel<5>, cgrid, cblock, 0, stream, ca);
             else if (rounds <= 6)
-                hipLaunchKernelGGL(slab_compact_kernel<6>, cgrid, cblock, 0, ctx->stream, ca);
+                hipLaunchKernelGGL(slab_compact_kernel<6>, cgrid, cblock, 0, stream, ca);
             else
-                hipLaunchKernelGGL(slab_compact_kernel<8>, cgrid, cblock, 0, ctx->stream, ca);
+                hipLaunchKernelGGL(slab_compact_kernel<8>, cgrid, cblock, 0, stream, ca);
         }
         GF2_HIP(hipGetLastError());
 
@@ -618,14 +618,22 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
         if (shares > max_shares) shares = max_shares;
         if (shares < 1) shares = 1;
         hipLaunchKernelGGL(slab_gather_kernel, dim3((unsigned)(shares * ck->nslabs512)), dim3(GAT_THREADS), lds_bytes,
-                           ctx->stream, ga);
+                           stream, ga);
         GF2_HIP(hipGetLastError());
 
         int64_t mblocks = gf2_cdiv(count, 1024);
         if (mblocks > (int64_t)ctx->num_cus) mblocks = ctx->num_cus;
-        hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3(256), 0, ctx->stream, pw, gf2_cdiv(count, 64) * 64, pad,
+        hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3(256), 0, stream, pw, gf2_cdiv(count, 64) * 64, pad,
                            ck->nslabs512, (u64*)hist_dev, nbins);
         GF2_HIP(hipGetLastError());
     }
     return GF2_OK;
+}
+
+// Grows the workspace of `ws_slot` for batches of this size now (growing synchronises the streams), so that a later
+// gf2_syndrome_slabs on a side stream does not.
+int gf2_slabs_reserve(gf2_ctx* ctx, const gf2_check* ck, int64_t batch, int ws_slot) {
+    const int64_t pass = batch < SLAB_MAX_BATCH ? batch : SLAB_MAX_BATCH;
+    const int64_t pad = gf2_cdiv(pass, 64) * 64;
+    return gf2_ws_reserve(ctx, ws_slot, (size_t)pad * 64 + (size_t)ck->nslabs512 * pad * 2);
 }

@@ -331,7 +331,7 @@ int gf2_syndrome_sparse_dev(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e
     // loads; GF2_SPARSE_SLABS / GF2_SPARSE_GATHER force one or the other (same results)
     if (!s_dev && gf2_slabs_ok(ck) && getenv("GF2_SPARSE_GATHER") == nullptr &&
         (batch >= 32768 || getenv("GF2_SPARSE_SLABS") != nullptr))
-        GF2_TRY(gf2_syndrome_slabs(ctx, ck, e_dev, batch, lde, hist_dev));
+        GF2_TRY(gf2_syndrome_slabs(ctx, ck, e_dev, batch, lde, hist_dev, ctx->stream, 2));
     else if (s_dev && hist_dev)
         launch_sparse<true, true>(ctx, ck, e_dev, batch, lde, (uint32_t*)s_dev, lds * 2, (u64*)hist_dev, (int)nbins);
     else if (s_dev)

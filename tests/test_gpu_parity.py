@@ -480,6 +480,21 @@ def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, monkeypatch):
     want = c_oracle.mc(h1, 2048, h2, 2047, 4096, 0xABC, 5 * 10**6, 20000, 0.004, 0.003, 0.002, 1)
     for got in (fused, sparse, dense):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # large counts: the sampler of chunk k + 1 overlaps the two components' slab pipelines of chunk k on three streams
+    # (two and a bit chunks of 2^20, so the double buffers are reused); same histograms as the fused kernel and, on its
+    # own pace, the serial sampler -> pipeline -> pipeline path; twice, to see that nothing is left behind on a stream
+    big = (0xABC, 123, (1 << 21) + 77777, 0.004, 0.003, 0.002, _native.HIST_WEIGHT)
+    piped = ctx.mc_run(c1, c2, *big)
+    piped_again = ctx.mc_run(c1, c2, *big)
+    monkeypatch.setenv("GF2_MC_FUSED", "1")
+    fused_big = ctx.mc_run(c1, c2, *big)
+    monkeypatch.delenv("GF2_MC_FUSED")
+    monkeypatch.setenv("GF2_MC_UNFUSED", "1")
+    serial_big = ctx.mc_run(c1, c2, *big)
+    monkeypatch.delenv("GF2_MC_UNFUSED")
+    assert int(piped[0].sum()) == big[2] and int(piped[1].sum()) == big[2]
+    for got in (piped_again, fused_big, serial_big):
+        assert np.array_equal(got[0], piped[0]) and np.array_equal(got[1], piped[1])
 
 
 # ---- table decode + logical-error tally -------------------------------------------------------------
