@@ -483,7 +483,7 @@ def main():
             o_ms, o_launch, o_n, o_hist = timed(ctx, other, 10, 2)
             other_z = other.hz.download((R1 + 1,), np.uint64)
             assert np.array_equal(other_z, single_z * np.uint64(10)), "the two syndrome kernels disagree"
-            # end to end: nothing resident, gf2_mc_run draws the errors itself (fused sampler + sparse kernel)
+            # end to end: nothing resident, gf2_mc_run draws the errors itself (sampler || slab pipelines, three streams)
             mc_count = 1 << 24
             ctx.mc_run(chk1, chk2, SEED, 0, 1 << 20, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)
             t_mc = time.perf_counter()
@@ -493,7 +493,7 @@ def main():
                 ctx.mc_run(chk1, chk2, SEED, first, batch, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)[0], single_z)
             out["secondary"] = {
                 "monte_carlo_end_to_end": {"value": mc_count / t_mc, "unit": "syndromes/s",
-                                           "what": "gf2_mc_run: sampler fused into the sparse kernel, no resident input, "
+                                           "what": "gf2_mc_run: sampler of chunk k+1 overlapping the two slab pipelines of chunk k on three streams, no resident input, "
                                                    "host wall time incl. histogram download, %d samples" % mc_count},
                 other.algo + "_kernel": {"value": 10 * batch / (o_ms / 1e3), "unit": "syndromes/s", "ms_per_step": o_ms / 10,
                                          "roofline": roofline(other, o_launch, o_n), "histogram_ms_per_step": o_hist / 10},
