@@ -1002,3 +1002,35 @@ def test_two_rank_sharded_monte_carlo_on_the_gpu(tmp_path, steane_h):
         assert np.array_equal(r["hist_z"], want_z) and np.array_equal(r["hist_x"], want_x)
         assert np.array_equal(r["hist_z"], whole['hist_z'])
         assert list(r["decode"]) == [whole_dec[f] for f in montecarlo.DECODE_FIELDS]
+
+
+def test_two_contexts_share_checks_and_run_concurrently(ctx):
+    # bench.py issues the two components of a step on two contexts (two HIP streams, two workspaces) that share the prepared
+    # checks and the resident errors; 30 overlapping steps must accumulate exactly 30 times the one-stream histograms
+    r1, r2, n, batch = 1024, 1023, 2304, 40000
+    rng = np.random.default_rng(5)
+    h1 = rng.integers(0, 2, (r1, n), dtype=np.uint8)
+    h1[:, :r1] = np.identity(r1, dtype=np.uint8)
+    h2 = rng.integers(0, 2, (r2, n), dtype=np.uint8)
+    h2[:, n - r2:] = np.identity(r2, dtype=np.uint8)
+    c1, c2 = ctx.check_create(_native.pack_rows(h1), r1, n), ctx.check_create(_native.pack_rows(h2), r2, n)
+    lde = _native.words_for(n)
+    ex, ez = ctx.alloc(batch * lde * 8), ctx.alloc(batch * lde * 8)
+    ctx.sample_errors_dev(n, 8, 0, batch, 0.004, 0.003, 0.005, ex, ez, lde)
+    one_z, one_x = ctx.alloc((r1 + 1) * 8).zero(), ctx.alloc((r2 + 1) * 8).zero()
+    ctx.syndrome_sparse_dev(c1, ez, batch, lde, None, 0, one_z, r1 + 1)
+    ctx.syndrome_sparse_dev(c2, ex, batch, lde, None, 0, one_x, r2 + 1)
+    wz, wx = one_z.download((r1 + 1,), np.uint64), one_x.download((r2 + 1,), np.uint64)
+    other = _native.Context(ctx.device)
+    try:
+        hz, hx = ctx.alloc((r1 + 1) * 8).zero(), ctx.alloc((r2 + 1) * 8).zero()
+        ctx.sync()
+        for _ in range(30):
+            ctx.syndrome_sparse_dev(c1, ez, batch, lde, None, 0, hz, r1 + 1)
+            other.syndrome_sparse_dev(c2, ex, batch, lde, None, 0, hx, r2 + 1)
+        ctx.sync(), other.sync()
+        assert np.array_equal(hz.download((r1 + 1,), np.uint64), wz * np.uint64(30))
+        assert np.array_equal(hx.download((r2 + 1,), np.uint64), wx * np.uint64(30))
+    finally:
+        other.sync()
+        other.close()
