@@ -678,7 +678,8 @@ def test_normalize_with_a_column_swap_at_every_step(case, ctx):
 @pytest.mark.parametrize("case", [(2047, 4096, 2049, 1500, 0.007), (2048, 4096, 0, 5000, 0.01), (2048, 4096, 2048, 700, 0.012),
                                   (1000, 3000, 37, 1100, 0.004), (300, 2500, None, 600, 0.005), (2048, 4000, 1952, 513, 0.007),
                                   (130, 777, 500, 2049, 0.03), (2048, 4096, 0, 64, 0.0), (1300, 3100, 1700, 900, 0.006),
-                                  (200, 2000, None, 1000, 0.004), (1536, 3900, 2047, 300, 0.005), (512, 600, 88, 200, 0.02)])
+                                  (200, 2000, None, 1000, 0.004), (1536, 3900, 2047, 300, 0.005), (512, 600, 88, 200, 0.02),
+                                  (200, 200, 0, 300, 0.05), (2048, 4096, 1024, 400, 0.006)])
 def test_syndrome_slab_pipeline(case, ctx, monkeypatch):
     # histogram-only calls take the LDS row-slab pipeline (compact -> gather -> combine) when the check qualifies; it must
     # agree with the oracle and with the column-gather kernel on sparse samples, on samples beyond the record capacity
