@@ -36,8 +36,8 @@ The JSON line also carries
                 host, 1 core, on a bounded sample of the same workload.
   secondary     (rank 0, N = 1) the end-to-end Monte-Carlo (sampler included), the other syndrome kernels (column gather,
                 dense table) on the same workload, configs[1] and configs[2] (Steane, Reed-Muller), and RREF GB/s
-                (2 * m * ceil(n/64) * 8 bytes / time) for one and for 256 resident 2048 x 4096 matrices and for one
-                32768 x 65536 matrix.
+                (2 * m * ceil(n/64) * 8 bytes / time) for one and for 256 resident 2048 x 4096 matrices, for one
+                32768 x 65536 matrix, and for 256 MiB of 64 x 512 and of 128 x 512 matrices.
 """
 import argparse
 import json
@@ -277,6 +277,26 @@ def rref_numbers(ctx):
             best = ms if best is None else min(best, ms)
         assert int(rk.download((batch,), np.int64)[0]) == min(m, n)
         gbs = batch * 2 * a.nbytes / best / 1e6
+        res["%dx%d_x%d" % (m, n, batch)] = {"ms": best, "GB/s": gbs, "frac_hbm_peak": gbs / HBM_PEAK_GBS}
+        buf.free(), piv.free(), rk.free()
+    # many small matrices (one wavefront each, rows in registers): 256 MiB of 64 x 512 and of 128 x 512 matrices, read once
+    # and written once
+    for (m, n, batch) in ((64, 512, 65536), (128, 512, 32768)):
+        ld = n // 64
+        some = random_packed(1024 * m, n).reshape(1024, m, ld)
+        host = np.ascontiguousarray(np.tile(some, (batch // 1024, 1, 1)))
+        buf = ctx.alloc(host.nbytes)
+        piv, rk = ctx.alloc(batch * m * 8), ctx.alloc(batch * 8)
+        best = None
+        for _ in range(3):
+            buf.upload(host)
+            ctx.timer_start()
+            _native.check(_native.lib().gf2_rref_batch_dev(ctx.handle, buf.ptr, batch, m, n, ld, piv.ptr, rk.ptr))
+            ms = ctx.timer_stop()
+            best = ms if best is None else min(best, ms)
+        ranks = rk.download((batch,), np.int64)
+        assert int(ranks.min()) >= m - 3 and int(ranks.max()) == m
+        gbs = 2 * host.nbytes / best / 1e6
         res["%dx%d_x%d" % (m, n, batch)] = {"ms": best, "GB/s": gbs, "frac_hbm_peak": gbs / HBM_PEAK_GBS}
         buf.free(), piv.free(), rk.free()
     return res

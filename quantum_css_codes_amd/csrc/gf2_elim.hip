@@ -917,6 +917,108 @@ __global__ void nullspace_kernel(const u64* __restrict__ red, int64_t n, int64_t
 
 // ---- host side -----------------------------------------------------------------------------------------------------
 
+// ---- RREF of small matrices, one wavefront per matrix --------------------------------------------------------------------
+//
+// Up to 64 * RPL rows of up to 64 * LD columns: lane l holds rows l, l + 64, ... in registers (RPL rows of LD words).  The
+// columns are walked left to right; a column that still has a 1 in an unused row gets that row as its pivot (the RREF
+// does not depend on which one: the lowest lane of the lowest register row here), the pivot row is broadcast with
+// readlane and added to every other row that has the bit.  No LDS, no barrier; the matrix is read once and written once
+// (rows go out in pivot order, the zero rows after them), so a large batch of small matrices streams at what the walk
+// allows: ~20 instructions per column.  Grid-stride over the batch.
+template <int RPL, int LD>
+__global__ __launch_bounds__(256) void rref_small_kernel(u64* __restrict__ base, int64_t batch, int m, int n, int64_t ld,
+                                                         int64_t* __restrict__ pivots_base, int64_t cap,
+                                                         int64_t* __restrict__ rank_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t mat = wave; mat < batch; mat += nwaves) {
+        u64* a = base + mat * m * ld;
+        u64 w[RPL][LD];
+        int pivcol[RPL];                                            // >= 0 once this row has become a pivot row: its column
+        int myrank[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            const int row = lane + 64 * q;
+            pivcol[q] = -1;
+            myrank[q] = 0;
+#pragma unroll
+            for (int k = 0; k < LD; ++k) w[q][k] = (row < m && k < ld) ? a[(int64_t)row * ld + k] : 0ull;
+        }
+        int rank = 0;
+        for (int col = 0; col < n && rank < m; ++col) {
+            const int k = col >> 6, b = col & 63;                   // uniform
+            bool has[RPL];
+            int src_q = -1, src_lane = 0;
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                u64 word = 0;
+#pragma unroll
+                for (int kk = 0; kk < LD; ++kk)
+                    if (kk == k) word = w[q][kk];
+                has[q] = (word >> b) & 1ull;
+                const u64 cand = __ballot(has[q] && pivcol[q] < 0);
+                if (src_q < 0 && cand) {
+                    src_q = q;
+                    src_lane = __ffsll((long long)cand) - 1;
+                }
+            }
+            if (src_q < 0) continue;                                // no unused row has this column: not a pivot column
+            u64 pr[LD];
+#pragma unroll
+            for (int kk = 0; kk < LD; ++kk) {
+                u64 from = 0;
+#pragma unroll
+                for (int q = 0; q < RPL; ++q)
+                    if (q == src_q) from = w[q][kk];
+                pr[kk] = readlane64(from, src_lane);
+            }
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                const bool is_pivot = q == src_q && lane == src_lane;
+                if (is_pivot) {
+                    pivcol[q] = col;
+                    myrank[q] = rank;
+                } else if (has[q]) {
+#pragma unroll
+                    for (int kk = 0; kk < LD; ++kk) w[q][kk] ^= pr[kk];
+                }
+            }
+            rank += 1;
+        }
+        // rows out in pivot order; everything from row `rank` on is zero
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            const int row = lane + 64 * q;
+            if (pivcol[q] >= 0) {
+#pragma unroll
+                for (int k = 0; k < LD; ++k)
+                    if (k < ld) a[(int64_t)myrank[q] * ld + k] = w[q][k];
+                if (pivots_base) pivots_base[mat * cap + myrank[q]] = pivcol[q];
+            }
+            if (row >= rank && row < m) {
+#pragma unroll
+                for (int k = 0; k < LD; ++k)
+                    if (k < ld) a[(int64_t)row * ld + k] = 0ull;
+            }
+        }
+        if (lane == 0) rank_out[mat] = rank;
+    }
+}
+
+template <int RPL, int LD>
+static int launch_rref_small(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld, int64_t* pivots_dev,
+                             int64_t cap, int64_t* rank_dev) {
+    int64_t blocks = gf2_cdiv(batch, 4);
+    if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
+    GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
+    hipLaunchKernelGGL((rref_small_kernel<RPL, LD>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a_dev, batch, (int)m, (int)n,
+                       ld, pivots_dev, cap, rank_dev);
+    GF2_TRY(gf2_prof_end(ctx));
+    GF2_HIP(hipGetLastError());
+    return GF2_OK;
+}
+
 static int launch_eliminate(gf2_ctx* ctx, int mode, u64* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld,
                             int64_t offset, int64_t* pivots_dev, int64_t pivots_stride, int64_t* rank_dev,
                             int64_t* swaps_dev, int64_t* nswaps_dev, int* status_dev) {
@@ -1014,6 +1116,15 @@ int gf2_rref_batch_dev(gf2_ctx* ctx, uint64_t* a_dev, int64_t batch, int64_t m, 
     if (m == 0 || n == 0) return gf2_dev_zero(ctx, rank_dev, (size_t)batch * 8);
     if (!a_dev) GF2_FAIL(GF2_E_ARG, "gf2_rref_batch_dev: null matrix");
     const int64_t cap = m < n ? m : n;
+    if (getenv("GF2_RREF_SEQUENTIAL") == nullptr && getenv("GF2_RREF_NO_SMALL") == nullptr && m <= 128 && ld <= 8) {
+        // small matrices: one wavefront each, rows in registers
+        if (m <= 64 && ld <= 1) return launch_rref_small<1, 1>(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
+        if (m <= 64 && ld <= 2) return launch_rref_small<1, 2>(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
+        if (m <= 64 && ld <= 4) return launch_rref_small<1, 4>(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
+        if (m <= 64) return launch_rref_small<1, 8>(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
+        if (ld <= 4) return launch_rref_small<2, 4>(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
+        return launch_rref_small<2, 8>(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
+    }
     if (m < 0x7fffffffLL && batch <= 65535 && gf2_cdiv(m, 128) <= 65535 && getenv("GF2_RREF_SEQUENTIAL") == nullptr)
         return launch_rref_blocked(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
     return launch_eliminate(ctx, ELIM_RREF, (u64*)a_dev, batch, m, n, ld, 0, pivots_dev, cap, rank_dev, nullptr, nullptr,
