@@ -1116,14 +1116,26 @@ int gf2_rref_batch_dev(gf2_ctx* ctx, uint64_t* a_dev, int64_t batch, int64_t m, 
     if (m == 0 || n == 0) return gf2_dev_zero(ctx, rank_dev, (size_t)batch * 8);
     if (!a_dev) GF2_FAIL(GF2_E_ARG, "gf2_rref_batch_dev: null matrix");
     const int64_t cap = m < n ? m : n;
-    if (getenv("GF2_RREF_SEQUENTIAL") == nullptr && getenv("GF2_RREF_NO_SMALL") == nullptr && m <= 128 && ld <= 8) {
-        // small matrices: one wavefront each, rows in registers
-        if (m <= 64 && ld <= 1) return launch_rref_small<1, 1>(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
-        if (m <= 64 && ld <= 2) return launch_rref_small<1, 2>(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
-        if (m <= 64 && ld <= 4) return launch_rref_small<1, 4>(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
-        if (m <= 64) return launch_rref_small<1, 8>(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
-        if (ld <= 4) return launch_rref_small<2, 4>(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
-        return launch_rref_small<2, 8>(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
+    if (getenv("GF2_RREF_SEQUENTIAL") == nullptr && getenv("GF2_RREF_NO_SMALL") == nullptr && m <= 256 && ld <= 16 &&
+        gf2_cdiv(m, 64) * ld <= 32) {
+        // small matrices: one wavefront each, rows in registers (RPL rows of LD words per lane, at most 64 registers)
+#define GF2_SMALL(RPL, LD) return launch_rref_small<RPL, LD>(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev)
+        const int rpl = (int)gf2_cdiv(m, 64);
+        if (rpl <= 1) {
+            if (ld <= 1) GF2_SMALL(1, 1);
+            if (ld <= 2) GF2_SMALL(1, 2);
+            if (ld <= 4) GF2_SMALL(1, 4);
+            if (ld <= 8) GF2_SMALL(1, 8);
+            GF2_SMALL(1, 16);
+        } else if (rpl <= 2) {
+            if (ld <= 4) GF2_SMALL(2, 4);
+            if (ld <= 8) GF2_SMALL(2, 8);
+            GF2_SMALL(2, 16);
+        } else {
+            if (ld <= 4) GF2_SMALL(4, 4);
+            GF2_SMALL(4, 8);
+        }
+#undef GF2_SMALL
     }
     if (m < 0x7fffffffLL && batch <= 65535 && gf2_cdiv(m, 128) <= 65535 && getenv("GF2_RREF_SEQUENTIAL") == nullptr)
         return launch_rref_blocked(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
