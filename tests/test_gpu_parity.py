@@ -1035,3 +1035,33 @@ def test_two_contexts_share_checks_and_run_concurrently(ctx):
     finally:
         other.sync()
         other.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (3, 7), (64, 64), (64, 65), (33, 128), (64, 200), (64, 512), (60, 1000), (64, 1024),
+                                   (65, 100), (128, 256), (100, 500), (128, 1024), (129, 250), (256, 256), (200, 512), (256, 512)])
+def test_rref_batch_small_matrix_kernel_every_variant(shape, ctx, monkeypatch):
+    # the wavefront-per-matrix kernel (rows in registers): every (rows per lane, words per row) instantiation, batches of
+    # different matrices incl. rank-deficient and zero ones; pivots, ranks and matrices against the C oracle, and the
+    # blocked path on the same input
+    m, n = shape
+    rng = np.random.default_rng(m * 1000 + n)
+    batch = 5
+    mats = []
+    for b in range(batch):
+        a = (rng.random((m, n)) < (0.5 if b < 3 else 0.03)).astype(np.uint8)
+        if b == 1 and m > 2:
+            a[m - 1] = a[0] ^ a[1]
+        if b == 4:
+            a[:] = 0
+        mats.append(_native.pack_rows(a))
+    packed = np.ascontiguousarray(np.stack(mats))
+    got = packed.copy()
+    piv, ranks = ctx.rref_batch(got, batch, m, n)
+    for b in range(batch):
+        want, want_piv, want_rank = c_oracle.rref(packed[b], m, n)
+        assert int(ranks[b]) == want_rank and np.array_equal(piv[b][:want_rank], want_piv), (shape, b)
+        assert np.array_equal(got[b], want), (shape, b)
+    monkeypatch.setenv("GF2_RREF_NO_SMALL", "1")
+    again = packed.copy()
+    piv2, ranks2 = ctx.rref_batch(again, batch, m, n)
+    assert np.array_equal(again, got) and np.array_equal(ranks2, ranks)
