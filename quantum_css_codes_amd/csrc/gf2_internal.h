@@ -93,12 +93,19 @@ struct gf2_check {
     // row-slab tables of the LDS sparse pipeline (gf2_slabs.hip): nslabs512 x slab_cols entries of 64 bytes (512 rows of
     // one non-identity column; the last entry of a slab is zero); null when the check does not qualify
     void* slab_tab_dev;
+    // column table of the lane-per-sample kernel (gf2_lane.hip): n entries of ceil(r/64) words; null unless 64 < n <= 512 or
+    // 64 < r <= 256 fits (n <= 512, r <= 256, not `small`)
+    void* lane_tab_dev;
     int slab_cols, slab_null, nslabs512;   // entries per row-part plane, index of a zero entry, row slabs
     uint64_t rows_small[64];
 };
 
 int gf2_build_columns(gf2_ctx* ctx, gf2_check* ck);
 int gf2_build_slab_table(gf2_ctx* ctx, gf2_check* ck);
+int gf2_build_lane_table(gf2_ctx* ctx, gf2_check* ck);
+bool gf2_lane_ok(const gf2_check* ck);
+int gf2_syndrome_lane(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde, uint64_t* s_dev,
+                      int64_t lds, uint64_t* hist_dev, hipStream_t stream);
 bool gf2_slabs_ok(const gf2_check* ck);
 // stream: the context's stream or one of its side streams; ws_slot: 2 or 3 (one per stream that may run concurrently)
 int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde,

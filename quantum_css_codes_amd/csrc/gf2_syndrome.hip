@@ -528,9 +528,11 @@ int gf2_check_create(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, int6
     }
     if ((rc = gf2_build_columns(ctx, ck)) != GF2_OK) goto fail;
     if ((rc = gf2_build_slab_table(ctx, ck)) != GF2_OK) goto fail;
+    if ((rc = gf2_build_lane_table(ctx, ck)) != GF2_OK) goto fail;
     *check_out = ck;
     return GF2_OK;
 fail:
+    if (ck->lane_tab_dev) (void)hipFree(ck->lane_tab_dev);
     if (ck->slab_tab_dev) (void)hipFree(ck->slab_tab_dev);
     if (ck->ht_dev) (void)hipFree(ck->ht_dev);
     if (ck->h_dev) (void)hipFree(ck->h_dev);
@@ -550,6 +552,7 @@ int gf2_check_destroy(gf2_ctx* ctx, gf2_check* check) {
     GF2_TRY(gf2_dev_free(ctx, check->npairs_dev));
     GF2_TRY(gf2_dev_free(ctx, check->ht_dev));
     GF2_TRY(gf2_dev_free(ctx, check->slab_tab_dev));
+    GF2_TRY(gf2_dev_free(ctx, check->lane_tab_dev));
     free(check);
     return GF2_OK;
 }

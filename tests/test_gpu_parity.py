@@ -430,7 +430,10 @@ def test_tiled_device_path_slab_major_output(ctx):
 @pytest.mark.parametrize("case", [(100, 300, None, 200, 0.02), (100, 300, 100, 130, 0.05), (64, 200, 17, 64, 0.5),
                                   (2048, 4096, 0, 300, 0.007), (2047, 4096, 2048, 300, 0.007), (2047, 4096, 2048, 40, 0.5),
                                   (3000, 5000, None, 70, 0.01), (3000, 9000, 6000, 70, 0.01), (70, 9000, 128, 50, 0.2),
-                                  (5000, 6000, 1000, 20, 0.02), (65, 65, 0, 10, 0.3)])
+                                  (5000, 6000, 1000, 20, 0.02), (65, 65, 0, 10, 0.3),
+                                  # the lane-per-sample kernel (n <= 512, r <= 256): 1, 2, 3 and 4 syndrome words; 2, 4, 8 error words
+                                  (130, 200, None, 100, 0.1), (192, 512, 320, 333, 0.02), (256, 512, 0, 1500, 0.01),
+                                  (10, 100, None, 70, 0.3), (255, 511, 256, 2000, 0.01), (129, 257, 1, 600, 0.05)])
 def test_syndrome_sparse_kernel(case, ctx):
     r, n, ioff, batch, density = case
     rng = np.random.default_rng(r * 3 + n)
