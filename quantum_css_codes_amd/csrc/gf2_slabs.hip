@@ -72,6 +72,7 @@ struct CompactArgs {
     u64* hist;
     int64_t batch, lde;
     int r, n, ident_off, null_ord;
+    u64* clk;                  // debugging (GF2_GATHER_CLOCK): earliest entry / latest exit of the workgroups, else null
 };
 
 // LDS per wavefront: item list (values + tags), the 64 records as four planes (plane q = slots 8q..8q+7, 16 bytes per
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(CMP_THREADS, 5) void slab_compact_kernel(CompactArg
     __shared__ unsigned int wlist[64];
     __shared__ u64 wmask[64];
     __shared__ unsigned int nw_shared;
+    if (a.clk && threadIdx.x == 0) atomicMin(&a.clk[0], (u64)wall_clock64());
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     CompactWaveLds& L = lds_all[wave];
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(CMP_THREADS, 5) void slab_compact_kernel(CompactArg
         for (int q = 0; q < 4; ++q) out[q] = R[q];
         wave_lds_sync();
     }
+    if (a.clk && lane == 0) atomicMax(&a.clk[1], (u64)wall_clock64());
 }
 
 // ---- gather ----------------------------------------------------------------------------------------------------------
@@ -274,6 +277,7 @@ struct GatherArgs {
     unsigned short* pw;        // nslabs x batch_pad partial weights
     int64_t batch, batch_pad, lde;   // batch_pad: stride of the partial weights; records exist for ceil(batch / 64) * 64 positions
     int tab_stride, nslabs, r, ident_off, null_ord;   // tab_stride: entries per row-part plane (= 4 mod 16)
+    u64* clk;                  // debugging (GF2_GATHER_CLOCK): earliest entry / latest exit of the workgroups at [2], [3], else null
 };
 
 __device__ __forceinline__ unsigned int keep_rows(int r, int row0) {
@@ -333,6 +337,45 @@ __device__ __forceinline__ void fetch_ident(const GatherArgs& a, unsigned int sa
     if (id_sh) {
         // the fifth dword is the neighbouring row part's first one; only the last part of the slab loads it
         if (last_part || !aligned16) iw[4] = rowp32[dw0 + 4 < row_dwords ? dw0 + 4 : 0u];
+    }
+}
+
+// Value of `v` in lane q of this lane's quad (q is a constant after unrolling).
+__device__ __forceinline__ unsigned int quad_pick(unsigned int v, int q) {
+    switch (q) {
+        case 0: return quad_bcast<0>(v);
+        case 1: return quad_bcast<1>(v);
+        case 2: return quad_bcast<2>(v);
+        default: return quad_bcast<3>(v);
+    }
+}
+
+// XORs the table entries of slots 0 .. 4 NB - 1 of a record into X.  Block b (slots 4b .. 4b + 3) is dwords (x, y) or (z, w)
+// of record quarter b / 2, i.e. of quad lane b / 2; `first_pair` replaces the dword that holds slot 0.  Straight-line code:
+// the four ds_read_b128 of block b are issued before block b - AHEAD is consumed, so LDS latency (and its bank conflicts)
+// overlaps the XORs of the same wavefront instead of relying on the other three wavefronts of the SIMD.
+template <int NB>
+__device__ __forceinline__ void lookup_blocks(unsigned int part_base, const u32x4& R, unsigned int first_pair,
+                                              unsigned int (&X)[4]) {
+    constexpr int AHEAD = 2;
+    u32x4 v[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB + AHEAD; ++b) {
+        if (b < NB) {
+            const unsigned int lo = b == 0 ? first_pair : quad_pick((b & 1) ? R.z : R.x, b >> 1);
+            const unsigned int hi = quad_pick((b & 1) ? R.w : R.y, b >> 1);
+            v[b][0] = *(lds_u32x4_ptr)(uintptr_t)entry_addr_lo(part_base, lo);
+            v[b][1] = *(lds_u32x4_ptr)(uintptr_t)entry_addr_hi(part_base, lo);
+            v[b][2] = *(lds_u32x4_ptr)(uintptr_t)entry_addr_lo(part_base, hi);
+            v[b][3] = *(lds_u32x4_ptr)(uintptr_t)entry_addr_hi(part_base, hi);
+        }
+        if (b >= AHEAD) {
+            const int c = b - AHEAD;
+            X[0] = xor3(xor3(X[0], v[c][0].x, v[c][1].x), v[c][2].x, v[c][3].x);
+            X[1] = xor3(xor3(X[1], v[c][0].y, v[c][1].y), v[c][2].y, v[c][3].y);
+            X[2] = xor3(xor3(X[2], v[c][0].z, v[c][1].z), v[c][2].z, v[c][3].z);
+            X[3] = xor3(xor3(X[3], v[c][0].w, v[c][1].w), v[c][2].w, v[c][3].w);
+        }
     }
 }
 
@@ -398,16 +441,20 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
     u32x4 RA, RB, RC;
     unsigned int iwA[5], iwB[5], iwC[5];
     const unsigned int part16 = (unsigned int)part * 16u;
-    unsigned int grp = (unsigned int)share * GAT_WAVES + wave;
-    RA = fetch_record(rec_rsrc, grp * 16 + lane_rec, part16);
-    RB = fetch_record(rec_rsrc, (grp + stride) * 16 + lane_rec, part16);
-    fetch_ident(a, record_sample(grp * 16 + lane_rec, quad_bcast<0>(RA.x)), row_bytes, dw0, row_dwords, aligned16, id_sh,
+    unsigned int grp = (unsigned int)share * GAT_WAVES + wave, k = 0;
+    // A tile's four groups of 16 records ascend by count and a wavefront's group index keeps its residue mod 4 (the stride is a
+    // multiple of 4), so without a rotation wavefront w would meet quartile w mod 4 of every tile -- the same quarter of the
+    // wavefronts (one SIMD's, as they are dealt out) would get all the long records.  Step k takes quartile (w + k) mod 4.
+    auto rec_pos = [&](unsigned int g, unsigned int rot) { return ((g & ~3u) | ((g + rot) & 3u)) * 16 + lane_rec; };
+    RA = fetch_record(rec_rsrc, rec_pos(grp, 0), part16);
+    RB = fetch_record(rec_rsrc, rec_pos(grp + stride, 1), part16);
+    fetch_ident(a, record_sample(rec_pos(grp, 0), quad_bcast<0>(RA.x)), row_bytes, dw0, row_dwords, aligned16, id_sh,
                 part == 3, iwA);
 
     auto step = [&](const u32x4& R, unsigned int (&iw)[5], const u32x4& Rnext, u32x4& Rfar, unsigned int (&iwnext)[5]) {
-        const unsigned int pos = grp * 16 + lane_rec;
-        Rfar = fetch_record(rec_rsrc, pos + 2 * stride * 16, part16);
-        fetch_ident(a, record_sample(pos + stride * 16, quad_bcast<0>(Rnext.x)), row_bytes, dw0, row_dwords, aligned16, id_sh,
+        const unsigned int pos = rec_pos(grp, k);
+        Rfar = fetch_record(rec_rsrc, rec_pos(grp + 2 * stride, k + 2), part16);
+        fetch_ident(a, record_sample(rec_pos(grp + stride, k + 1), quad_bcast<0>(Rnext.x)), row_bytes, dw0, row_dwords, aligned16, id_sh,
                     part == 3, iwnext);
         const unsigned int head = quad_bcast<0>(R.x);               // slot 0 (count, tile-local sample) and slot 1
         const unsigned int slot0 = head & 0xFFFFu;
@@ -460,14 +507,182 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
 #pragma unroll 1
     while (grp < ngroups) {
         step(RA, iwA, RB, RC, iwB);
-        grp += stride;
+        grp += stride, ++k;
         if (grp >= ngroups) break;
         step(RB, iwB, RC, RA, iwC);
-        grp += stride;
+        grp += stride, ++k;
         if (grp >= ngroups) break;
         step(RC, iwC, RA, RB, iwA);
-        grp += stride;
+        grp += stride, ++k;
     }
+}
+
+// ---- gather, hand-scheduled variant -----------------------------------------------------------------------------------
+//
+// Same work as slab_gather_kernel for the common shape: a standard-form check whose identity words are 16-byte pieces of the
+// error rows (ident_off mod 128 < 32, even row pitch), which is what the n = 4096 checks are.  The generic kernel leaves the
+// memory waits to the compiler, which ends every step with s_waitcnt vmcnt(0): whatever the ring depth, a request has one
+// step (about 1.7 us, no more than an HBM round trip under load) to come back.  Here the loads are issued through inline
+// assembly, which the compiler's wait insertion does not see, and the waits are written by hand: the record of step i + 4 and
+// the identity words of step i + 2 are requested at the end of step i, and step i waits for exactly the requests it needs
+// (vector memory operations complete in order, so "all but the last N").
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+template <bool EXTRA>                              // EXTRA: ident_off is not a multiple of 32, a fifth dword per row part
+__global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(GatherArgs a) {
+    extern __shared__ __align__(16) unsigned char lds[];            // the only LDS: the table starts at LDS address 0
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (a.clk && threadIdx.x == 0) atomicMin(&a.clk[2], (u64)wall_clock64());
+    int slab, share;                                                // as in slab_gather_kernel: the slabs of a share on one XCD
+    const int shares = gridDim.x / a.nslabs;
+    if ((shares & 7) == 0) {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        slab = local % a.nslabs;
+        share = (local / a.nslabs) * 8 + xcd;
+    } else {
+        slab = blockIdx.x % a.nslabs;
+        share = blockIdx.x / a.nslabs;
+    }
+    {
+        const u32x4* src = a.tab + (int64_t)slab * a.tab_stride * 4;
+        for (int v = threadIdx.x; v < a.tab_stride * 4; v += GAT_THREADS) reinterpret_cast<u32x4*>(lds)[v] = src[v];
+    }
+    // Steps are handed out from a counter behind the table.  The SIMD arbiter favours its oldest wavefront: with a fixed split the
+    // four wavefronts of a SIMD finish one after the other (the first after 55 % of the kernel's duration) and the last
+    // quarter of the work runs on one wavefront per SIMD with nothing to hide its latencies behind.
+    unsigned int* const next_step = reinterpret_cast<unsigned int*>(lds + (size_t)a.tab_stride * 64);
+    if (threadIdx.x == 0) *next_step = 0;
+    __syncthreads();
+
+    const int part = lane & 3;
+    const unsigned int part_base = (unsigned int)part * (unsigned int)a.tab_stride * 16u;
+    const int row0 = slab * SLAB_ROWS + part * 128;
+    unsigned int keep[4];                                           // rows past r (all ones elsewhere: applied always)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) keep[q] = keep_rows(a.r, row0 + 32 * q);
+    const int id_sh = a.ident_off & 31;
+    const unsigned int slab_dw0 = (unsigned int)(a.ident_off >> 5) + slab * (SLAB_ROWS / 32);
+    const unsigned int dw0 = slab_dw0 + part * 4;
+    const unsigned int row_dwords = (unsigned int)a.lde * 2u, row_bytes = (unsigned int)a.lde * 8u;
+    unsigned int inrow[5];                                          // error dwords past the end of the row read as zero
+#pragma unroll
+    for (int t = 0; t < 5; ++t) inrow[t] = (dw0 + t < row_dwords && (t < 4 || EXTRA)) ? ~0u : 0u;
+    if (!EXTRA) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) keep[q] &= inrow[q];            // the identity dwords are the rows' bits as they are
+    }
+    const unsigned int null_ent = (unsigned int)a.null_ord << 4;
+    unsigned short* const pw = a.pw + (int64_t)slab * a.batch_pad;
+    // raw buffer over the records: positions past the end read zeros
+    const u64 rec_base = reinterpret_cast<u64>(a.rec);
+    const i32x4 rsrc = {__builtin_amdgcn_readfirstlane((int)(unsigned int)rec_base),
+                        __builtin_amdgcn_readfirstlane((int)((unsigned int)(rec_base >> 32) & 0xFFFFu)),
+                        __builtin_amdgcn_readfirstlane((int)(a.batch_pad * 64)), 0x00020000};
+    const char* const ident_base = reinterpret_cast<const char*>(a.e) + dw0 * 4u;
+    const unsigned int fifth_off = ((dw0 + 4 < row_dwords ? dw0 + 4 : 0u) - dw0) * 4u;       // from ident_base, wraps
+
+    const unsigned int ngroups = (unsigned int)(((a.batch + 63) >> 6) << 2);
+    const unsigned int stride = (unsigned int)shares * GAT_WAVES;
+    const unsigned int lane_rec = lane >> 2;
+    const unsigned int part16 = (unsigned int)part * 16u;
+
+    auto issue_record = [&](u32x4& R, unsigned int pos) {
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(R) : "v"((pos << 6) | part16), "s"(rsrc) : "memory");
+    };
+    auto issue_ident = [&](u32x4& I, unsigned int& E, unsigned int pos, unsigned int slot0_dword) {
+        const unsigned int sample = record_sample(pos, slot0_dword);
+        const char* p = ident_base + (u64)(sample < (unsigned int)a.batch ? sample : 0u) * row_bytes;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(I) : "v"(p) : "memory");
+        if (EXTRA) {
+            // the fifth dword is the neighbouring row part's first one; only the last part of the slab loads it
+            if (part == 3) asm volatile("global_load_dword %0, %1, off" : "=v"(E) : "v"(p + (int)fifth_off) : "memory");
+        }
+    };
+
+    u32x4 R0, R1, R2, R3, I0, I1;
+    unsigned int E0 = 0, E1 = 0;
+    // ticket t = step t / 16 of the fixed split's wavefront t mod 16: group share * 16 + t mod 16 + (t / 16) * stride
+    auto take = [&]() {
+        unsigned int t = 0;
+        if (lane == 0) t = atomicAdd(next_step, 1u);
+        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+        return (unsigned int)share * GAT_WAVES + (t & (GAT_WAVES - 1)) + (t / GAT_WAVES) * stride;
+    };
+    auto rec_pos = [&](unsigned int g) { return g * 16 + lane_rec; };
+    unsigned int G0 = take(), G1 = take(), G2 = take(), G3 = take();
+    issue_record(R0, rec_pos(G0));
+    issue_record(R1, rec_pos(G1));
+    issue_record(R2, rec_pos(G2));
+    issue_record(R3, rec_pos(G3));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(R0), "+v"(R1), "+v"(R2), "+v"(R3)::"memory");
+    issue_ident(I0, E0, rec_pos(G0), quad_bcast<0>(R0.x));
+    issue_ident(I1, E1, rec_pos(G1), quad_bcast<0>(R1.x));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(I0), "+v"(I1), "+v"(E0), "+v"(E1)::"memory");
+
+    // One step: R, I, E = record and identity words of this step (requested four and two steps ago), Rp2 = record of the
+    // step after next.  Requests younger than the ones needed here: last step's store, record and identity loads.
+    auto step = [&](u32x4& R, u32x4& I, unsigned int& E, u32x4& Rp2, unsigned int& G, unsigned int Gp2) {
+        if (EXTRA)
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(R), "+v"(I), "+v"(E), "+v"(Rp2)::"memory");
+        else
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(R), "+v"(I), "+v"(E), "+v"(Rp2)::"memory");
+        const unsigned int pos = rec_pos(G);
+        const unsigned int head = quad_bcast<0>(R.x);               // slot 0 (count, tile-local sample) and slot 1
+        const unsigned int slot0 = head & 0xFFFFu;
+        const bool flagged = (slot0 & 0xFFu) == REC_OVER;
+        const bool valid = record_sample(pos, slot0) < (unsigned int)a.batch;
+        const unsigned int c = flagged || !valid ? 0u : (slot0 & 0xFFu);
+        unsigned int iw[5] = {I.x, I.y, I.z, I.w, 0u};
+        if (EXTRA) {                                                // quad_perm [1,2,3,3]: lane p takes lane p + 1's first dword
+            const unsigned int nb = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)I.x, 0xF9, 0xF, 0xF, false);
+            iw[4] = part != 3 ? nb : E;
+        }
+        unsigned int X[4];
+        if (EXTRA) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                X[q] = __builtin_amdgcn_alignbit(iw[q + 1] & inrow[q + 1], iw[q] & inrow[q], id_sh) & keep[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) X[q] = iw[q] & keep[q];
+        }
+        // the tile is sorted by count (finished and out-of-batch samples first, as 0): the last record has the most slots
+        const unsigned int nblk = ((unsigned int)__builtin_amdgcn_readlane((int)c, 63) + 4u) >> 2;
+        const unsigned int first_pair = (head & 0xFFFF0000u) | null_ent;
+        switch (nblk) {
+            case 1: lookup_blocks<1>(part_base, R, first_pair, X); break;
+            case 2: lookup_blocks<2>(part_base, R, first_pair, X); break;
+            case 3: lookup_blocks<3>(part_base, R, first_pair, X); break;
+            case 4: lookup_blocks<4>(part_base, R, first_pair, X); break;
+            case 5: lookup_blocks<5>(part_base, R, first_pair, X); break;
+            case 6: lookup_blocks<6>(part_base, R, first_pair, X); break;
+            case 7: lookup_blocks<7>(part_base, R, first_pair, X); break;
+            default: lookup_blocks<8>(part_base, R, first_pair, X); break;
+        }
+        unsigned int wt = __popc(X[0]) + __popc(X[1]) + __popc(X[2]) + __popc(X[3]);
+        wt += __builtin_amdgcn_update_dpp(0u, wt, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
+        wt += __builtin_amdgcn_update_dpp(0u, wt, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
+        if (part == 0) pw[pos] = (unsigned short)(flagged || !valid ? REC_FLAG : wt);
+        // refill the buffers this step has emptied: exactly one store, one record load and one (EXTRA: two) identity loads
+        // per step, in this order -- the wait counts above depend on it
+        asm volatile("" ::: "memory");
+        G = take();
+        issue_record(R, rec_pos(G));
+        issue_ident(I, E, rec_pos(Gp2), quad_bcast<0>(Rp2.x));
+    };
+#pragma unroll 1
+    while (G0 < ngroups) {                                          // a wavefront's tickets ascend
+        step(R0, I0, E0, R2, G0, G2);
+        if (G1 >= ngroups) break;
+        step(R1, I1, E1, R3, G1, G3);
+        if (G2 >= ngroups) break;
+        step(R2, I0, E0, R0, G2, G0);
+        if (G3 >= ngroups) break;
+        step(R3, I1, E1, R1, G3, G1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (a.clk && lane == 0) atomicMax(&a.clk[3], (u64)wall_clock64());
 }
 
 // ---- combine ---------------------------------------------------------------------------------------------------------
@@ -475,8 +690,9 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
 // Four consecutive record positions per lane and step: one 8-byte load per slab (at most four slabs: r <= 2048), all issued before
 // any is used.
 __global__ __launch_bounds__(256) void slab_combine_kernel(const unsigned short* __restrict__ pw, int64_t positions, int64_t batch_pad,
-                                                          int nslabs, u64* __restrict__ hist, int nbins) {
+                                                          int nslabs, u64* __restrict__ hist, int nbins, u64* clk) {
     __shared__ unsigned int bins[SLAB_MAX_BINS];
+    if (clk && threadIdx.x == 0) atomicMin(&clk[0], (u64)wall_clock64());
     for (int i = threadIdx.x; i < nbins; i += blockDim.x) bins[i] = 0;
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
@@ -506,6 +722,7 @@ __global__ __launch_bounds__(256) void slab_combine_kernel(const unsigned short*
     __syncthreads();
     for (int i = threadIdx.x; i < nbins; i += blockDim.x)
         if (bins[i]) atomicAdd(&hist[i], (u64)bins[i]);
+    if (clk && threadIdx.x == 0) atomicMax(&clk[1], (u64)wall_clock64());
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -560,6 +777,10 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
     if (!ctx->lds_optin[2]) {
         GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
+        GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_fast_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
+        GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_fast_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
         ctx->lds_optin[2] = true;
     }
     const int64_t pass = batch < SLAB_MAX_BATCH ? batch : SLAB_MAX_BATCH;
@@ -571,7 +792,14 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
     for (int64_t first = 0; first < batch; first += pass) {
         const int64_t count = batch - first < pass ? batch - first : pass;
         const uint64_t* e = e_dev + first * lde;
+        u64* clk_dev = nullptr;
+        if (getenv("GF2_GATHER_CLOCK") != nullptr) {
+            static const u64 init[6] = {~0ull, 0, ~0ull, 0, ~0ull, 0};
+            GF2_HIP(hipMalloc((void**)&clk_dev, 64));
+            GF2_HIP(hipMemcpy(clk_dev, init, 48, hipMemcpyHostToDevice));
+        }
         CompactArgs ca;
+        ca.clk = clk_dev;
         ca.e = (const u64*)e;
         ca.ht = ck->ht_dev;
         ca.rec = rec;
@@ -618,19 +846,40 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
         ga.r = (int)ck->r;
         ga.ident_off = (int)ck->ident_off;
         ga.null_ord = ck->slab_null;
+        ga.clk = clk_dev;
         int64_t shares = ctx->num_cus / ck->nslabs512;
         const int64_t max_shares = gf2_cdiv(gf2_cdiv(count, 16), GAT_WAVES);
         if (shares > max_shares) shares = max_shares;
         if (shares < 1) shares = 1;
-        hipLaunchKernelGGL(slab_gather_kernel, dim3((unsigned)(shares * ck->nslabs512)), dim3(GAT_THREADS), lds_bytes,
-                           stream, ga);
+        // the hand-scheduled variant needs every slab's identity words to be whole 16-byte pieces inside the row
+        const int64_t first_dw = ck->ident_off >= 0 ? ck->ident_off >> 5 : 0;
+        const bool fast = ck->ident_off >= 0 && (lde & 1) == 0 && (reinterpret_cast<uintptr_t>(e) & 15) == 0 &&
+                          (first_dw & 3) == 0 && first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) <= lde * 2 &&
+                          getenv("GF2_GATHER_GENERIC") == nullptr;
+        const dim3 ggrid((unsigned)(shares * ck->nslabs512));
+        if (fast && (ck->ident_off & 31) != 0)
+            hipLaunchKernelGGL(slab_gather_fast_kernel<true>, ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+        else if (fast)
+            hipLaunchKernelGGL(slab_gather_fast_kernel<false>, ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+        else
+            hipLaunchKernelGGL(slab_gather_kernel, ggrid, dim3(GAT_THREADS), lds_bytes, stream, ga);
         GF2_HIP(hipGetLastError());
 
         int64_t mblocks = gf2_cdiv(count, 1024);
         if (mblocks > (int64_t)ctx->num_cus) mblocks = ctx->num_cus;
         hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3(256), 0, stream, pw, gf2_cdiv(count, 64) * 64, pad,
-                           ck->nslabs512, (u64*)hist_dev, nbins);
+                           ck->nslabs512, (u64*)hist_dev, nbins, clk_dev ? clk_dev + 4 : nullptr);
         GF2_HIP(hipGetLastError());
+        if (clk_dev) {
+            u64 c[6];
+            GF2_HIP(hipStreamSynchronize(stream));
+            GF2_HIP(hipMemcpy(c, clk_dev, 48, hipMemcpyDeviceToHost));
+            fprintf(stderr, "pipeline: compact %.1f .. %.1f us, combine %.1f .. %.1f us (from compact's first workgroup)\n", 0.0,
+                    (double)(c[1] - c[0]) / 100.0, (double)(c[4] - c[0]) / 100.0, (double)(c[5] - c[0]) / 100.0);
+            fprintf(stderr, "pipeline: gather %.1f .. %.1f us\n", (double)((int64_t)(c[2] - c[0])) / 100.0,
+                    (double)((int64_t)(c[3] - c[0])) / 100.0);
+            GF2_HIP(hipFree(clk_dev));
+        }
     }
     return GF2_OK;
 }
