@@ -30,7 +30,6 @@
 #define CMP_WAVES 4
 #define CMP_THREADS (64 * CMP_WAVES)
 #define CMP_SUB 8                             // samples per compaction sub-pass
-#define CMP_ITEM_CAP 176                      // non-zero words per sub-pass (expected ~90 at p = 0.01)
 #define REC_SLOTS 32                          // 16-bit slots per record: count + 31 columns
 #define REC_OVER 0xFFu                        // count byte of a sample that was finished by the slow routine
 #define REC_FLAG 0xFFFFu                      // its partial weights
@@ -75,15 +74,22 @@ struct CompactArgs {
     u64* clk;                  // debugging (GF2_GATHER_CLOCK): earliest entry / latest exit of the workgroups, else null
 };
 
-// LDS per wavefront: item list (values + tags), the 64 records as four planes (plane q = slots 8q..8q+7, 16 bytes per
-// sample, so that both the lane = item stores and the lane = sample reads are spread over the banks), the counters.
-struct CompactWaveLds {
-    u64 item_v[CMP_ITEM_CAP];
-    unsigned short item_m[CMP_ITEM_CAP];
-    unsigned char pad[2304 - CMP_ITEM_CAP * 10];   // the slow routine's list (SPARSE_LIST_CAP + 8 dwords) reuses this region
-    unsigned char planes[4096];
+// LDS per wavefront.  Non-zero (sample, word) pairs wait in a ring of 128 until 64 of them are there, so every pass over them
+// has all lanes busy; a pass writes the FIRST column of each word and moves words with more columns to the `left` list,
+// which is worked off when it fills up and at the end of the tile.  The 64 records of the tile are 64 contiguous bytes each
+// (slot k of sample j at 64 j + 2 k); a column beyond slot 31 is written to the next record's slot 0, which is filled in
+// last (the 16 bytes after the records take sample 63's).
+#define CMP_RING 128
+#define CMP_LEFT 128
+struct alignas(16) CompactWaveLds {
+    u64 ring_v[CMP_RING];                 // word
+    unsigned short ring_m[CMP_RING];      // tile-local sample << 6 | word index
+    u64 left_v[CMP_LEFT];                 // columns still to write
+    unsigned int left_m[CMP_LEFT];        // next slot (<= 32) | sample << 6 | column base << 16 (16 bits, see ord16)
+    unsigned char rec[4096 + 16];
     unsigned int cnt[64];
 };
+static_assert(CMP_RING * 10 + CMP_LEFT * 12 >= (SPARSE_LIST_CAP + 8) * 4, "the slow routine's list reuses the ring and left regions");
 
 // A sub-pass scans 8 samples.  Only the words that hold non-identity columns matter (half of them in a standard form), so
 // the (sample, word) pairs of a sub-pass are dealt out densely: pair p = t * 64 + lane of round t is word
@@ -96,25 +102,36 @@ struct PairMap {
     u64 mask[T];               // the word's non-identity columns
 };
 
+// Requests the words of the sub-pass that starts at row s_first (T loads, whatever the path: the wait counts in the kernel
+// rely on it).  Inline assembly: the compiler's wait insertion does not see these loads, the kernel waits by hand.
 template <int T>
 __device__ __forceinline__ void load_pairs(const CompactArgs& a, int64_t s_first, const PairMap<T>& pm, u64 (&w)[T]) {
     if (s_first + CMP_SUB <= a.batch) {                             // uniform: all 8 rows exist, one scalar base for the loads
-        const char* base = reinterpret_cast<const char*>(a.e + s_first * a.lde);
+        const u64* base = a.e + s_first * a.lde;
 #pragma unroll
-        for (int t = 0; t < T; ++t) w[t] = *reinterpret_cast<const u64*>(base + pm.off[t]);
+        for (int t = 0; t < T; ++t)
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(w[t]) : "v"(pm.off[t]), "s"(base) : "memory");
     } else {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const int64_t sample = s_first + (pm.jw[t] >> 6);
-            w[t] = a.e[(sample < a.batch ? sample : a.batch - 1) * a.lde + (pm.jw[t] & 63u)];
+            int64_t sample = s_first + (pm.jw[t] >> 6);
+            if (sample >= a.batch) sample = a.batch - 1;            // clamped into the batch; the caller masks
+            const unsigned int off = (unsigned int)sample * (unsigned int)a.lde * 8u + (pm.jw[t] & 63u) * 8u;
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(w[t]) : "v"(off), "s"(a.e) : "memory");
         }
     }
 }
 
-static_assert(2304 >= (SPARSE_LIST_CAP + 8) * 4, "item region too small for the slow routine's list");
+// Waits until at most N vector memory operations are outstanding and makes `w` depend on the wait.
+template <int N, int T>
+__device__ __forceinline__ void wait_pairs(u64 (&w)[T]) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#pragma unroll
+    for (int t = 0; t < T; ++t) asm volatile("" : "+v"(w[t]));
+}
 
 template <int T>
-__global__ __launch_bounds__(CMP_THREADS, 5) void slab_compact_kernel(CompactArgs a) {
+__global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 6 ? 4 : 3)) void slab_compact_kernel(CompactArgs a) {
     __shared__ CompactWaveLds lds_all[CMP_WAVES];
     __shared__ unsigned int wlist[64];
     __shared__ u64 wmask[64];
@@ -149,78 +166,142 @@ __global__ __launch_bounds__(CMP_THREADS, 5) void slab_compact_kernel(CompactArg
         pm.mask[t] = live ? wmask[wi] : 0ull;
     }
     const unsigned int null_ent = (unsigned int)a.null_ord << 4;        // entries are LDS byte offsets inside a row-part plane
-    const unsigned int null2 = null_ent | (null_ent << 16);
-    const u32x4 null4 = {null2, null2, null2, null2};
+    const unsigned int null2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)(null_ent | (null_ent << 16)));   // stays scalar
     const SparseSide side = {a.ht, (int64_t)a.r, (int64_t)a.ident_off, nullptr, 0};
+    // ordinal of column c: c below the identity block, c - r above it.  A word holds columns of one side only unless the
+    // block is narrower than a word (`mixed`); otherwise the word's base carries the subtraction (16-bit wrap-around is fine).
+    const bool mixed = a.ident_off >= 0 && a.r < 64;                    // uniform
+    auto col_base16 = [&](unsigned int col0, unsigned int first_bit) -> unsigned int {
+        if (mixed) return col0 << 4;
+        return ((a.ident_off >= 0 && (int)(col0 + first_bit) >= a.ident_off) ? col0 - (unsigned int)a.r : col0) << 4;
+    };
+    auto ord16 = [&](unsigned int cb, unsigned int bit) -> unsigned int {
+        if (!mixed) return cb + (bit << 4);
+        const unsigned int col = (cb >> 4) + bit;
+        return ((int)col >= a.ident_off ? col - (unsigned int)a.r : col) << 4;
+    };
+    unsigned int lc = 0;                                                // entries of the left list (uniform)
+    auto flush_left = [&]() {
+        wave_lds_sync();
+        for (unsigned int i0 = 0; i0 < lc; i0 += 64) {
+            const unsigned int i = i0 + lane;
+            if (i < lc) {
+                u64 v = L.left_v[i];
+                const unsigned int m = L.left_m[i];
+                unsigned char* const rj = L.rec + (m & 0xFC0u);
+                unsigned char* p = rj + (m & 63u) * 2;
+                const unsigned int cb = m >> 16;
+                while (v) {
+                    const unsigned int bit = (unsigned int)(__ffsll((long long)v) - 1);
+                    v &= v - 1;
+                    *reinterpret_cast<unsigned short*>(p < rj + 64 ? p : rj + 64) = (unsigned short)ord16(cb, bit);
+                    p += 2;
+                }
+            }
+        }
+        lc = 0;
+        wave_lds_sync();
+    };
+    // One pass over `count` <= 64 ring entries starting at `first`: slots are reserved per word with one LDS atomic.
+    auto process = [&](unsigned int first, unsigned int count) {
+        bool more = false;
+        u64 v = 0;
+        unsigned int meta = 0;
+        if ((unsigned int)lane < count) {
+            const unsigned int at = (first + lane) & (CMP_RING - 1);
+            v = L.ring_v[at];
+            const unsigned int m = L.ring_m[at];
+            const unsigned int j = m >> 6, col0 = (m & 63u) << 6;
+            const unsigned int slot = atomicAdd(&L.cnt[j], (unsigned int)__popcll(v)) + 1u;
+            const unsigned int bit = (unsigned int)(__ffsll((long long)v) - 1);
+            const unsigned int cb = col_base16(col0, bit);
+            unsigned char* const rj = L.rec + j * 64;
+            *reinterpret_cast<unsigned short*>(rj + (slot < REC_SLOTS ? slot * 2 : 64u)) = (unsigned short)ord16(cb, bit);
+            v &= v - 1;
+            more = v != 0;
+            meta = (slot + 1 < REC_SLOTS ? slot + 1 : (unsigned int)REC_SLOTS) | (j << 6) | (cb << 16);
+        }
+        const u64 mact = __ballot(more);
+        if (more) {
+            const unsigned int q = lc + __builtin_amdgcn_mbcnt_hi((unsigned int)(mact >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mact, 0u));
+            L.left_v[q] = v;
+            L.left_m[q] = meta;
+        }
+        lc += (unsigned int)__popcll(mact);
+        if (lc > CMP_LEFT - 64) flush_left();                           // uniform
+    };
 
     const int64_t ntiles = (a.batch + 63) >> 6;
     const int64_t total_waves = (int64_t)gridDim.x * CMP_WAVES;
-    // The row loads of a sub-pass issue back to back (rows clamped into the batch), and the loads of the next sub-pass are
-    // in flight while this one is compacted.
-    u64 wn[T];
-    load_pairs<T>(a, ((int64_t)blockIdx.x * CMP_WAVES + wave) * 64, pm, wn);
-#pragma unroll 1
-    for (int64_t tile = (int64_t)blockIdx.x * CMP_WAVES + wave; tile < ntiles; tile += total_waves) {
-        const int64_t s0 = tile * 64;
+    // The words of two sub-passes are in flight while a third is compacted: two register buffers take turns (the sub-pass loop
+    // is unrolled by two), each refilled for the sub-pass after next as soon as its words have been masked.  Vector memory
+    // operations complete in order, so a sub-pass waits until all but the other buffer's T loads (and, in the first two
+    // sub-passes of a tile, the previous tile's four record stores) have completed.
+    u64 wa[T], wb[T];
+    unsigned int head = 0, tail = 0;                                    // ring positions (uniform, running)
+    int64_t tile = (int64_t)blockIdx.x * CMP_WAVES + wave;
+    load_pairs<T>(a, tile * 64, pm, wa);
+    load_pairs<T>(a, tile * 64 + CMP_SUB, pm, wb);
+    wait_pairs<0, T>(wa);
+    wait_pairs<0, T>(wb);
+    auto sub_pass = [&](int64_t s0, int sub, u64 (&wbuf)[T], int64_t next_tile) {
+        if (sub < 2)
+            wait_pairs<T + 4, T>(wbuf);
+        else
+            wait_pairs<T, T>(wbuf);
+        u64 w[T];
+        if (s0 + (sub + 1) * CMP_SUB <= a.batch) {                  // uniform
 #pragma unroll
-        for (int q = 0; q < 4; ++q) reinterpret_cast<u32x4*>(L.planes)[q * 64 + lane] = null4;
+            for (int t = 0; t < T; ++t) w[t] = wbuf[t] & pm.mask[t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < T; ++t) w[t] = s0 + sub * CMP_SUB + (pm.jw[t] >> 6) < a.batch ? wbuf[t] & pm.mask[t] : 0ull;
+        }
+        load_pairs<T>(a, sub + 2 < 64 / CMP_SUB ? s0 + (sub + 2) * CMP_SUB : next_tile * 64 + (sub + 2 - 64 / CMP_SUB) * CMP_SUB, pm,
+                      wbuf);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const bool nz = w[t] != 0;
+            const u64 act = __ballot(nz);
+            if (nz) {
+                const unsigned int pos = (tail + __builtin_amdgcn_mbcnt_hi((unsigned int)(act >> 32),
+                                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)act, 0u))) &
+                                         (CMP_RING - 1);
+                L.ring_v[pos] = w[t];
+                L.ring_m[pos] = (unsigned short)(pm.jw[t] + ((unsigned int)(sub * CMP_SUB) << 6));
+            }
+            tail += (unsigned int)__popcll(act);
+            if (tail - head >= 64) {                                    // uniform; at most 63 entries stay behind
+                wave_lds_sync();
+                process(head, 64);
+                head += 64;
+            }
+        }
+    };
+#pragma unroll 1
+    for (; tile < ntiles; tile += total_waves) {
+        const int64_t s0 = tile * 64;
+        {
+            u32x4 null4;                            // made here every time: hoisted out of the loop it gets spilled, and a
+            unsigned int n0, n1, n2, n3;            // scratch reload makes the compiler wait for every load in flight
+            asm volatile("v_mov_b32 %0, %1" : "=v"(n0) : "s"(null2));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(n1) : "s"(null2));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(n2) : "s"(null2));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(n3) : "s"(null2));
+            null4.x = n0, null4.y = n1, null4.z = n2, null4.w = n3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) reinterpret_cast<u32x4*>(L.rec)[lane * 4 + q] = null4;
+        }
         L.cnt[lane] = 0;
 #pragma unroll 1
-        for (int sub = 0; sub < 64 / CMP_SUB; ++sub) {
-            u64 w[T];
-            if (s0 + (sub + 1) * CMP_SUB <= a.batch) {              // uniform
-#pragma unroll
-                for (int t = 0; t < T; ++t) w[t] = wn[t] & pm.mask[t];
-            } else {
-#pragma unroll
-                for (int t = 0; t < T; ++t)
-                    w[t] = s0 + sub * CMP_SUB + (pm.jw[t] >> 6) < a.batch ? wn[t] & pm.mask[t] : 0ull;
-            }
-            {
-                const int64_t nxt = sub + 1 < 64 / CMP_SUB ? s0 + (sub + 1) * CMP_SUB : (tile + total_waves) * 64;
-                load_pairs<T>(a, nxt, pm, wn);
-            }
-            unsigned int base = 0;
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const bool nz = w[t] != 0;
-                const u64 act = __ballot(nz);
-                if (nz) {
-                    const unsigned int pos = base + __builtin_amdgcn_mbcnt_hi((unsigned int)(act >> 32),
-                                                        __builtin_amdgcn_mbcnt_lo((unsigned int)act, 0u));
-                    if (pos < CMP_ITEM_CAP) {
-                        L.item_v[pos] = w[t];
-                        L.item_m[pos] = (unsigned short)(pm.jw[t] + ((unsigned int)(sub * CMP_SUB) << 6));
-                    }
-                }
-                base += (unsigned int)__popcll(act);
-            }
-            wave_lds_sync();
-            if (base > CMP_ITEM_CAP) {                              // uniform: these 16 samples take the slow routine
-                if (lane / CMP_SUB == sub) L.cnt[lane] = 1000;
-                base = 0;
-            }
-            for (unsigned int i0 = 0; i0 < base; i0 += 64) {
-                const unsigned int i = i0 + lane;
-                if (i < base) {
-                    u64 v = L.item_v[i];
-                    const unsigned int m = L.item_m[i];
-                    const unsigned int j = m >> 6, col0 = (m & 63u) << 6;
-                    unsigned char* const myrec = L.planes + j * 16;
-                    unsigned int slot = atomicAdd(&L.cnt[j], (unsigned int)__popcll(v)) + 1u;   // one reservation per word
-                    while (v) {
-                        const unsigned int col = col0 + (unsigned int)(__ffsll((long long)v) - 1);
-                        v &= v - 1;
-                        const unsigned int ord = (a.ident_off >= 0 && (int)col >= a.ident_off) ? col - a.r : col;
-                        if (slot < REC_SLOTS)
-                            *reinterpret_cast<unsigned short*>(myrec + (slot >> 3) * 1024 + (slot & 7) * 2) =
-                                (unsigned short)(ord << 4);
-                        ++slot;
-                    }
-                }
-            }
-            wave_lds_sync();
+        for (int sub = 0; sub < 64 / CMP_SUB; sub += 2) {
+            sub_pass(s0, sub, wa, tile + total_waves);
+            sub_pass(s0, sub + 1, wb, tile + total_waves);
         }
+        wave_lds_sync();
+        if (tail != head) process(head, tail - head);
+        head = tail;
+        flush_left();
 
         // lane = sample from here on
         const unsigned int c = L.cnt[lane];
@@ -258,7 +339,7 @@ __global__ __launch_bounds__(CMP_THREADS, 5) void slab_compact_kernel(CompactArg
         const unsigned int rank = sort_bins[32 + key] + in_bucket;
         u32x4 R[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) R[q] = reinterpret_cast<const u32x4*>(L.planes)[q * 64 + lane];
+        for (int q = 0; q < 4; ++q) R[q] = reinterpret_cast<const u32x4*>(L.rec)[lane * 4 + q];
         R[0].x = (R[0].x & 0xFFFF0000u) | (over ? REC_OVER : c) | ((unsigned int)lane << 8);
         u32x4* out = a.rec + (s0 + rank) * 4;
 #pragma unroll
@@ -689,7 +770,7 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
 
 // Four consecutive record positions per lane and step: one 8-byte load per slab (at most four slabs: r <= 2048), all issued before
 // any is used.
-__global__ __launch_bounds__(256) void slab_combine_kernel(const unsigned short* __restrict__ pw, int64_t positions, int64_t batch_pad,
+__global__ __launch_bounds__(1024) void slab_combine_kernel(const unsigned short* __restrict__ pw, int64_t positions, int64_t batch_pad,
                                                           int nslabs, u64* __restrict__ hist, int nbins, u64* clk) {
     __shared__ unsigned int bins[SLAB_MAX_BINS];
     if (clk && threadIdx.x == 0) atomicMin(&clk[0], (u64)wall_clock64());
@@ -811,8 +892,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
         ca.ident_off = (int)ck->ident_off;
         ca.null_ord = ck->slab_null;
         int64_t cblocks = gf2_cdiv(gf2_cdiv(count, 64), CMP_WAVES);
-        if (cblocks > (int64_t)ctx->num_cus * 5) cblocks = (int64_t)ctx->num_cus * 5;
-        // rounds per sub-pass: ceil(8 * words with non-identity columns / 64)
+        // rounds per sub-pass: ceil(8 * words with non-identity columns / 64); workgroups per CU as the variant's registers allow
         {
             int nw = 0;
             for (int64_t wd = 0; wd < gf2_words(ck->n); ++wd) {
@@ -821,6 +901,8 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
                 nw += inside ? 0 : 1;
             }
             const int rounds = (CMP_SUB * nw + 63) / 64;
+            const int per_cu = rounds <= 4 ? 5 : (rounds <= 6 ? 4 : 3);
+            if (cblocks > (int64_t)ctx->num_cus * per_cu) cblocks = (int64_t)ctx->num_cus * per_cu;
             const dim3 cgrid((unsigned)cblocks), cblock(CMP_THREADS);
             if (rounds <= 4)
                 hipLaunchKernelGGL(slab_compact_kernel<4>, cgrid, cblock, 0, stream, ca);
@@ -865,9 +947,12 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
             hipLaunchKernelGGL(slab_gather_kernel, ggrid, dim3(GAT_THREADS), lds_bytes, stream, ga);
         GF2_HIP(hipGetLastError());
 
-        int64_t mblocks = gf2_cdiv(count, 1024);
-        if (mblocks > (int64_t)ctx->num_cus) mblocks = ctx->num_cus;
-        hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3(256), 0, stream, pw, gf2_cdiv(count, 64) * 64, pad,
+        // few large workgroups: every workgroup ends with one global atomic per non-empty bin
+        int64_t mblocks = gf2_cdiv(count, 4096);
+        const char* mb_env = getenv("GF2_COMBINE_BLOCKS");
+        const int64_t mb_cap = mb_env ? atoi(mb_env) : 128;
+        if (mblocks > mb_cap) mblocks = mb_cap;
+        hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3(1024), 0, stream, pw, gf2_cdiv(count, 64) * 64, pad,
                            ck->nslabs512, (u64*)hist_dev, nbins, clk_dev ? clk_dev + 4 : nullptr);
         GF2_HIP(hipGetLastError());
         if (clk_dev) {
