@@ -7,7 +7,7 @@ from quantum_css_codes_amd import _native
 
 def main():
     ctx = _native.default_context()
-    n, r, batch = 4096, 2048, 1 << 20
+    n, r, batch = 4096, 2048, 1 << int(os.environ.get("SLAB_LOG2_BATCH", "20"))
     rng = np.random.default_rng(1)
     results = []
     for (rr, ioff) in ((2048, 0), (2047, 2049)):
@@ -24,7 +24,7 @@ def main():
         for _ in range(20):
             ctx.syndrome_sparse_dev(chk, ex, batch, 64, None, 0, hist, rr + 1)
         ms = ctx.timer_stop() / 20
-        results.append("r=%d off=%d: %.4f ms/launch (%.0f GB/s)" % (rr, ioff, ms, batch * 512 / ms / 1e6))
+        results.append("r=%d off=%d: %.4f ms/launch of 2^%d (%.0f GB/s)" % (rr, ioff, ms, batch.bit_length() - 1, batch * 512 / ms / 1e6))
     print(("gather kernel: " if os.environ.get("GF2_SPARSE_GATHER") else "slab pipeline: ") + " | ".join(results))
 
 main()
