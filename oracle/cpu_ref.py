@@ -334,12 +334,13 @@ def quantise_probability(x):
 
 
 def pauli_thresholds(p_x, p_y, p_z):
+    """(t_any, t_1, t_2): a qubit errs with probability t_any / 2^32; the kind uniform c of an erroneous qubit gives
+    X for c < t_1, Y for t_1 <= c < t_2, Z otherwise."""
     p_t = p_x + p_y + p_z
-    p_xy = p_x + p_y
     t_any = quantise_probability(p_t)
-    t_x = quantise_probability(p_xy / p_t) if p_t > 0 else 0
-    t_y = quantise_probability(p_y / p_xy) if p_xy > 0 else 0
-    return t_any, t_x, t_y
+    t_1 = quantise_probability(p_x / p_t) if p_t > 0 else 0
+    t_2 = quantise_probability((p_x + p_y) / p_t) if p_t > 0 else 0
+    return t_any, t_1, t_2
 
 
 def binomial_cdf_table(t_any, nb):
@@ -368,26 +369,12 @@ def binomial_cdf_table(t_any, nb):
     return cdf
 
 
-class _UniformStream(object):
-    """32-bit uniforms: high half then low half of draw 0, 1, 2, ... of one stream."""
-
-    def __init__(self, base):
-        self.base, self.queue, self.draws = base, [], 0
-
-    def next(self):
-        if not self.queue:
-            word = mix64(self.base + GOLDEN * (self.draws + 1))
-            self.draws += 1
-            self.queue = [word >> 32, word & 0xFFFFFFFF]
-        return self.queue.pop(0)
-
-
 def sample_pauli_error(seed, sample, n, p_x, p_y, p_z):
     """[build-defined, x3]  Error of global sample index `sample`: a pure function of (seed, sample).  Returns
-    (e_x, e_z) as length-n int arrays.  Per 64-qubit word: the number of erroneous qubits comes from one uniform by
-    inverse binomial CDF, their positions by Floyd's algorithm, then one uniform per erroneous qubit decides whether
-    it has an X component and one per X-carrying qubit whether it is a Y (DESIGN.md "Sampler")."""
-    t_any, t_x, t_y = pauli_thresholds(p_x, p_y, p_z)
+    (e_x, e_z) as length-n int arrays.  Per 64-qubit word one draw d: its high half gives the number of erroneous
+    qubits by inverse binomial CDF; each erroneous qubit takes one further draw mix64(d + G (k + 1)), whose high half
+    picks its position (Floyd's algorithm) and whose low half its kind (DESIGN.md "Sampler")."""
+    t_any, t_1, t_2 = pauli_thresholds(p_x, p_y, p_z)
     ks = mix64(seed + GOLDEN * (sample + 1))
     e_x = np.zeros(n, dtype='int')
     e_z = np.zeros(n, dtype='int')
@@ -395,18 +382,18 @@ def sample_pauli_error(seed, sample, n, p_x, p_y, p_z):
     for w in range(words):
         nb = 64 if w < words - 1 else n - 64 * (words - 1)
         cdf = binomial_cdf_table(t_any, nb)
-        streams = [_UniformStream(mix64(ks ^ ((STREAM_MULT * (4 * w + s + 1)) & _M64))) for s in range(3)]
-        u = streams[0].next()
-        k_err = sum(1 for k in range(nb) if u >= cdf[k])
+        d = mix64(ks + STREAM_MULT * (w + 1))
+        k_err = sum(1 for k in range(nb) if (d >> 32) >= cdf[k])
         chosen = set()
-        for i in range(nb - k_err, nb):                       # Floyd: k_err distinct positions in range(nb)
-            t = (streams[0].next() * (i + 1)) >> 32
-            chosen.add(i if t in chosen else t)
-        for j in sorted(chosen):
-            has_x = streams[1].next() < t_x
-            is_y = has_x and streams[2].next() < t_y
-            e_x[64 * w + j] = 1 if has_x else 0
-            e_z[64 * w + j] = 1 if (not has_x or is_y) else 0
+        for k in range(k_err):                                 # Floyd: k_err distinct positions in range(nb)
+            v = mix64(d + GOLDEN * (k + 1))
+            j = nb - k_err + k
+            t = ((v >> 32) * (j + 1)) >> 32
+            pos = j if t in chosen else t
+            chosen.add(pos)
+            kind = v & 0xFFFFFFFF
+            e_x[64 * w + pos] = 1 if kind < t_2 else 0
+            e_z[64 * w + pos] = 1 if kind >= t_1 else 0
     return e_x, e_z
 
 

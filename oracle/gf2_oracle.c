@@ -186,23 +186,12 @@ static void binomial_cdf(u64 t_any, int nb, u64* cdf) {
     }
 }
 
-/* 32-bit uniforms of one stream: high half, then low half of draw 0, 1, 2, ... */
-typedef struct { u64 base; u64 word; unsigned int taken; } uniform_stream;
-
-static u64 next_uniform(uniform_stream* st) {
-    const unsigned int d = st->taken >> 1;
-    if ((st->taken & 1u) == 0) st->word = mix64(st->base + GOLDEN * (u64)(d + 1));
-    const u64 out = (st->taken & 1u) ? (st->word & 0xFFFFFFFFull) : (st->word >> 32);
-    st->taken += 1;
-    return out;
-}
-
 int orc_sample_errors(int64_t n, u64 seed, int64_t first, int64_t count, double p_x, double p_y, double p_z,
                       u64* ex, u64* ez, int64_t lde) {
     const double p_t = p_x + p_y + p_z, p_xy = p_x + p_y;
     const u64 t_any = quantise(p_t);
-    const u64 t_x = p_t > 0.0 ? quantise(p_xy / p_t) : 0;
-    const u64 t_y = p_xy > 0.0 ? quantise(p_y / p_xy) : 0;
+    const u64 t_1 = p_t > 0.0 ? quantise(p_x / p_t) : 0;          /* X only below t_1, Y below t_2, else Z */
+    const u64 t_2 = p_t > 0.0 ? quantise(p_xy / p_t) : 0;
     const int64_t words = (n + 63) >> 6;
     const int nb_last = n > 0 ? (int)(n - (words - 1) * 64) : 0;
     u64 cdf_full[65], cdf_last[65];
@@ -215,28 +204,21 @@ int orc_sample_errors(int64_t n, u64 seed, int64_t first, int64_t count, double 
             if (w < words) {
                 const int nb = w == words - 1 ? nb_last : 64;
                 const u64* cdf = w == words - 1 ? cdf_last : cdf_full;
-                uniform_stream s0 = {mix64(ks ^ (STREAM_MULT * (u64)(4 * w + 1))), 0, 0};
-                uniform_stream s1 = {mix64(ks ^ (STREAM_MULT * (u64)(4 * w + 2))), 0, 0};
-                uniform_stream s2 = {mix64(ks ^ (STREAM_MULT * (u64)(4 * w + 3))), 0, 0};
-                const u64 u = next_uniform(&s0);
+                const u64 d = mix64(ks + STREAM_MULT * ((u64)w + 1));      /* the word's draw */
                 int k_err = 0;
                 for (int k = 0; k < nb; ++k)
-                    if (u >= cdf[k]) k_err += 1;                   /* the table is non-decreasing */
-                u64 chosen = 0;                                    /* Floyd's sampling of k_err distinct positions */
-                for (int i2 = nb - k_err; i2 < nb; ++i2) {
-                    const int t = (int)((next_uniform(&s0) * (u64)(i2 + 1)) >> 32);
-                    if ((chosen >> t) & 1ull)
-                        chosen |= 1ull << i2;
-                    else
-                        chosen |= 1ull << t;
+                    if ((d >> 32) >= cdf[k]) k_err += 1;                   /* the table is non-decreasing */
+                u64 chosen = 0;
+                for (int k = 0; k < k_err; ++k) {                         /* Floyd: k_err distinct positions, one draw each */
+                    const u64 v = mix64(d + GOLDEN * ((u64)k + 1));
+                    const int j = nb - k_err + k;
+                    const int t = (int)(((v >> 32) * (u64)(j + 1)) >> 32);
+                    const int pos = ((chosen >> t) & 1ull) ? j : t;
+                    const u64 kind = v & 0xFFFFFFFFull;
+                    chosen |= 1ull << pos;
+                    if (kind < t_2) x |= 1ull << pos;                      /* X or Y */
+                    if (kind >= t_1) z |= 1ull << pos;                     /* Y or Z */
                 }
-                u64 with_x = 0, as_y = 0;
-                for (int j = 0; j < nb; ++j)
-                    if (((chosen >> j) & 1ull) && next_uniform(&s1) < t_x) with_x |= 1ull << j;
-                for (int j = 0; j < nb; ++j)
-                    if (((with_x >> j) & 1ull) && next_uniform(&s2) < t_y) as_y |= 1ull << j;
-                x = with_x;
-                z = (chosen & ~with_x) | as_y;
             }
             ex[i * lde + w] = x;
             ez[i * lde + w] = z;

@@ -34,11 +34,101 @@ __global__ __launch_bounds__(256) void sampler_kernel(u64 seed, int64_t first_sa
         u64 x = 0, z = 0;
         if (i < count && w < words) {
             const bool last = w == words - 1;
-            sample_word(seed, (u64)(first_sample + i), (u64)w, last ? th.nb_last : 64, cdf_lds + (last ? 65 : 0), th.t_x,
-                        th.t_y, &x, &z);
+            sample_word(seed, (u64)(first_sample + i), (u64)w, last ? th.nb_last : 64, cdf_lds + (last ? 65 : 0), th.t_1,
+                        th.t_2, &x, &z);
         }
         ex[idx] = x;
         ez[idx] = z;
+    }
+}
+
+// Sample-major errors of up to 64 words per sample: one wavefront per block of 8 samples, lane = word.  Every word takes its
+// one draw and writes zeros into an LDS image of the block; the words with errors (a third of them at p = 0.01) queue up in a
+// ring and are worked off 64 at a time, so that the draws per erroneous qubit run on full wavefronts instead of on the
+// few lanes of each sample that need them; the image then leaves as whole rows.
+#define SMP_BLOCK 8
+#define SMP_WAVES 4
+#define SMP_RING 128
+struct alignas(16) SamplerWaveLds {
+    u64 ring_d[SMP_RING];                       // the word's draw
+    unsigned short ring_m[SMP_RING];            // sample in block << 6 | word, error count << 9
+    u64 img[2][SMP_BLOCK][64];                  // e_x, e_z of the block
+};
+
+__global__ __launch_bounds__(64 * SMP_WAVES) void sampler_rows_kernel(u64 seed, int64_t first_sample, int64_t count, int words,
+                                                                    int64_t lde, SamplerTables th, uint64_t* __restrict__ ex,
+                                                                    uint64_t* __restrict__ ez) {
+    __shared__ u64 cdf_lds[130];
+    __shared__ SamplerWaveLds lds_all[SMP_WAVES];
+    stage_cdf(th, cdf_lds);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SamplerWaveLds& L = lds_all[wave];
+    const bool live = lane < words;
+    const bool last = lane == words - 1;
+    const int nb = last ? th.nb_last : 64;
+    const u64* const cdf = cdf_lds + (last ? 65 : 0);
+    const u64 cdf0 = cdf[0];
+    const int64_t nblocks = (count + SMP_BLOCK - 1) / SMP_BLOCK;
+    const int64_t total_waves = (int64_t)gridDim.x * SMP_WAVES;
+    unsigned int head = 0, tail = 0;
+    auto process = [&](unsigned int first, unsigned int n_items) {
+        if ((unsigned int)lane < n_items) {
+            const unsigned int at = (first + lane) & (SMP_RING - 1);
+            const u64 d = L.ring_d[at];
+            const unsigned int m = L.ring_m[at];
+            const unsigned int sw = m & 511u, w = m & 63u;
+            u64 x, z;
+            place_errors(d, (int)(m >> 9), (int)w == words - 1 ? th.nb_last : 64, th.t_1, th.t_2, &x, &z);
+            (&L.img[0][0][0])[sw] = x;
+            (&L.img[1][0][0])[sw] = z;
+        }
+    };
+#pragma unroll 1
+    for (int64_t blk = (int64_t)blockIdx.x * SMP_WAVES + wave; blk < nblocks; blk += total_waves) {
+        const int64_t i0 = blk * SMP_BLOCK;
+#pragma unroll 1
+        for (int s = 0; s < SMP_BLOCK; ++s) {
+            // the sample's key is the same in every lane: made scalar by hand, the compiler keeps it in vector registers
+            const u64 si = (u64)(first_sample + i0 + s);
+            const u64 si_s = ((u64)(unsigned int)__builtin_amdgcn_readfirstlane((int)(si >> 32)) << 32) |
+                             (unsigned int)__builtin_amdgcn_readfirstlane((int)si);
+            const u64 ks = sample_key(seed, si_s);
+            L.img[0][s][lane] = 0;
+            L.img[1][s][lane] = 0;
+            int k_err = 0;
+            u64 d = 0;
+            if (live && i0 + s < count) {
+                d = word_draw(ks, (u64)lane);
+                if ((d >> 32) >= cdf0) k_err = error_count(d, nb, cdf);
+            }
+            const u64 act = __ballot(k_err > 0);
+            if (k_err > 0) {
+                const unsigned int pos = (tail + __builtin_amdgcn_mbcnt_hi((unsigned int)(act >> 32),
+                                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)act, 0u))) &
+                                         (SMP_RING - 1);
+                L.ring_d[pos] = d;
+                L.ring_m[pos] = (unsigned short)((unsigned int)(s << 6) | (unsigned int)lane | ((unsigned int)k_err << 9));
+            }
+            tail += (unsigned int)__popcll(act);
+            if (tail - head >= 64) {                                // uniform
+                __builtin_amdgcn_wave_barrier();
+                process(head, 64);
+                head += 64;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (tail != head) process(head, tail - head);
+        head = tail;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < SMP_BLOCK; ++s) {
+            if (i0 + s < count && lane < lde) {
+                ex[(i0 + s) * lde + lane] = L.img[0][s][lane];
+                ez[(i0 + s) * lde + lane] = L.img[1][s][lane];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -61,7 +151,7 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeRows rows, int r1, in
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         u64 ex, ez;
-        sample_word(seed, (u64)(first_sample + i), 0, n, cdf_lds + 65, th.t_x, th.t_y, &ex, &ez);
+        sample_word(seed, (u64)(first_sample + i), 0, n, cdf_lds + 65, th.t_1, th.t_2, &ex, &ez);
         u64 kx = 0, kz = 0;                                   // vec_to_int keys: row 0 is the most significant bit
         for (int k = 0; k < r2; ++k) kx = (kx << 1) | (u64)(__popcll(rows.h2[k] & ex) & 1);
         for (int k = 0; k < r1; ++k) kz = (kz << 1) | (u64)(__popcll(rows.h1[k] & ez) & 1);
@@ -99,7 +189,7 @@ __global__ __launch_bounds__(256) void mc_small_kernel(DecodeRows rows, int r1, 
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         u64 ex, ez;
-        sample_word(seed, (u64)(first_sample + i), 0, n, cdf_lds + 65, th.t_x, th.t_y, &ex, &ez);
+        sample_word(seed, (u64)(first_sample + i), 0, n, cdf_lds + 65, th.t_1, th.t_2, &ex, &ez);
         u64 kx = 0, kz = 0;
         if (mode == GF2_HIST_FULL) {
             for (int k = 0; k < r2; ++k) kx = (kx << 1) | (u64)(__popcll(rows.h2[k] & ex) & 1);
@@ -147,7 +237,12 @@ int gf2_sample_errors_dev(gf2_ctx* ctx, int64_t n, uint64_t seed, int64_t first_
     if (layout == GF2_LAYOUT_TILED)
         hipLaunchKernelGGL(sampler_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (u64)seed, first_sample,
                            count, n, gf2_words(n), lde, total, th, ex_dev, ez_dev);
-    else
+    else if (lde <= 64 && gf2_words(n) >= 8 && getenv("GF2_SAMPLER_GENERIC") == nullptr) {
+        int64_t rblocks = gf2_cdiv(gf2_cdiv(count, SMP_BLOCK), SMP_WAVES);
+        if (rblocks > (int64_t)ctx->num_cus * 8) rblocks = (int64_t)ctx->num_cus * 8;
+        hipLaunchKernelGGL(sampler_rows_kernel, dim3((unsigned)rblocks), dim3(64 * SMP_WAVES), 0, ctx->stream, (u64)seed, first_sample,
+                           count, (int)gf2_words(n), lde, th, ex_dev, ez_dev);
+    } else
         hipLaunchKernelGGL(sampler_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (u64)seed, first_sample,
                            count, n, gf2_words(n), lde, total, th, ex_dev, ez_dev);
     GF2_TRY(gf2_prof_end(ctx));

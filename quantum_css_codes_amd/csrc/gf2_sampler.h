@@ -12,63 +12,52 @@ __host__ __device__ static inline u64 mix64(u64 z) {
     return z ^ (z >> 31);
 }
 
-// Sampler (DESIGN.md "Sampler"): per 64-qubit word of a sample, three independent streams of 32-bit uniforms
-// (high then low half of successive splitmix64 draws).
-//   stream 0: the first uniform picks the number K of erroneous qubits in the word by inverse binomial CDF (an integer
-//             table made on the host); K distinct positions follow by Floyd's algorithm, one uniform each.
-//   stream 1: one uniform per erroneous qubit, ascending: the error has an X component iff uniform < t_x.
-//   stream 2: one uniform per qubit with an X component, ascending: it is a Y iff uniform < t_y.
+// Sampler (DESIGN.md "Sampler"), per 64-qubit word w of sample i:
+//   ks = mix64(seed + G (i + 1)),  d = mix64(ks + M (w + 1))                        one draw per word
+//   K  = #{k < nb : (d >> 32) >= cdf[k]} erroneous qubits (inverse binomial CDF, an integer table made on the host)
+//   for k = 0 .. K - 1:  v = mix64(d + G (k + 1));  the high half of v picks a position by Floyd's algorithm (K distinct
+//   positions out of nb), the low half c its kind: c < t_1 -> X, t_1 <= c < t_2 -> Y, else Z.
+// A word without errors costs one mix64, each erroneous qubit one more.
 struct SamplerTables {
-    u64 t_x, t_y;              // thresholds in [0, 2^32]
+    u64 t_1, t_2;              // thresholds in [0, 2^32]: X only below t_1, Y below t_2
     u64 cdf_full[65];          // K = #{k < 64 : u >= cdf_full[k]} for whole words
     u64 cdf_last[65];          // the same for the last word of nb_last valid qubits
     int nb_last;
 };
 
-struct UniformStream {
-    u64 base, cur;
-    unsigned int k;
-    bool half;
-    __device__ __forceinline__ explicit UniformStream(u64 b) : base(b), cur(0), k(0), half(false) {}
-    __device__ __forceinline__ u64 next() {                   // 32-bit uniform: high half, then low half of each draw
-        if (!half) {
-            cur = mix64(base + GF2_GOLDEN * (u64)(k + 1));
-            k += 1;
-            half = true;
-            return cur >> 32;
-        }
-        half = false;
-        return cur & 0xFFFFFFFFull;
-    }
-};
+// The draw of word w that fixes its number of errors and seeds its further draws; ks = sample_key(seed, sample).
+__host__ __device__ static inline u64 sample_key(u64 seed, u64 sample) { return mix64(seed + GF2_GOLDEN * (sample + 1)); }
+__host__ __device__ static inline u64 word_draw(u64 ks, u64 w) { return mix64(ks + GF2_STREAM_MULT * (w + 1)); }
 
-// cdf: the table for this word (in LDS); nb: valid qubits of this word (1..64).
-__device__ static inline void sample_word(u64 seed, u64 sample, u64 w, int nb, const u64* cdf, u64 t_x, u64 t_y,
-                                          u64* ex, u64* ez) {
-    const u64 ks = mix64(seed + GF2_GOLDEN * (sample + 1));
-    UniformStream s0(mix64(ks ^ (GF2_STREAM_MULT * (4 * w + 1))));
-    const u64 u = s0.next();
-    int count = 0;
-    while (count < nb && u >= cdf[count]) count += 1;
-    u64 any_err = 0;
-    for (int idx = 0; idx < count; ++idx) {                    // Floyd: `count` distinct positions out of nb
-        const int i = nb - count + idx;
-        const int t = (int)((s0.next() * (u64)(i + 1)) >> 32);
-        any_err |= 1ull << (((any_err >> t) & 1ull) ? i : t);
-    }
-    u64 has_x = 0, is_y = 0;
-    if (any_err) {
-        UniformStream s1(mix64(ks ^ (GF2_STREAM_MULT * (4 * w + 2))));
-        for (u64 x = any_err; x; x &= x - 1)
-            if (s1.next() < t_x) has_x |= x & (0ull - x);
-    }
-    if (has_x) {
-        UniformStream s2(mix64(ks ^ (GF2_STREAM_MULT * (4 * w + 3))));
-        for (u64 x = has_x; x; x &= x - 1)
-            if (s2.next() < t_y) is_y |= x & (0ull - x);
+// Errors of a word with `count` erroneous qubits out of nb (Floyd's sampling, one mix64 per qubit).
+__device__ static inline void place_errors(u64 d, int count, int nb, u64 t_1, u64 t_2, u64* ex, u64* ez) {
+    u64 chosen = 0, has_x = 0, has_z = 0;
+    for (int k = 0; k < count; ++k) {
+        const u64 v = mix64(d + GF2_GOLDEN * (u64)(k + 1));
+        const int j = nb - count + k;
+        const int t = (int)(((v >> 32) * (u64)(j + 1)) >> 32);
+        const int pos = ((chosen >> t) & 1ull) ? j : t;
+        const u64 c = v & 0xFFFFFFFFull;
+        chosen |= 1ull << pos;
+        if (c < t_2) has_x |= 1ull << pos;
+        if (c >= t_1) has_z |= 1ull << pos;
     }
     *ex = has_x;
-    *ez = (any_err & ~has_x) | is_y;
+    *ez = has_z;
+}
+
+// cdf: the table for this word (in LDS); nb: valid qubits of this word (1..64).
+__device__ static inline int error_count(u64 d, int nb, const u64* cdf) {
+    const u64 u = d >> 32;
+    int count = 0;
+    while (count < nb && u >= cdf[count]) count += 1;
+    return count;
+}
+
+__device__ static inline void sample_word(u64 seed, u64 sample, u64 w, int nb, const u64* cdf, u64 t_1, u64 t_2,
+                                          u64* ex, u64* ez) {
+    const u64 d = word_draw(sample_key(seed, sample), w);
+    place_errors(d, error_count(d, nb, cdf), nb, t_1, t_2, ex, ez);
 }
 
 // Copies the two CDF tables of the kernel argument into LDS (per-lane table indices need addressable memory).
@@ -104,8 +93,8 @@ static inline int make_thresholds(double p_x, double p_y, double p_z, int64_t n,
         GF2_FAIL(GF2_E_ARG, "probabilities must be non-negative and sum to at most 1");
     const double p_t = p_x + p_y + p_z, p_xy = p_x + p_y;
     const uint64_t t_any = gf2_quantise(p_t);
-    th->t_x = p_t > 0.0 ? gf2_quantise(p_xy / p_t) : 0;
-    th->t_y = p_xy > 0.0 ? gf2_quantise(p_y / p_xy) : 0;
+    th->t_1 = p_t > 0.0 ? gf2_quantise(p_x / p_t) : 0;
+    th->t_2 = p_t > 0.0 ? gf2_quantise(p_xy / p_t) : 0;
     th->nb_last = n > 0 ? (int)(n - ((n - 1) / 64) * 64) : 0;
     binomial_cdf_table(t_any, 64, th->cdf_full);
     binomial_cdf_table(t_any, th->nb_last, th->cdf_last);

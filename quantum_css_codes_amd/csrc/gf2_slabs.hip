@@ -613,7 +613,6 @@ template <bool EXTRA>                              // EXTRA: ident_off is not a 
 __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(GatherArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];            // the only LDS: the table starts at LDS address 0
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (a.clk && threadIdx.x == 0) atomicMin(&a.clk[2], (u64)wall_clock64());
     int slab, share;                                                // as in slab_gather_kernel: the slabs of a share on one XCD
     const int shares = gridDim.x / a.nslabs;

@@ -229,8 +229,8 @@ __global__ __launch_bounds__(64 * SPARSE_WAVES) void mc_sparse_fused_kernel(Spar
     for (int64_t i = (int64_t)blockIdx.x * SPARSE_WAVES + wave; i < count; i += total_waves) {
         u64 ex = 0, ez = 0;
         if (lane < words)
-            sample_word(seed, (u64)(first_sample + i), (u64)lane, last ? th.nb_last : 64, cdf_lds + (last ? 65 : 0), th.t_x,
-                        th.t_y, &ex, &ez);
+            sample_word(seed, (u64)(first_sample + i), (u64)lane, last ? th.nb_last : 64, cdf_lds + (last ? 65 : 0), th.t_1,
+                        th.t_2, &ex, &ez);
         const unsigned int wz = sparse_component_weight(ez, side_z, n, lane, list[wave]);
         const unsigned int wx = sparse_component_weight(ex, side_x, n, lane, list[wave]);
         if (lane == 0) {

@@ -312,8 +312,9 @@ def test_css_code_mid_size_vs_oracle():
 
 # ---- Monte-Carlo -------------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("n", [7, 64, 70, 200, 4096])
+@pytest.mark.parametrize("n", [7, 64, 70, 200, 512, 513, 1000, 4095, 4096, 5000])
 def test_sampler_vs_oracle(n, ctx):
+    # n >= 512 with rows of at most 64 words takes the block-wise kernel (queued error words), the rest the word-per-lane one
     count, lde = 300, max(1, _native.words_for(n))
     for (px, py, pz) in ((0.01, 0.01, 0.01), (0.2, 0.1, 0.3), (0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 0.5, 0.5)):
         ex_buf, ez_buf = ctx.alloc(count * lde * 8), ctx.alloc(count * lde * 8)
@@ -323,6 +324,21 @@ def test_sampler_vs_oracle(n, ctx):
         assert np.array_equal(ex, want_x) and np.array_equal(ez, want_z), (n, px, py, pz)
         ex_buf.free()
         ez_buf.free()
+
+
+@pytest.mark.parametrize("case", [(1000, 20, 1), (3000, 64, 13), (4096, 64, 64), (640, 10, 7)])
+def test_sampler_block_kernel_padded_rows_and_ragged_counts(case, ctx):
+    n, lde, count = case
+    words = _native.words_for(n)
+    ex_buf, ez_buf = ctx.alloc(count * lde * 8), ctx.alloc(count * lde * 8)
+    ex_buf.upload(np.full((count, lde), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64))     # pad words must come back zero
+    ez_buf.upload(np.full((count, lde), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64))
+    ctx.sample_errors_dev(n, 5, 77, count, 0.02, 0.01, 0.03, ex_buf, ez_buf, lde)
+    ex, ez = ex_buf.download((count, lde), "<u8"), ez_buf.download((count, lde), "<u8")
+    want_x, want_z = c_oracle.sample_errors(n, 5, 77, count, 0.02, 0.01, 0.03)
+    assert np.array_equal(ex[:, :words], want_x) and np.array_equal(ez[:, :words], want_z)
+    assert not ex[:, words:].any() and not ez[:, words:].any()
+    ex_buf.free(), ez_buf.free()
 
 
 def test_monte_carlo_steane_config2(steane_h):
