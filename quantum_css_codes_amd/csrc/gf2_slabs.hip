@@ -33,6 +33,7 @@
 #define REC_SLOTS 32                          // 16-bit slots per record: count + 31 columns
 #define REC_OVER 0xFFu                        // count byte of a sample that was finished by the slow routine
 #define REC_FLAG 0xFFFFu                      // its partial weights
+#define REC_STRAY 0xFF80u                     // | tile-local sample index: partial weight of a sample that has a column compact left out
 #define GAT_THREADS 1024
 #define GAT_WAVES 16
 #define SLAB_ROWS 512
@@ -71,6 +72,8 @@ struct CompactArgs {
     u64* hist;
     int64_t batch, lde;
     int r, n, ident_off, null_ord;
+    u64 skip_words;            // words whose few non-identity columns are left to the redo pass (bit w = word w)
+    unsigned int* redo_count;  // zeroed here for the combine kernel of this call (null: no redo pass)
     u64* clk;                  // debugging (GF2_GATHER_CLOCK): earliest entry / latest exit of the workgroups, else null
 };
 
@@ -146,7 +149,9 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 6 ? 4 : 3)) void sl
     if (lane < words) {
         amask = ~ident_mask(a.ident_off, a.r, lane);
         if (lane == words - 1 && (a.n & 63)) amask &= ~(~0ull << (a.n & 63));
+        if ((a.skip_words >> lane) & 1ull) amask = 0;
     }
+    if (a.redo_count && blockIdx.x == 0 && threadIdx.x == 0) *a.redo_count = 0;
     if (wave == 0) {
         const u64 act = __ballot(amask != 0);
         if (amask) wlist[__builtin_amdgcn_mbcnt_hi((unsigned int)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)act, 0u))] = lane;
@@ -358,6 +363,7 @@ struct GatherArgs {
     unsigned short* pw;        // nslabs x batch_pad partial weights
     int64_t batch, batch_pad, lde;   // batch_pad: stride of the partial weights; records exist for ceil(batch / 64) * 64 positions
     int tab_stride, nslabs, r, ident_off, null_ord;   // tab_stride: entries per row-part plane (= 4 mod 16)
+    int stray_n, stray_col[2];   // columns compact left out (hand-scheduled kernel only): a sample that has one is flagged REC_STRAY
     u64* clk;                  // debugging (GF2_GATHER_CLOCK): earliest entry / latest exit of the workgroups at [2], [3], else null
 };
 
@@ -654,6 +660,13 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
     }
     const unsigned int null_ent = (unsigned int)a.null_ord << 4;
     unsigned short* const pw = a.pw + (int64_t)slab * a.batch_pad;
+    // columns next to the identity block that compact left out sit in the identity dwords of one row part: the bits to test
+    unsigned int sm[4] = {0, 0, 0, 0};
+    for (int t = 0; t < a.stray_n; ++t) {
+        const unsigned int dc = (unsigned int)a.stray_col[t] >> 5;
+        if (dc >= dw0 && dc < dw0 + 4) sm[dc - dw0] |= 1u << (a.stray_col[t] & 31);
+    }
+    const bool has_stray = __ballot((sm[0] | sm[1] | sm[2] | sm[3]) != 0) != 0;      // uniform
     // raw buffer over the records: positions past the end read zeros
     const u64 rec_base = reinterpret_cast<u64>(a.rec);
     const i32x4 rsrc = {__builtin_amdgcn_readfirstlane((int)(unsigned int)rec_base),
@@ -713,6 +726,12 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         const bool flagged = (slot0 & 0xFFu) == REC_OVER;
         const bool valid = record_sample(pos, slot0) < (unsigned int)a.batch;
         const unsigned int c = flagged || !valid ? 0u : (slot0 & 0xFFu);
+        unsigned int stray = 0;
+        if (has_stray) {
+            stray = (I.x & sm[0]) | (I.y & sm[1]) | (I.z & sm[2]) | (I.w & sm[3]);
+            stray |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)stray, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+            stray |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)stray, 0x4E, 0xF, 0xF, true);     // quad_perm [2,3,0,1]
+        }
         unsigned int iw[5] = {I.x, I.y, I.z, I.w, 0u};
         if (EXTRA) {                                                // quad_perm [1,2,3,3]: lane p takes lane p + 1's first dword
             const unsigned int nb = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)I.x, 0xF9, 0xF, 0xF, false);
@@ -743,7 +762,7 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         unsigned int wt = __popc(X[0]) + __popc(X[1]) + __popc(X[2]) + __popc(X[3]);
         wt += __builtin_amdgcn_update_dpp(0u, wt, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
         wt += __builtin_amdgcn_update_dpp(0u, wt, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-        if (part == 0) pw[pos] = (unsigned short)(flagged || !valid ? REC_FLAG : wt);
+        if (part == 0) pw[pos] = (unsigned short)(flagged || !valid ? REC_FLAG : (stray ? REC_STRAY | ((slot0 >> 8) & 63u) : wt));
         // refill the buffers this step has emptied: exactly one store, one record load and one (EXTRA: two) identity loads
         // per step, in this order -- the wait counts above depend on it
         asm volatile("" ::: "memory");
@@ -768,12 +787,16 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
 // ---- combine ---------------------------------------------------------------------------------------------------------
 
 // Four consecutive record positions per lane and step: one 8-byte load per slab (at most four slabs: r <= 2048), all issued before
-// any is used.
+// any is used.  Positions a slab has flagged REC_STRAY go on the redo list instead of into the histogram.
 __global__ __launch_bounds__(1024) void slab_combine_kernel(const unsigned short* __restrict__ pw, int64_t positions, int64_t batch_pad,
-                                                          int nslabs, u64* __restrict__ hist, int nbins, u64* clk) {
+                                                           int nslabs, u64* __restrict__ hist, int nbins, unsigned int* redo_count,
+                                                           unsigned int* __restrict__ redo_list, u64* clk) {
     __shared__ unsigned int bins[SLAB_MAX_BINS];
+    __shared__ unsigned int redo_local[1024];                   // this workgroup's redo positions, handed over in one piece
+    __shared__ unsigned int redo_n, redo_base;
     if (clk && threadIdx.x == 0) atomicMin(&clk[0], (u64)wall_clock64());
     for (int i = threadIdx.x; i < nbins; i += blockDim.x) bins[i] = 0;
+    if (threadIdx.x == 0) redo_n = 0;
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
     for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; s < positions; s += stride) {
@@ -781,9 +804,10 @@ __global__ __launch_bounds__(1024) void slab_combine_kernel(const unsigned short
 #pragma unroll
         for (int k = 0; k < 4; ++k) four[k] = *reinterpret_cast<const u64*>(pw + (int64_t)(k < nslabs ? k : 0) * batch_pad + s);
         unsigned int w[4] = {0, 0, 0, 0};
-        bool skip[4];
+        bool skip[4], stray[4];
+        unsigned int local[4] = {0, 0, 0, 0};                      // tile-local sample index of a flagged position
 #pragma unroll
-        for (int t = 0; t < 4; ++t) skip[t] = false;            // finished and out-of-batch records carry REC_FLAG
+        for (int t = 0; t < 4; ++t) skip[t] = stray[t] = false;   // finished and out-of-batch records carry REC_FLAG
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k < nslabs) {
@@ -791,18 +815,58 @@ __global__ __launch_bounds__(1024) void slab_combine_kernel(const unsigned short
                 for (int t = 0; t < 4; ++t) {
                     const unsigned int v = (unsigned int)(four[k] >> (16 * t)) & 0xFFFFu;
                     skip[t] |= v == REC_FLAG;
+                    if ((v & 0xFFC0u) == REC_STRAY) {
+                        stray[t] = true;
+                        local[t] = v & 63u;
+                    }
                     w[t] += v;
                 }
             }
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
-            if (!skip[t]) atomicAdd(&bins[w[t]], 1u);
+        for (int t = 0; t < 4; ++t) {
+            if (skip[t]) continue;
+            if (stray[t]) {
+                const unsigned int sample = (unsigned int)((s + t) & ~(int64_t)63) + local[t];
+                const unsigned int at = atomicAdd(&redo_n, 1u);
+                if (at < 1024)
+                    redo_local[at] = sample;
+                else
+                    redo_list[atomicAdd(redo_count, 1u)] = sample;                       // more than the staging area holds
+            } else
+                atomicAdd(&bins[w[t]], 1u);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nbins; i += blockDim.x)
         if (bins[i]) atomicAdd(&hist[i], (u64)bins[i]);
+    const unsigned int mine = redo_n < 1024 ? redo_n : 1024;
+    if (mine) {                                                     // uniform
+        if (threadIdx.x == 0) redo_base = atomicAdd(redo_count, mine);
+        __syncthreads();
+        for (unsigned int i = threadIdx.x; i < mine; i += blockDim.x) redo_list[redo_base + i] = redo_local[i];
+    }
     if (clk && threadIdx.x == 0) atomicMax(&clk[1], (u64)wall_clock64());
+}
+
+// The samples on the redo list (they have a column that compact left out), one wavefront each, from the packed row.
+__global__ __launch_bounds__(256) void slab_redo_kernel(const u64* __restrict__ e, int64_t batch, int64_t lde,
+                                                        const unsigned int* __restrict__ redo_count,
+                                                        const unsigned int* __restrict__ redo_list, const uint32_t* __restrict__ ht, int r,
+                                                        int n, int ident_off, u64* __restrict__ hist) {
+    __shared__ unsigned int lists[4][SPARSE_LIST_CAP + 8];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned int count = *redo_count;
+    const SparseSide side = {ht, (int64_t)r, (int64_t)ident_off, nullptr, 0};
+    const int words = (n + 63) >> 6;
+    for (unsigned int i = blockIdx.x * 4 + wave; i < count; i += gridDim.x * 4) {
+        const int64_t sample = (int64_t)redo_list[i];
+        if (sample >= batch) continue;                              // uniform
+        const u64 ww = lane < words ? e[sample * lde + lane] : 0ull;
+        const unsigned int wt = sparse_component_weight(ww, side, n, lane, lists[wave]);
+        if (lane == 0) atomicAdd(&hist[wt], 1ull);
+    }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------
@@ -849,6 +913,50 @@ int gf2_build_slab_table(gf2_ctx* ctx, gf2_check* ck) {
 
 bool gf2_slabs_ok(const gf2_check* ck) { return ck->slab_tab_dev != nullptr; }
 
+// Words at the edges of the identity block whose few non-identity columns cost compact a whole scan round (H2 of a CSS code
+// with k logical qubits has r1 + k non-identity columns: k beyond the 32 words of H = [A | I | c]).  They may be left out
+// of the records when (1) leaving them out saves a round, (2) they are at most two columns, and (3) every one of them lies
+// in an identity dword that the hand-scheduled gather kernel loads anyway: that kernel flags the samples that have such a
+// column (0.7 % per column at p = 0.01) and the redo kernel computes those from the packed row.
+struct StrayPlan {
+    u64 skip_words;
+    int n_cols, col[2];
+};
+
+static int non_identity_words(const gf2_check* ck, u64 skip) {
+    int nw = 0;
+    for (int64_t wd = 0; wd < gf2_words(ck->n); ++wd) {
+        const int64_t lo = wd * 64, hi = lo + 64 < ck->n ? lo + 64 : ck->n;
+        const bool inside = ck->ident_off >= 0 && lo >= ck->ident_off && hi <= ck->ident_off + ck->r;
+        nw += (inside || ((skip >> wd) & 1ull)) ? 0 : 1;
+    }
+    return nw;
+}
+
+static StrayPlan plan_stray(const gf2_check* ck) {
+    StrayPlan none = {0, 0, {0, 0}}, plan = none;
+    if (ck->ident_off < 0 || ck->n > 4096 || getenv("GF2_NO_REDO") != nullptr) return none;
+    const int64_t lo = ck->ident_off, hi = ck->ident_off + ck->r;           // identity columns [lo, hi)
+    const int64_t first_dw = lo >> 5, last_dw = first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32);
+    int64_t cand[2][2] = {{(lo >> 6) * 64, lo}, {hi, ((hi >> 6) + 1) * 64 < ck->n ? ((hi >> 6) + 1) * 64 : ck->n}};
+    for (int side = 0; side < 2; ++side) {
+        const int64_t c0 = cand[side][0], c1 = cand[side][1];              // non-identity columns of the edge word
+        if ((side == 0 && (lo & 63) == 0) || (side == 1 && ((hi & 63) == 0 || hi >= ck->n))) continue;
+        if (c1 - c0 < 1 || plan.n_cols + (c1 - c0) > 2) continue;
+        bool visible = true;
+        for (int64_t c = c0; c < c1; ++c) visible = visible && (c >> 5) >= first_dw && (c >> 5) < last_dw;
+        if (!visible) continue;
+        // the word must not hold non-identity columns on its other side too (r < 64)
+        if ((side == 0 ? hi : lo) > (c0 >> 6) * 64 && (side == 0 ? hi : lo) < (c0 >> 6) * 64 + 64 && ck->r < 64) continue;
+        for (int64_t c = c0; c < c1; ++c) plan.col[plan.n_cols++] = (int)c;
+        plan.skip_words |= 1ull << (c0 >> 6);
+    }
+    if (!plan.n_cols) return none;
+    const int rounds_all = (CMP_SUB * non_identity_words(ck, 0) + 63) / 64;
+    const int rounds_cut = (CMP_SUB * non_identity_words(ck, plan.skip_words) + 63) / 64;
+    return rounds_cut < rounds_all ? plan : none;
+}
+
 // Weight histogram of batch resident sample-major errors (hist: r + 1 bins, accumulated into).
 int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde,
                        uint64_t* hist_dev, hipStream_t stream, int ws_slot) {
@@ -865,10 +973,12 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
     }
     const int64_t pass = batch < SLAB_MAX_BATCH ? batch : SLAB_MAX_BATCH;
     const int64_t pad = gf2_cdiv(pass, 64) * 64;
-    const size_t rec_bytes = (size_t)pad * 64, pw_bytes = (size_t)ck->nslabs512 * pad * 2;
-    GF2_TRY(gf2_ws_reserve(ctx, ws_slot, rec_bytes + pw_bytes));
+    const size_t rec_bytes = (size_t)pad * 64, pw_bytes = (size_t)ck->nslabs512 * pad * 2, redo_bytes = (size_t)pad * 4 + 256;
+    GF2_TRY(gf2_ws_reserve(ctx, ws_slot, rec_bytes + pw_bytes + redo_bytes));
     u32x4* rec = (u32x4*)ctx->ws[ws_slot];
     unsigned short* pw = (unsigned short*)((char*)ctx->ws[ws_slot] + rec_bytes);
+    unsigned int* redo_count = (unsigned int*)((char*)ctx->ws[ws_slot] + rec_bytes + pw_bytes);
+    unsigned int* redo_list = redo_count + 64;
     for (int64_t first = 0; first < batch; first += pass) {
         const int64_t count = batch - first < pass ? batch - first : pass;
         const uint64_t* e = e_dev + first * lde;
@@ -878,6 +988,14 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
             GF2_HIP(hipMalloc((void**)&clk_dev, 64));
             GF2_HIP(hipMemcpy(clk_dev, init, 48, hipMemcpyHostToDevice));
         }
+        // the hand-scheduled gather kernel needs every slab's identity words to be whole 16-byte pieces inside the row
+        const int64_t first_dw = ck->ident_off >= 0 ? ck->ident_off >> 5 : 0;
+        const bool fast = ck->ident_off >= 0 && (lde & 1) == 0 && (reinterpret_cast<uintptr_t>(e) & 15) == 0 &&
+                          (first_dw & 3) == 0 && first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) <= lde * 2 &&
+                          getenv("GF2_GATHER_GENERIC") == nullptr;
+        StrayPlan stray = {0, 0, {0, 0}};
+        if (fast) stray = plan_stray(ck);
+
         CompactArgs ca;
         ca.clk = clk_dev;
         ca.e = (const u64*)e;
@@ -890,16 +1008,12 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
         ca.n = (int)ck->n;
         ca.ident_off = (int)ck->ident_off;
         ca.null_ord = ck->slab_null;
+        ca.skip_words = stray.skip_words;
+        ca.redo_count = redo_count;
         int64_t cblocks = gf2_cdiv(gf2_cdiv(count, 64), CMP_WAVES);
         // rounds per sub-pass: ceil(8 * words with non-identity columns / 64); workgroups per CU as the variant's registers allow
         {
-            int nw = 0;
-            for (int64_t wd = 0; wd < gf2_words(ck->n); ++wd) {
-                const int64_t lo = wd * 64, hi = lo + 64 < ck->n ? lo + 64 : ck->n;
-                const bool inside = ck->ident_off >= 0 && lo >= ck->ident_off && hi <= ck->ident_off + ck->r;
-                nw += inside ? 0 : 1;
-            }
-            const int rounds = (CMP_SUB * nw + 63) / 64;
+            const int rounds = (CMP_SUB * non_identity_words(ck, stray.skip_words) + 63) / 64;
             const int per_cu = rounds <= 4 ? 5 : (rounds <= 6 ? 4 : 3);
             if (cblocks > (int64_t)ctx->num_cus * per_cu) cblocks = (int64_t)ctx->num_cus * per_cu;
             const dim3 cgrid((unsigned)cblocks), cblock(CMP_THREADS);
@@ -927,16 +1041,14 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
         ga.r = (int)ck->r;
         ga.ident_off = (int)ck->ident_off;
         ga.null_ord = ck->slab_null;
+        ga.stray_n = stray.n_cols;
+        ga.stray_col[0] = stray.col[0];
+        ga.stray_col[1] = stray.col[1];
         ga.clk = clk_dev;
         int64_t shares = ctx->num_cus / ck->nslabs512;
         const int64_t max_shares = gf2_cdiv(gf2_cdiv(count, 16), GAT_WAVES);
         if (shares > max_shares) shares = max_shares;
         if (shares < 1) shares = 1;
-        // the hand-scheduled variant needs every slab's identity words to be whole 16-byte pieces inside the row
-        const int64_t first_dw = ck->ident_off >= 0 ? ck->ident_off >> 5 : 0;
-        const bool fast = ck->ident_off >= 0 && (lde & 1) == 0 && (reinterpret_cast<uintptr_t>(e) & 15) == 0 &&
-                          (first_dw & 3) == 0 && first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) <= lde * 2 &&
-                          getenv("GF2_GATHER_GENERIC") == nullptr;
         const dim3 ggrid((unsigned)(shares * ck->nslabs512));
         if (fast && (ck->ident_off & 31) != 0)
             hipLaunchKernelGGL(slab_gather_fast_kernel<true>, ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
@@ -952,8 +1064,14 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
         const int64_t mb_cap = mb_env ? atoi(mb_env) : 128;
         if (mblocks > mb_cap) mblocks = mb_cap;
         hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3(1024), 0, stream, pw, gf2_cdiv(count, 64) * 64, pad,
-                           ck->nslabs512, (u64*)hist_dev, nbins, clk_dev ? clk_dev + 4 : nullptr);
+                           ck->nslabs512, (u64*)hist_dev, nbins, redo_count, redo_list, clk_dev ? clk_dev + 4 : nullptr);
         GF2_HIP(hipGetLastError());
+        if (stray.n_cols) {
+            hipLaunchKernelGGL(slab_redo_kernel, dim3((unsigned)ctx->num_cus * 8), dim3(256), 0, stream, (const u64*)e, count, lde,
+                               (const unsigned int*)redo_count, (const unsigned int*)redo_list, ck->ht_dev,
+                               (int)ck->r, (int)ck->n, (int)ck->ident_off, (u64*)hist_dev);
+            GF2_HIP(hipGetLastError());
+        }
         if (clk_dev) {
             u64 c[6];
             GF2_HIP(hipStreamSynchronize(stream));
@@ -973,5 +1091,5 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
 int gf2_slabs_reserve(gf2_ctx* ctx, const gf2_check* ck, int64_t batch, int ws_slot) {
     const int64_t pass = batch < SLAB_MAX_BATCH ? batch : SLAB_MAX_BATCH;
     const int64_t pad = gf2_cdiv(pass, 64) * 64;
-    return gf2_ws_reserve(ctx, ws_slot, (size_t)pad * 64 + (size_t)ck->nslabs512 * pad * 2);
+    return gf2_ws_reserve(ctx, ws_slot, (size_t)pad * 64 + (size_t)ck->nslabs512 * pad * 2 + (size_t)pad * 4 + 256);
 }

@@ -728,6 +728,36 @@ def test_syndrome_slab_pipeline(case, ctx, monkeypatch):
     assert np.array_equal(hist2.download((r + 1,), np.uint64), want)
 
 
+@pytest.mark.parametrize("case", [(2047, 4096, 2048, 3000, 0.007, None), (2046, 4096, 2048, 1500, 0.01, None),
+                                  (2047, 4096, 2049, 1500, 0.007, None), (2047, 4096, 2048, 700, 0.004, 4095),
+                                  (1023, 2048, 1024, 2100, 0.01, None), (2045, 4096, 2048, 500, 0.01, None)])
+def test_slab_pipeline_columns_left_to_the_redo_pass(case, ctx, monkeypatch):
+    # a check with one or two non-identity columns next to the identity block (H2 of a CSS code with k = 1, 2): compact leaves
+    # their word out, the gather kernel flags the samples that have them and the redo kernel computes those from the row;
+    # three columns (last case) stay in the records.  Same histogram with the redo pass switched off and from the oracle.
+    r, n, ioff, batch, density, all_set = case
+    rng = np.random.default_rng(r + n + batch)
+    hm = rng.integers(0, 2, (r, n))
+    hm[:, ioff:ioff + r] = np.identity(r, dtype=int)
+    em = (rng.random((batch, n)) < density).astype(np.uint8)
+    if all_set is not None:
+        em[:, all_set] = 1                                     # every sample goes through the redo pass
+    em[5] = (rng.random(n) < 0.03).astype(np.uint8)            # beyond a record's capacity: finished by compact
+    h, e = _native.pack_rows(hm), _native.pack_rows(em)
+    chk = ctx.check_create(h, r, n)
+    lde = e.shape[1]
+    e_buf = ctx.alloc(e.nbytes).upload(e)
+    want = c_oracle.histogram(c_oracle.syndrome_batch(h, r, n, e, batch), batch, r, 1, r + 1)
+    monkeypatch.setenv("GF2_SPARSE_SLABS", "1")
+    hist = ctx.alloc((r + 1) * 8).zero()
+    ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist, r + 1)
+    assert np.array_equal(hist.download((r + 1,), np.uint64), want)
+    monkeypatch.setenv("GF2_NO_REDO", "1")
+    hist2 = ctx.alloc((r + 1) * 8).zero()
+    ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist2, r + 1)
+    assert np.array_equal(hist2.download((r + 1,), np.uint64), want)
+
+
 def test_syndrome_slab_pipeline_default_route_large_batch(ctx, monkeypatch):
     # above the batch threshold the histogram-only call takes the slab pipeline by itself (64 sample shares per slab,
     # XCD-grouped); same histogram as the column-gather kernel and as the dense table kernel's syndromes
