@@ -187,11 +187,14 @@ int gf2_syndrome_batch(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, in
 int gf2_syndrome_dev(gf2_ctx* ctx, const gf2_check* check, const uint64_t* e_dev, int64_t batch, int64_t lde,
                      int layout, uint64_t* s_dev, int64_t lds);
 
-/* Sparse-error path: work proportional to the weight of each error (one wavefront per sample XORs the
- * transposed check's column for every set bit).  Sample-major errors (batch x lde).  Produces the sample-major
- * syndromes (s_dev, batch x lds; may be null) and/or accumulates the syndrome-weight histogram (hist_dev with
- * r+1 uint64 bins; may be null) without materialising the syndromes.  Identical results to gf2_syndrome_dev;
- * faster when errors are sparse (DESIGN.md gives the crossover).  Fails for small checks (n, r <= 64) and r > 8192. */
+/* Sparse-error path: work proportional to the weight of each error.  Sample-major errors (batch x lde).  Produces the
+ * sample-major syndromes (s_dev, batch x lds; may be null) and/or accumulates the syndrome-weight histogram (hist_dev
+ * with r+1 uint64 bins; may be null) without materialising the syndromes.  Identical results to gf2_syndrome_dev;
+ * faster when errors are sparse (DESIGN.md gives the crossover).  Fails for small checks (n, r <= 64) and r > 8192.
+ * Three implementations behind it: histogram-only batches of at least 32768 samples on a check
+ * with r <= 2048 and n - r <= 2400 take the LDS row-slab pipeline (compact -> gather -> combine, plus a redo pass for
+ * columns left out of the records); checks with n <= 512 and r <= 256 the lane-per-sample kernel; everything else one
+ * wavefront per sample gathering columns of the transposed check from L2. */
 int gf2_syndrome_sparse_dev(gf2_ctx* ctx, const gf2_check* check, const uint64_t* e_dev, int64_t batch, int64_t lde,
                             uint64_t* s_dev, int64_t lds, uint64_t* hist_dev, int64_t nbins);
 
