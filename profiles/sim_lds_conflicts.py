@@ -73,3 +73,39 @@ def run_h2():
                 tot+=c; n+=L
     return tot/n
 print('H2 greedy class pattern (k+s)%4:', run_h2())
+
+def run_block_local():
+    """Reordering only inside each block of four slots: slot 4b + i prefers class (i + s) mod 4."""
+    tot=0; n=0
+    for t in range(NT):
+        cnt=rng.binomial(2048,0.02/3,64)
+        cols=[rng.choice(2048,c,replace=False) for c in cnt]
+        idx=np.argsort(cnt,kind='stable')
+        for q in range(4):
+            recs=[cols[i] for i in idx[16*q:16*q+16]]
+            mx=max(len(r) for r in recs)
+            nb=(mx+1+3)//4*4
+            for g in groups:
+                lists=[]
+                for s,ri in enumerate(g):
+                    full=np.full(nb,-1); full[1:1+len(recs[ri])]=recs[ri]     # slot 0 = count
+                    out=full.copy()
+                    for b in range(nb//4):
+                        blk=[x for x in full[4*b:4*b+4]]
+                        fixed0 = (b==0)
+                        elems=[x for x in (blk[1:] if fixed0 else blk) if x>=0]
+                        slots=[i for i in range(4) if not (fixed0 and i==0)]
+                        res={i:-1 for i in slots}
+                        rest=[]
+                        for x in elems:
+                            want=[i for i in slots if res[i]<0 and (i+s)%4==x%4]
+                            if want: res[want[0]]=x
+                            else: rest.append(x)
+                        for x in rest:
+                            free=[i for i in slots if res[i]<0]; res[free[0]]=x
+                        for i in slots: out[4*b+i]=res[i]
+                    lists.append(out[1:])
+                c,L=cycles(lists,lambda o:o%4)
+                tot+=c; n+=L
+    return tot/n
+print('block-local reorder:', run_block_local())

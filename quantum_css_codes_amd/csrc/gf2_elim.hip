@@ -677,12 +677,18 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_kernel(u64* __restrict
             x[u] = (d[u] && word_live && !from_zero) ? a[row * ld + cw0 + lane] : 0ull;
         }
 #pragma unroll 1
-        for (int g = 0; g < 16; ++g) {                                 // groups outside, rows inside: 8 reads in flight
+        for (int g = 0; g < 16; g += 2) {                              // group pairs outside, rows inside: 16 reads in flight
             const unsigned int goff = (unsigned int)g * 8192u;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const unsigned int soff = goff + (unsigned int)((d[u] >> (4 * g)) & 15ull) * 512u;   // scalar
-                x[u] ^= *(lds_u64_ptr)(uintptr_t)(lane8 + soff);
+                const unsigned int soff0 = goff + (unsigned int)((d[u] >> (4 * g)) & 15ull) * 512u;             // scalar
+                const unsigned int soff1 = goff + 8192u + (unsigned int)((d[u] >> (4 * g + 4)) & 15ull) * 512u;
+                const u64 t0 = *(lds_u64_ptr)(uintptr_t)(lane8 + soff0), t1 = *(lds_u64_ptr)(uintptr_t)(lane8 + soff1);
+                // v_bitop3_b32 with truth table 0x96: a three-way XOR per dword
+                const unsigned int lo = __builtin_amdgcn_bitop3_b32((unsigned int)x[u], (unsigned int)t0, (unsigned int)t1, 0x96);
+                const unsigned int hi = __builtin_amdgcn_bitop3_b32((unsigned int)(x[u] >> 32), (unsigned int)(t0 >> 32),
+                                                                    (unsigned int)(t1 >> 32), 0x96);
+                x[u] = ((u64)hi << 32) | lo;
             }
         }
 #pragma unroll
