@@ -3,6 +3,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <time.h>
+
 #include "gf2_internal.h"
 
 static thread_local char g_error[512] = "";
@@ -12,6 +14,24 @@ void gf2_set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_error, sizeof(g_error), fmt, ap);
     va_end(ap);
+}
+
+// Waits for a stream.  hipStreamSynchronize blocks on an interrupt after a short poll and was seen to wake up milliseconds
+// late (a 12 ms gf2_mc_run returned after 20 ms every other call): poll hipStreamQuery for the first 50 ms instead, then block.
+int gf2_stream_wait(hipStream_t stream) {
+    timespec t0, t;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned int spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(stream);
+        if (q == hipSuccess) return GF2_OK;
+        if (q != hipErrorNotReady) GF2_HIP(q);
+        if ((spins & 63u) == 63u) {
+            clock_gettime(CLOCK_MONOTONIC, &t);
+            if ((t.tv_sec - t0.tv_sec) * 1000000000ll + (t.tv_nsec - t0.tv_nsec) > 50000000ll) break;
+        }
+    }
+    GF2_HIP(hipStreamSynchronize(stream));
+    return GF2_OK;
 }
 
 extern "C" {
@@ -85,7 +105,7 @@ int gf2_ctx_destroy(gf2_ctx* ctx) {
 int gf2_ctx_sync(gf2_ctx* ctx) {
     if (!ctx) GF2_FAIL(GF2_E_ARG, "gf2_ctx_sync: null context");
     GF2_TRY(gf2_ctx_activate(ctx));
-    GF2_HIP(hipStreamSynchronize(ctx->stream));
+    GF2_TRY(gf2_stream_wait(ctx->stream));
     return GF2_OK;
 }
 
@@ -129,8 +149,9 @@ int gf2_d2h(gf2_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
     if (!ctx || ((!host_dst || !dev_src) && bytes)) GF2_FAIL(GF2_E_ARG, "gf2_d2h: null argument");
     GF2_TRY(gf2_ctx_activate(ctx));
     if (bytes) {
+        GF2_TRY(gf2_stream_wait(ctx->stream));          // a copy to pageable memory waits for the stream first: do it by polling
         GF2_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-        GF2_HIP(hipStreamSynchronize(ctx->stream));
+        GF2_TRY(gf2_stream_wait(ctx->stream));
     }
     return GF2_OK;
 }

@@ -100,6 +100,7 @@ struct gf2_check {
     uint64_t rows_small[64];
 };
 
+int gf2_stream_wait(hipStream_t stream);            // polls, then blocks (gf2_ctx.hip)
 int gf2_build_columns(gf2_ctx* ctx, gf2_check* ck);
 int gf2_build_slab_table(gf2_ctx* ctx, gf2_check* ck);
 int gf2_build_lane_table(gf2_ctx* ctx, gf2_check* ck);
