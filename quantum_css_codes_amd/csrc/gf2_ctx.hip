@@ -167,6 +167,7 @@ int gf2_timer_stop(gf2_ctx* ctx, float* elapsed_ms_out) {
     if (!ctx || !elapsed_ms_out) GF2_FAIL(GF2_E_ARG, "gf2_timer_stop: null argument");
     GF2_TRY(gf2_ctx_activate(ctx));
     GF2_HIP(hipEventRecord(ctx->t1, ctx->stream));
+    GF2_TRY(gf2_stream_wait(ctx->stream));              // polled (see gf2_stream_wait); the event is then complete
     GF2_HIP(hipEventSynchronize(ctx->t1));
     GF2_HIP(hipEventElapsedTime(elapsed_ms_out, ctx->t0, ctx->t1));
     return GF2_OK;
