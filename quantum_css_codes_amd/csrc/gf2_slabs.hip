@@ -631,8 +631,22 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         share = blockIdx.x / a.nslabs;
     }
     {
+        // the slab's table: 9 loads per lane in flight (2400 columns x 4 parts = 9.4 rounds of 1024 lanes), then the LDS stores
         const u32x4* src = a.tab + (int64_t)slab * a.tab_stride * 4;
-        for (int v = threadIdx.x; v < a.tab_stride * 4; v += GAT_THREADS) reinterpret_cast<u32x4*>(lds)[v] = src[v];
+        const int total = a.tab_stride * 4;
+        for (int v0 = threadIdx.x; v0 < total; v0 += 9 * GAT_THREADS) {
+            u32x4 t[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int v = v0 + k * GAT_THREADS;
+                t[k] = src[v < total ? v : v0];
+            }
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int v = v0 + k * GAT_THREADS;
+                if (v < total) reinterpret_cast<u32x4*>(lds)[v] = t[k];
+            }
+        }
     }
     // Steps are handed out from a counter behind the table.  The SIMD arbiter favours its oldest wavefront: with a fixed split the
     // four wavefronts of a SIMD finish one after the other (the first after 55 % of the kernel's duration) and the last
