@@ -297,8 +297,12 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
     // Sparse-error pipeline: when few bits are set per error the column kernel wins: sampler writes
     // sample-major errors, the sparse kernel accumulates the weight histograms directly, no syndromes stored.
     const double dens = (p_x + p_y > p_z + p_y ? p_x + p_y : p_z + p_y) * (double)n;
+    // mid-size checks (n <= 512, r <= 256): sampler, then the lane-per-sample kernel per component on one stream (the serial
+    // path below) -- 3.0e10 / 1.7e10 / 4.0e9 samples/s at n = 127 / 255 / 511 against 8.0e9 / 6.5e9 / 2.8e9 through the slab
+    // pipelines and 2.8e9 / 2.3e9 / 2.0e9 with the sampler fused into the column-gather kernel
+    const bool lanes = gf2_lane_ok(c1) && gf2_lane_ok(c2);
     if (mode == GF2_HIST_WEIGHT && dens <= 160.0 && gf2_slabs_ok(c1) && gf2_slabs_ok(c2) && getenv("GF2_MC_DENSE") == nullptr &&
-        getenv("GF2_MC_UNFUSED") == nullptr && getenv("GF2_MC_FUSED") == nullptr && count >= 65536) {
+        getenv("GF2_MC_UNFUSED") == nullptr && getenv("GF2_MC_FUSED") == nullptr && count >= 65536 && !lanes) {
         // Three streams: the sampler draws chunk k + 1 on the context's stream while the LDS-slab pipelines of the two
         // components work on chunk k on the two side streams (double-buffered errors; events carry the hand-overs).
         const int64_t lde_s = gf2_words(n);
@@ -349,7 +353,7 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
         return GF2_OK;
     }
     if (mode == GF2_HIST_WEIGHT && dens <= 160.0 && gf2_mc_sparse_fused_ok(c1, c2) && getenv("GF2_MC_DENSE") == nullptr &&
-        getenv("GF2_MC_UNFUSED") == nullptr) {
+        getenv("GF2_MC_UNFUSED") == nullptr && (!lanes || getenv("GF2_MC_FUSED") != nullptr)) {
         // one kernel: every lane draws its own error words, nothing but the histograms touches memory
         const size_t hzb = (size_t)nbins_z * 8, hxb = (size_t)nbins_x * 8;
         auto al2 = [](size_t v) { return (v + 255) & ~(size_t)255; };

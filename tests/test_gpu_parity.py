@@ -516,6 +516,27 @@ def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, monkeypatch):
         assert np.array_equal(got[0], piped[0]) and np.array_equal(got[1], piped[1])
 
 
+@pytest.mark.parametrize("case", [(127, 63, 64), (255, 127, 127), (511, 255, 250), (300, 100, 150)])
+def test_monte_carlo_mid_size_checks_take_the_lane_kernel(case, ctx, monkeypatch):
+    # n <= 512, r <= 256: gf2_mc_run draws dense rows and runs the lane-per-sample kernel per component; same histograms
+    # from the oracle, from the fused kernel and from the slab pipelines
+    n, r1, r2 = case
+    rng = np.random.default_rng(n)
+    hm1, hm2 = rng.integers(0, 2, (r1, n)), rng.integers(0, 2, (r2, n))
+    hm1[:, :r1] = np.identity(r1, dtype=int)
+    hm2[:, n - r2:] = np.identity(r2, dtype=int)
+    h1, h2 = _native.pack_rows(hm1), _native.pack_rows(hm2)
+    c1, c2 = ctx.check_create(h1, r1, n), ctx.check_create(h2, r2, n)
+    args = (77, 1000, 70001, 0.004, 0.003, 0.005, _native.HIST_WEIGHT)
+    got = ctx.mc_run(c1, c2, *args)
+    want = c_oracle.mc(h1, r1, h2, r2, n, 77, 1000, 70001, 0.004, 0.003, 0.005, 1)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    monkeypatch.setenv("GF2_MC_FUSED", "1")
+    fused = ctx.mc_run(c1, c2, *args)
+    monkeypatch.delenv("GF2_MC_FUSED")
+    assert np.array_equal(fused[0], want[0]) and np.array_equal(fused[1], want[1])
+
+
 # ---- table decode + logical-error tally -------------------------------------------------------------
 
 def test_logical_error_rates_vs_oracle(steane_h, rm15):
