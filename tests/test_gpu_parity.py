@@ -719,7 +719,11 @@ def test_normalize_with_a_column_swap_at_every_step(case, ctx):
                                   (1000, 3000, 37, 1100, 0.004), (300, 2500, None, 600, 0.005), (2048, 4000, 1952, 513, 0.007),
                                   (130, 777, 500, 2049, 0.03), (2048, 4096, 0, 64, 0.0), (1300, 3100, 1700, 900, 0.006),
                                   (200, 2000, None, 1000, 0.004), (1536, 3900, 2047, 300, 0.005), (512, 600, 88, 200, 0.02),
-                                  (200, 200, 0, 300, 0.05), (2048, 4096, 1024, 400, 0.006)])
+                                  (200, 200, 0, 300, 0.05), (2048, 4096, 1024, 400, 0.006),
+                                  # the hand-scheduled gather kernel (identity words = 16-byte pieces) away from the benchmark's
+                                  # shapes: fewer rows than a slab holds, a bit offset inside the dword, a slab cut by r
+                                  (1000, 3000, 1024, 1300, 0.005), (700, 2600, 1285, 2200, 0.006), (300, 1536, 1152, 900, 0.01),
+                                  (1500, 4096, 2560, 777, 0.006), (513, 2048, 1408, 1000, 0.008), (2040, 4096, 2051, 650, 0.007)])
 def test_syndrome_slab_pipeline(case, ctx, monkeypatch):
     # histogram-only calls take the LDS row-slab pipeline (compact -> gather -> combine) when the check qualifies; it must
     # agree with the oracle and with the column-gather kernel on sparse samples, on samples beyond the record capacity
