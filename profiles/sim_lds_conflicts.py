@@ -109,3 +109,42 @@ def run_block_local():
                 tot+=c; n+=L
     return tot/n
 print('block-local reorder:', run_block_local())
+
+def run_class_slots():
+    """What the compact kernel does: the first four columns of class q in slots q, q+4, q+8, q+12 (class 0: 4, 8, 12, 16), the
+    rest from slot 17 on, columns above slot c moved into the holes; sample s reads the slots of a block rotated by s."""
+    tot=0; n=0
+    for t in range(NT):
+        cnt=rng.binomial(2048,0.02/3,64)
+        cols=[rng.choice(2048,c,replace=False) for c in cnt]
+        idx=np.argsort(cnt,kind='stable')
+        for q in range(4):
+            recs=[cols[i] for i in idx[16*q:16*q+16]]
+            mx=max(len(r) for r in recs)
+            nb=(mx+1+3)//4*4
+            for g in groups:
+                lists=[]
+                for s,ri in enumerate(g):
+                    slots=np.full(40,-1); ncls=[0,0,0,0]; tail=0
+                    for x in recs[ri]:
+                        c=x%4
+                        if ncls[c]<4:
+                            k=4*ncls[c]+(c if c else 4); ncls[c]+=1
+                        else:
+                            k=17+tail; tail+=1
+                        slots[k]=x
+                    c=len(recs[ri])
+                    holes=[k for k in range(1,c+1) if slots[k]<0]
+                    extras=[k for k in range(39,c,-1) if slots[k]>=0]
+                    for h,e in zip(holes,extras):
+                        slots[h]=slots[e]; slots[e]=-1
+                    full=slots[:nb].copy()
+                    rot=np.full(nb,-1)
+                    for b in range(nb//4):
+                        for i in range(4):
+                            rot[4*b+i]=full[4*b+((i+s)%4)]
+                    lists.append(rot)
+                c2,L=cycles(lists,lambda o:o%4)
+                tot+=c2; n+=L
+    return tot/n
+print('class slots + hole filling + rotation (as built):', run_class_slots())
