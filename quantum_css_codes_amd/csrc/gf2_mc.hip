@@ -8,6 +8,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <time.h>
+
 #include "gf2_internal.h"
 
 #include "gf2_sampler.h"
@@ -306,7 +308,7 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
         // Three streams: the sampler draws chunk k + 1 on the context's stream while the LDS-slab pipelines of the two
         // components work on chunk k on the two side streams (double-buffered errors; events carry the hand-overs).
         const int64_t lde_s = gf2_words(n);
-        const int64_t chunk_s = 1ll << 20;
+        const int64_t chunk_s = 1ll << 21;
         auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t eb = (size_t)chunk_s * lde_s * 8, hzb = (size_t)nbins_z * 8, hxb = (size_t)nbins_x * 8;
         GF2_TRY(gf2_ws_reserve(ctx, 0, 4 * al(eb) + al(hzb) + al(hxb)));
@@ -327,6 +329,8 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
         GF2_TRY(gf2_dev_zero(ctx, dz, hzb));
         GF2_TRY(gf2_dev_zero(ctx, dx, hxb));
         int64_t k = 0;
+        timespec t_begin;
+        clock_gettime(CLOCK_MONOTONIC, &t_begin);
         for (int64_t done = 0; done < count; done += chunk_s, ++k) {
             const int64_t now = count - done < chunk_s ? count - done : chunk_s;
             const int b = (int)(k & 1);
@@ -344,12 +348,23 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
             GF2_HIP(hipEventRecord(done_z[b], ctx->side[0]));
             GF2_HIP(hipEventRecord(done_x[b], ctx->side[1]));
         }
+        timespec t_enqueued;
+        clock_gettime(CLOCK_MONOTONIC, &t_enqueued);
         for (int b = 0; b < 2 && b < k; ++b) {                     // join: the histograms are read on the context's stream
             GF2_HIP(hipStreamWaitEvent(ctx->stream, done_z[b], 0));
             GF2_HIP(hipStreamWaitEvent(ctx->stream, done_x[b], 0));
         }
         GF2_TRY(gf2_d2h(ctx, hist_z, dz, hzb));
+        timespec t_first;
+        clock_gettime(CLOCK_MONOTONIC, &t_first);
         GF2_TRY(gf2_d2h(ctx, hist_x, dx, hxb));
+        if (getenv("GF2_MC_TIMES")) {                              // diagnostic: where the host's time went
+            timespec t_second;
+            clock_gettime(CLOCK_MONOTONIC, &t_second);
+            auto ms = [](const timespec& a, const timespec& b) { return (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6; };
+            fprintf(stderr, "mc_run: enqueue %.2f ms, first d2h (waits for the GPU) %.2f ms, second d2h %.2f ms\n", ms(t_begin, t_enqueued),
+                    ms(t_enqueued, t_first), ms(t_first, t_second));
+        }
         return GF2_OK;
     }
     if (mode == GF2_HIST_WEIGHT && dens <= 160.0 && gf2_mc_sparse_fused_ok(c1, c2) && getenv("GF2_MC_DENSE") == nullptr &&
