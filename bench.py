@@ -182,11 +182,9 @@ class Path(object):
         assert int(self.hz.download((R1 + 1,), np.uint64).sum()) == self.batch
         if self.algo == "sparse":
             # the histogram-only route of the timed region (LDS-slab pipeline), forced onto the same 512-sample prefix
-            os.environ["GF2_SPARSE_SLABS"] = "1"
-            try:
+            from quantum_css_codes_amd import _native
+            with self.ctx.flags(_native.F_SPARSE_SLABS):
                 got_z, got_x = self.prefix_hist(512)
-            finally:
-                del os.environ["GF2_SPARSE_SLABS"]
             assert np.array_equal(got_z, want_z) and np.array_equal(got_x, want_x), "slab pipeline differs from the oracle"
 
     def free(self):
@@ -369,6 +367,8 @@ def main():
                     help="gloo lets several ranks share one GPU to rehearse the multi-process path (histograms are "
                          "then all-reduced on the host); the driver's runs use nccl = RCCL")
     ap.add_argument("--algo", choices=("sparse", "dense"), default="sparse")
+    ap.add_argument("--slab-pass-log2", type=int, default=None,
+                    help="samples per pass of the slab pipeline through its workspace (GF2_OPT_SLAB_PASS_LOG2)")
     ap.add_argument("--one-stream", action="store_true",
                     help="issue both components of a step on one HIP stream (default: H2.e_x goes to a second context)")
     args = ap.parse_args()
@@ -400,6 +400,9 @@ def main():
     first = rank * batch               # this rank's shard of the global sample stream: sample i = f(seed, i)
 
     ctx2 = None if args.one_stream else _native.Context(ctx.device)
+    for c in (ctx, ctx2):
+        if c is not None and args.slab_pass_log2 is not None:
+            c.set_option(_native.OPT_SLAB_PASS_LOG2, args.slab_pass_log2)
     path = Path(ctx, args.algo, chk1, chk2, batch, first, ctx2)
     if rank == 0:
         path.check_against_oracle(h1, h2, first)        # correctness of what is about to be timed
@@ -492,13 +495,10 @@ def main():
                     "one-stream and two-stream steps disagree"
                 single = {"value": 50 * batch / (s_ms / 1e3), "unit": "syndromes/s", "ms_per_step": s_ms / 50,
                           "roofline": roofline(plain, s_launch, s_n)}
-                os.environ["GF2_SPARSE_GATHER"] = "1"
-                try:
+                with ctx.flags(_native.F_SPARSE_GATHER):
                     g_ms, g_launch, g_n, _ = timed(ctx, plain, 10, 2)
                     assert np.array_equal(plain.hz.download((R1 + 1,), np.uint64), single_z * np.uint64(10)), \
                         "column-gather kernel and slab pipeline disagree"
-                finally:
-                    del os.environ["GF2_SPARSE_GATHER"]
                 plain.kernel = "syndrome_sparse_kernel"
                 gather = {"value": 10 * batch / (g_ms / 1e3), "unit": "syndromes/s", "ms_per_step": g_ms / 10,
                           "roofline": roofline(plain, g_launch, g_n)}

@@ -66,6 +66,31 @@ int gf2_ctx_create(int device, gf2_ctx** ctx_out);
 int gf2_ctx_destroy(gf2_ctx* ctx);
 int gf2_ctx_sync(gf2_ctx* ctx);
 
+/* Routing flags of a context.  Several entry points have more than one implementation behind them,
+ * all bit-identical; 0 (the default) leaves the choice to the library.  Tests and bench.py force a route with these; the
+ * library never reads the environment per call (gf2_ctx_create reads GF2_FLAGS once as the initial value). */
+#define GF2_F_SPARSE_GATHER        (1u << 0)   /* gf2_syndrome_sparse_dev: wavefront-per-sample column gather            */
+#define GF2_F_SPARSE_SLABS         (1u << 1)   /* gf2_syndrome_sparse_dev: LDS row-slab pipeline also for small batches  */
+#define GF2_F_NO_REDO              (1u << 2)   /* slab pipeline: no column is left to the redo pass                     */
+#define GF2_F_GATHER_GENERIC       (1u << 3)   /* slab pipeline: compiler-scheduled gather kernel                       */
+#define GF2_F_MC_UNFUSED           (1u << 4)   /* gf2_mc_run: sampler, then the syndrome calls, on one stream           */
+#define GF2_F_MC_DENSE             (1u << 5)   /* gf2_mc_run: dense table kernel whatever the error rate                */
+#define GF2_F_MC_FUSED             (1u << 6)   /* gf2_mc_run: sampler fused into the column-gather kernel               */
+#define GF2_F_MC_PIPELINE          (1u << 7)   /* gf2_mc_run on small codes: sampler + syndrome + histogram kernels     */
+#define GF2_F_RREF_SEQUENTIAL      (1u << 8)   /* gf2_rref*: one pivot per step                                         */
+#define GF2_F_RREF_NO_SMALL        (1u << 9)   /* gf2_rref*: no wavefront-per-matrix kernel                             */
+#define GF2_F_NORMALIZE_SEQUENTIAL (1u << 10)  /* gf2_normalize*: one pivot per step                                    */
+#define GF2_F_SAMPLER_GENERIC      (1u << 11)  /* gf2_sample_errors_dev: lane-per-word kernel                           */
+#define GF2_F_DIAG_CLOCKS          (1u << 12)  /* slab pipeline: print wall-clock stamps of its kernels to stderr       */
+#define GF2_F_DIAG_MC_TIMES        (1u << 13)  /* gf2_mc_run: print the host's phases to stderr                         */
+int gf2_ctx_set_flags(gf2_ctx* ctx, uint32_t flags);
+int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
+/* Tunables of a context (value < 0 restores the default). */
+#define GF2_OPT_SLAB_PASS_LOG2  0   /* slab pipeline: 2^k samples per pass through the workspace, 12 <= k <= 21 (default 21) */
+#define GF2_OPT_COMBINE_BLOCKS  1   /* slab pipeline: workgroups of the combine kernel (default 128)                      */
+#define GF2_OPT_COUNT           2
+int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value);
+
 /* Device memory and stream-ordered copies on the context's stream (copies are synchronous). */
 int gf2_dev_alloc(gf2_ctx* ctx, size_t bytes, void** dev_out);
 int gf2_dev_free(gf2_ctx* ctx, void* dev);

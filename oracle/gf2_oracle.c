@@ -3,9 +3,12 @@
  *
  * Plain-C, single-threaded restatement on packed words of the hot path of jimpo/quantum-css-codes, used
  * by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg to check libgf2hip.so at sizes
- * where the NumPy restatement (oracle/cpu_ref.py) would take minutes.  Parity status: PINNED -- the
- * functions that restate reference functions are checked against the reference-generated fixtures
- * (tests/test_oracle_golden.py::test_c_oracle_*) and against oracle/cpu_ref.py.
+ * where the NumPy restatement (oracle/cpu_ref.py) would take minutes.  Parity status: PINNED by the CPU suite --
+ * tests/test_oracle_golden.py::test_c_oracle_{rref,normalize,syndromes,full_size_digests,swap_columns} compare orc_rref,
+ * orc_normalize (matrices, swap lists, both error codes), orc_syndrome_batch, orc_histogram and orc_swap_columns with every
+ * array the reference itself produced (tests/golden/reference_golden.npz, incl. the three 2048 x 4096 SHA-256 digests);
+ * test_c_oracle_{nullspace,sampler,sampler_n4096,monte_carlo} and test_decode_tally_c_vs_numpy compare the build-defined
+ * pieces with oracle/cpu_ref.py (multi-word rows with a ragged last word included).
  *
  * Packed layout as in include/gf2hip.h: row-major uint64 words, column j at word j>>6 bit j&63.
  * Nothing here shares code with quantum_css_codes_amd/csrc.

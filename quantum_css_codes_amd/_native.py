@@ -4,6 +4,7 @@ ctypes binding of libgf2hip.so (include/gf2hip.h) and the packed-word helpers th
 There is no CPU fallback.  If the shared library is missing, or no gfx950 device is usable, the
 first compute call raises GF2Error -- the product never routes through oracle/ or NumPy arithmetic.
 """
+import contextlib
 import ctypes
 import os
 import threading
@@ -17,6 +18,11 @@ GF2_OK, GF2_E_ARG, GF2_E_COLUMNS, GF2_E_DEPENDENT, GF2_E_HIP, GF2_E_NOMEM, GF2_E
 LAYOUT_SAMPLE_MAJOR, LAYOUT_BIT_SLICED, LAYOUT_TILED = 0, 1, 2
 HIST_FULL, HIST_WEIGHT = 0, 1
 K_SYNDROME, K_HIST, K_SAMPLER, K_ELIM = 0, 1, 2, 3
+# routing flags of a context (GF2_F_* of include/gf2hip.h) and its tunables (GF2_OPT_*)
+(F_SPARSE_GATHER, F_SPARSE_SLABS, F_NO_REDO, F_GATHER_GENERIC, F_MC_UNFUSED, F_MC_DENSE, F_MC_FUSED, F_MC_PIPELINE,
+ F_RREF_SEQUENTIAL, F_RREF_NO_SMALL, F_NORMALIZE_SEQUENTIAL, F_SAMPLER_GENERIC, F_DIAG_CLOCKS,
+ F_DIAG_MC_TIMES) = (1 << k for k in range(14))
+OPT_SLAB_PASS_LOG2, OPT_COMBINE_BLOCKS = 0, 1
 
 
 class GF2Error(RuntimeError):
@@ -42,6 +48,9 @@ SIGNATURES = {
     "gf2_ctx_create": [ctypes.c_int, _pp],
     "gf2_ctx_destroy": [_p],
     "gf2_ctx_sync": [_p],
+    "gf2_ctx_set_flags": [_p, ctypes.c_uint32],
+    "gf2_ctx_get_flags": [_p, ctypes.POINTER(ctypes.c_uint32)],
+    "gf2_ctx_set_option": [_p, ctypes.c_int, _c_i64],
     "gf2_dev_alloc": [_p, ctypes.c_size_t, _pp],
     "gf2_dev_free": [_p, _p],
     "gf2_dev_zero": [_p, _p, ctypes.c_size_t],
@@ -300,6 +309,28 @@ class Context(object):
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    # -- routing ----------------------------------------------------------------------------------------
+    def get_flags(self):
+        out = ctypes.c_uint32(0)
+        check(lib().gf2_ctx_get_flags(self.handle, ctypes.byref(out)))
+        return int(out.value)
+
+    def set_flags(self, flags):
+        check(lib().gf2_ctx_set_flags(self.handle, int(flags)))
+
+    @contextlib.contextmanager
+    def flags(self, extra):
+        """`with ctx.flags(F_SPARSE_SLABS): ...` forces a route (GF2_F_*) for the calls inside."""
+        before = self.get_flags()
+        self.set_flags(before | int(extra))
+        try:
+            yield self
+        finally:
+            self.set_flags(before)
+
+    def set_option(self, option, value):
+        check(lib().gf2_ctx_set_option(self.handle, int(option), -1 if value is None else int(value)))
 
     # -- timing ---------------------------------------------------------------------------------------
     def timer_start(self):

@@ -34,6 +34,34 @@ int gf2_stream_wait(hipStream_t stream) {
     return GF2_OK;
 }
 
+// The context's streams and events.  On failure the caller destroys whatever was created (every handle starts out null).
+static int create_streams_and_events(gf2_ctx* ctx) {
+    GF2_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) GF2_HIP(hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
+    for (int k = 0; k < 7; ++k) GF2_HIP(hipEventCreateWithFlags(&ctx->side_ev[k], hipEventDisableTiming));
+    GF2_HIP(hipEventCreate(&ctx->t0));
+    GF2_HIP(hipEventCreate(&ctx->t1));
+    for (int i = 0; i < gf2_ctx::kProfSlots; ++i) {
+        GF2_HIP(hipEventCreate(&ctx->prof_ev[i][0]));
+        GF2_HIP(hipEventCreate(&ctx->prof_ev[i][1]));
+    }
+    return GF2_OK;
+}
+
+static void destroy_streams_and_events(gf2_ctx* ctx) {
+    for (int i = 0; i < gf2_ctx::kProfSlots; ++i) {
+        if (ctx->prof_ev[i][0]) (void)hipEventDestroy(ctx->prof_ev[i][0]);
+        if (ctx->prof_ev[i][1]) (void)hipEventDestroy(ctx->prof_ev[i][1]);
+    }
+    if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+    if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+    for (int k = 0; k < 7; ++k)
+        if (ctx->side_ev[k]) (void)hipEventDestroy(ctx->side_ev[k]);
+    for (int k = 0; k < 2; ++k)
+        if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+}
+
 extern "C" {
 
 int gf2_version(void) { return GF2_VERSION_NUMBER; }
@@ -69,16 +97,40 @@ int gf2_ctx_create(int device, gf2_ctx** ctx_out) {
     if (!ctx) GF2_FAIL(GF2_E_NOMEM, "gf2_ctx_create: out of host memory");
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
-    GF2_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    for (int k = 0; k < 2; ++k) GF2_HIP(hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
-    for (int k = 0; k < 7; ++k) GF2_HIP(hipEventCreateWithFlags(&ctx->side_ev[k], hipEventDisableTiming));
-    GF2_HIP(hipEventCreate(&ctx->t0));
-    GF2_HIP(hipEventCreate(&ctx->t1));
-    for (int i = 0; i < gf2_ctx::kProfSlots; ++i) {
-        GF2_HIP(hipEventCreate(&ctx->prof_ev[i][0]));
-        GF2_HIP(hipEventCreate(&ctx->prof_ev[i][1]));
+    for (int k = 0; k < GF2_OPT_COUNT; ++k) ctx->opt[k] = -1;
+    const char* env_flags = getenv("GF2_FLAGS");                    // read once, here: the initial routing flags
+    ctx->flags = env_flags ? (uint32_t)strtoul(env_flags, nullptr, 0) : 0u;
+    const int rc = create_streams_and_events(ctx);
+    if (rc != GF2_OK) {                                             // the message of the failing call stays in g_error
+        destroy_streams_and_events(ctx);
+        free(ctx);
+        return rc;
     }
     *ctx_out = ctx;
+    return GF2_OK;
+}
+
+int gf2_ctx_set_flags(gf2_ctx* ctx, uint32_t flags) {
+    if (!ctx) GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_flags: null context");
+    ctx->flags = flags;
+    return GF2_OK;
+}
+
+int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out) {
+    if (!ctx || !flags_out) GF2_FAIL(GF2_E_ARG, "gf2_ctx_get_flags: null argument");
+    *flags_out = ctx->flags;
+    return GF2_OK;
+}
+
+int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value) {
+    if (!ctx || option < 0 || option >= GF2_OPT_COUNT) GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: bad argument");
+    if (value >= 0) {
+        if (option == GF2_OPT_SLAB_PASS_LOG2 && (value < 12 || value > 21))
+            GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_SLAB_PASS_LOG2 must be in 12..21");
+        if (option == GF2_OPT_COMBINE_BLOCKS && (value < 1 || value > 65535))
+            GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_COMBINE_BLOCKS must be in 1..65535");
+    }
+    ctx->opt[option] = value < 0 ? -1 : value;
     return GF2_OK;
 }
 
@@ -89,15 +141,7 @@ int gf2_ctx_destroy(gf2_ctx* ctx) {
     for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(ctx->side[k]);
     for (int k = 0; k < 4; ++k)
         if (ctx->ws[k]) (void)hipFree(ctx->ws[k]);
-    for (int i = 0; i < gf2_ctx::kProfSlots; ++i) {
-        (void)hipEventDestroy(ctx->prof_ev[i][0]);
-        (void)hipEventDestroy(ctx->prof_ev[i][1]);
-    }
-    (void)hipEventDestroy(ctx->t0);
-    (void)hipEventDestroy(ctx->t1);
-    for (int k = 0; k < 7; ++k) (void)hipEventDestroy(ctx->side_ev[k]);
-    for (int k = 0; k < 2; ++k) (void)hipStreamDestroy(ctx->side[k]);
-    (void)hipStreamDestroy(ctx->stream);
+    destroy_streams_and_events(ctx);
     free(ctx);
     return GF2_OK;
 }

@@ -1122,7 +1122,7 @@ int gf2_rref_batch_dev(gf2_ctx* ctx, uint64_t* a_dev, int64_t batch, int64_t m, 
     if (m == 0 || n == 0) return gf2_dev_zero(ctx, rank_dev, (size_t)batch * 8);
     if (!a_dev) GF2_FAIL(GF2_E_ARG, "gf2_rref_batch_dev: null matrix");
     const int64_t cap = m < n ? m : n;
-    if (getenv("GF2_RREF_SEQUENTIAL") == nullptr && getenv("GF2_RREF_NO_SMALL") == nullptr && m <= 256 && ld <= 16 &&
+    if (!gf2_flag(ctx, GF2_F_RREF_SEQUENTIAL) && !gf2_flag(ctx, GF2_F_RREF_NO_SMALL) && m <= 256 && ld <= 16 &&
         gf2_cdiv(m, 64) * ld <= 32) {
         // small matrices: one wavefront each, rows in registers (RPL rows of LD words per lane, at most 64 registers)
 #define GF2_SMALL(RPL, LD) return launch_rref_small<RPL, LD>(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev)
@@ -1143,7 +1143,7 @@ int gf2_rref_batch_dev(gf2_ctx* ctx, uint64_t* a_dev, int64_t batch, int64_t m, 
         }
 #undef GF2_SMALL
     }
-    if (m < 0x7fffffffLL && batch <= 65535 && gf2_cdiv(m, 128) <= 65535 && getenv("GF2_RREF_SEQUENTIAL") == nullptr)
+    if (m < 0x7fffffffLL && batch <= 65535 && gf2_cdiv(m, 128) <= 65535 && !gf2_flag(ctx, GF2_F_RREF_SEQUENTIAL))
         return launch_rref_blocked(ctx, (u64*)a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
     return launch_eliminate(ctx, ELIM_RREF, (u64*)a_dev, batch, m, n, ld, 0, pivots_dev, cap, rank_dev, nullptr, nullptr,
                             nullptr);
@@ -1194,7 +1194,7 @@ int gf2_normalize_dev(gf2_ctx* ctx, uint64_t* h_dev, int64_t r, int64_t n, int64
     GF2_TRY(gf2_dev_zero(ctx, status_dev, 4));
     if (r == 0) return GF2_OK;
     if (!h_dev) GF2_FAIL(GF2_E_ARG, "gf2_normalize_dev: null matrix");
-    if (r > 8 * RB_THREADS || ld > ELIM_MAX_LD || getenv("GF2_NORMALIZE_SEQUENTIAL") != nullptr)
+    if (r > 8 * RB_THREADS || ld > ELIM_MAX_LD || gf2_flag(ctx, GF2_F_NORMALIZE_SEQUENTIAL))
         return launch_eliminate(ctx, ELIM_NORMALIZE, (u64*)h_dev, 1, r, n, ld, offset, nullptr, 0, nullptr, swaps_dev,
                                 nswaps_dev, status_dev);
     // blocked: panel -> update -> (single sequential step if the panel stalled); the host looks at the state every 8 rounds

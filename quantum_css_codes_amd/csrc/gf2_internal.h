@@ -59,7 +59,11 @@ struct gf2_ctx {
     // large dynamic-LDS opt-in (hipFuncSetAttribute) done for this context's device: [0] syndrome_tiled_kernel,
     // [1] rref_update_kernel, [2] slab_gather_kernel, [3] conjugate_kernel
     bool lds_optin[4];
+    // routing flags (GF2_F_*) and tunables (GF2_OPT_*, -1 = default): gf2_ctx_set_flags / gf2_ctx_set_option
+    uint32_t flags;
+    int64_t opt[GF2_OPT_COUNT];
 };
+static inline bool gf2_flag(const gf2_ctx* ctx, uint32_t f) { return (ctx->flags & f) != 0; }
 
 int gf2_ctx_activate(gf2_ctx* ctx);
 int gf2_ws_reserve(gf2_ctx* ctx, int slot, size_t bytes);

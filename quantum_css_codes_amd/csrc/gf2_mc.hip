@@ -239,7 +239,7 @@ int gf2_sample_errors_dev(gf2_ctx* ctx, int64_t n, uint64_t seed, int64_t first_
     if (layout == GF2_LAYOUT_TILED)
         hipLaunchKernelGGL(sampler_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (u64)seed, first_sample,
                            count, n, gf2_words(n), lde, total, th, ex_dev, ez_dev);
-    else if (lde <= 64 && gf2_words(n) >= 8 && getenv("GF2_SAMPLER_GENERIC") == nullptr) {
+    else if (lde <= 64 && gf2_words(n) >= 8 && !gf2_flag(ctx, GF2_F_SAMPLER_GENERIC)) {
         int64_t rblocks = gf2_cdiv(gf2_cdiv(count, SMP_BLOCK), SMP_WAVES);
         if (rblocks > (int64_t)ctx->num_cus * 8) rblocks = (int64_t)ctx->num_cus * 8;
         hipLaunchKernelGGL(sampler_rows_kernel, dim3((unsigned)rblocks), dim3(64 * SMP_WAVES), 0, ctx->stream, (u64)seed, first_sample,
@@ -270,7 +270,7 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
     GF2_TRY(gf2_ctx_activate(ctx));
 
     // Small codes: one fused kernel, nothing but the histograms touches memory.
-    if (c1->small && c2->small && c1->r <= 20 && c2->r <= 20 && n >= 1 && getenv("GF2_MC_PIPELINE") == nullptr) {
+    if (c1->small && c2->small && c1->r <= 20 && c2->r <= 20 && n >= 1 && !gf2_flag(ctx, GF2_F_MC_PIPELINE)) {
         const size_t hzb = (size_t)nbins_z * 8, hxb = (size_t)nbins_x * 8;
         auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
         GF2_TRY(gf2_ws_reserve(ctx, 0, al(hzb) + al(hxb)));
@@ -303,8 +303,8 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
     // path below) -- 3.0e10 / 1.7e10 / 4.0e9 samples/s at n = 127 / 255 / 511 against 8.0e9 / 6.5e9 / 2.8e9 through the slab
     // pipelines and 2.8e9 / 2.3e9 / 2.0e9 with the sampler fused into the column-gather kernel
     const bool lanes = gf2_lane_ok(c1) && gf2_lane_ok(c2);
-    if (mode == GF2_HIST_WEIGHT && dens <= 160.0 && gf2_slabs_ok(c1) && gf2_slabs_ok(c2) && getenv("GF2_MC_DENSE") == nullptr &&
-        getenv("GF2_MC_UNFUSED") == nullptr && getenv("GF2_MC_FUSED") == nullptr && count >= 65536 && !lanes) {
+    if (mode == GF2_HIST_WEIGHT && dens <= 160.0 && gf2_slabs_ok(c1) && gf2_slabs_ok(c2) && !gf2_flag(ctx, GF2_F_MC_DENSE) &&
+        !gf2_flag(ctx, GF2_F_MC_UNFUSED) && !gf2_flag(ctx, GF2_F_MC_FUSED) && count >= 65536 && !lanes) {
         // Three streams: the sampler draws chunk k + 1 on the context's stream while the LDS-slab pipelines of the two
         // components work on chunk k on the two side streams (double-buffered errors; events carry the hand-overs).
         const int64_t lde_s = gf2_words(n);
@@ -358,7 +358,7 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
         timespec t_first;
         clock_gettime(CLOCK_MONOTONIC, &t_first);
         GF2_TRY(gf2_d2h(ctx, hist_x, dx, hxb));
-        if (getenv("GF2_MC_TIMES")) {                              // diagnostic: where the host's time went
+        if (gf2_flag(ctx, GF2_F_DIAG_MC_TIMES)) {                              // diagnostic: where the host's time went
             timespec t_second;
             clock_gettime(CLOCK_MONOTONIC, &t_second);
             auto ms = [](const timespec& a, const timespec& b) { return (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6; };
@@ -367,8 +367,8 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
         }
         return GF2_OK;
     }
-    if (mode == GF2_HIST_WEIGHT && dens <= 160.0 && gf2_mc_sparse_fused_ok(c1, c2) && getenv("GF2_MC_DENSE") == nullptr &&
-        getenv("GF2_MC_UNFUSED") == nullptr && (!lanes || getenv("GF2_MC_FUSED") != nullptr)) {
+    if (mode == GF2_HIST_WEIGHT && dens <= 160.0 && gf2_mc_sparse_fused_ok(c1, c2) && !gf2_flag(ctx, GF2_F_MC_DENSE) &&
+        !gf2_flag(ctx, GF2_F_MC_UNFUSED) && (!lanes || gf2_flag(ctx, GF2_F_MC_FUSED))) {
         // one kernel: every lane draws its own error words, nothing but the histograms touches memory
         const size_t hzb = (size_t)nbins_z * 8, hxb = (size_t)nbins_x * 8;
         auto al2 = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -382,7 +382,7 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
         GF2_TRY(gf2_d2h(ctx, hist_x, dx, hxb));
         return GF2_OK;
     }
-    if (mode == GF2_HIST_WEIGHT && c1->ht_dev && c2->ht_dev && dens <= 160.0 && getenv("GF2_MC_DENSE") == nullptr) {
+    if (mode == GF2_HIST_WEIGHT && c1->ht_dev && c2->ht_dev && dens <= 160.0 && !gf2_flag(ctx, GF2_F_MC_DENSE)) {
         const int64_t lde_s = gf2_words(n);
         int64_t chunk_s = (int64_t)(2048ll << 20) / (2 * lde_s * 8);      // 2 GiB of packed errors per round trip
         if (chunk_s > count) chunk_s = count > 0 ? count : 1;

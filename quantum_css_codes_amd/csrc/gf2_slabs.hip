@@ -947,9 +947,9 @@ static int non_identity_words(const gf2_check* ck, u64 skip) {
     return nw;
 }
 
-static StrayPlan plan_stray(const gf2_check* ck) {
+static StrayPlan plan_stray(const gf2_ctx* ctx, const gf2_check* ck) {
     StrayPlan none = {0, 0, {0, 0}}, plan = none;
-    if (ck->ident_off < 0 || ck->n > 4096 || getenv("GF2_NO_REDO") != nullptr) return none;
+    if (ck->ident_off < 0 || ck->n > 4096 || gf2_flag(ctx, GF2_F_NO_REDO)) return none;
     const int64_t lo = ck->ident_off, hi = ck->ident_off + ck->r;           // identity columns [lo, hi)
     const int64_t first_dw = lo >> 5, last_dw = first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32);
     int64_t cand[2][2] = {{(lo >> 6) * 64, lo}, {hi, ((hi >> 6) + 1) * 64 < ck->n ? ((hi >> 6) + 1) * 64 : ck->n}};
@@ -971,6 +971,12 @@ static StrayPlan plan_stray(const gf2_check* ck) {
     return rounds_cut < rounds_all ? plan : none;
 }
 
+// Samples per pass through the workspace (records, partial weights, redo list).
+static int64_t slab_pass(const gf2_ctx* ctx, int64_t batch) {
+    const int64_t cap = ctx->opt[GF2_OPT_SLAB_PASS_LOG2] > 0 ? (1ll << ctx->opt[GF2_OPT_SLAB_PASS_LOG2]) : SLAB_MAX_BATCH;
+    return batch < cap ? batch : cap;
+}
+
 // Weight histogram of batch resident sample-major errors (hist: r + 1 bins, accumulated into).
 int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde,
                        uint64_t* hist_dev, hipStream_t stream, int ws_slot) {
@@ -985,7 +991,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
         ctx->lds_optin[2] = true;
     }
-    const int64_t pass = batch < SLAB_MAX_BATCH ? batch : SLAB_MAX_BATCH;
+    const int64_t pass = slab_pass(ctx, batch);
     const int64_t pad = gf2_cdiv(pass, 64) * 64;
     const size_t rec_bytes = (size_t)pad * 64, pw_bytes = (size_t)ck->nslabs512 * pad * 2, redo_bytes = (size_t)pad * 4 + 256;
     GF2_TRY(gf2_ws_reserve(ctx, ws_slot, rec_bytes + pw_bytes + redo_bytes));
@@ -997,7 +1003,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
         const int64_t count = batch - first < pass ? batch - first : pass;
         const uint64_t* e = e_dev + first * lde;
         u64* clk_dev = nullptr;
-        if (getenv("GF2_GATHER_CLOCK") != nullptr) {
+        if (gf2_flag(ctx, GF2_F_DIAG_CLOCKS)) {
             static const u64 init[6] = {~0ull, 0, ~0ull, 0, ~0ull, 0};
             GF2_HIP(hipMalloc((void**)&clk_dev, 64));
             GF2_HIP(hipMemcpy(clk_dev, init, 48, hipMemcpyHostToDevice));
@@ -1006,9 +1012,9 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
         const int64_t first_dw = ck->ident_off >= 0 ? ck->ident_off >> 5 : 0;
         const bool fast = ck->ident_off >= 0 && (lde & 1) == 0 && (reinterpret_cast<uintptr_t>(e) & 15) == 0 &&
                           (first_dw & 3) == 0 && first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) <= lde * 2 &&
-                          getenv("GF2_GATHER_GENERIC") == nullptr;
+                          !gf2_flag(ctx, GF2_F_GATHER_GENERIC);
         StrayPlan stray = {0, 0, {0, 0}};
-        if (fast) stray = plan_stray(ck);
+        if (fast) stray = plan_stray(ctx, ck);
 
         CompactArgs ca;
         ca.clk = clk_dev;
@@ -1074,8 +1080,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
 
         // few large workgroups: every workgroup ends with one global atomic per non-empty bin
         int64_t mblocks = gf2_cdiv(count, 4096);
-        const char* mb_env = getenv("GF2_COMBINE_BLOCKS");
-        const int64_t mb_cap = mb_env ? atoi(mb_env) : 128;
+        const int64_t mb_cap = ctx->opt[GF2_OPT_COMBINE_BLOCKS] > 0 ? ctx->opt[GF2_OPT_COMBINE_BLOCKS] : 128;
         if (mblocks > mb_cap) mblocks = mb_cap;
         hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3(1024), 0, stream, pw, gf2_cdiv(count, 64) * 64, pad,
                            ck->nslabs512, (u64*)hist_dev, nbins, redo_count, redo_list, clk_dev ? clk_dev + 4 : nullptr);
@@ -1103,7 +1108,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
 // Grows the workspace of `ws_slot` for batches of this size now (growing synchronises the streams), so that a later
 // gf2_syndrome_slabs on a side stream does not.
 int gf2_slabs_reserve(gf2_ctx* ctx, const gf2_check* ck, int64_t batch, int ws_slot) {
-    const int64_t pass = batch < SLAB_MAX_BATCH ? batch : SLAB_MAX_BATCH;
+    const int64_t pass = slab_pass(ctx, batch);
     const int64_t pad = gf2_cdiv(pass, 64) * 64;
     return gf2_ws_reserve(ctx, ws_slot, (size_t)pad * 64 + (size_t)ck->nslabs512 * pad * 2 + (size_t)pad * 4 + 256);
 }

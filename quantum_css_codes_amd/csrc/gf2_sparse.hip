@@ -329,10 +329,10 @@ int gf2_syndrome_sparse_dev(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_SYNDROME));
     // histogram only: the LDS-slab pipeline (gf2_slabs.hip) once the batch amortises its three launches and the table
     // loads; GF2_SPARSE_SLABS / GF2_SPARSE_GATHER force one or the other (same results)
-    if (gf2_lane_ok(ck) && getenv("GF2_SPARSE_GATHER") == nullptr && getenv("GF2_SPARSE_SLABS") == nullptr)
+    if (gf2_lane_ok(ck) && !gf2_flag(ctx, GF2_F_SPARSE_GATHER) && !gf2_flag(ctx, GF2_F_SPARSE_SLABS))
         GF2_TRY(gf2_syndrome_lane(ctx, ck, e_dev, batch, lde, s_dev, lds, hist_dev, ctx->stream));   // n <= 512, r <= 256
-    else if (!s_dev && gf2_slabs_ok(ck) && getenv("GF2_SPARSE_GATHER") == nullptr &&
-        (batch >= 32768 || getenv("GF2_SPARSE_SLABS") != nullptr))
+    else if (!s_dev && gf2_slabs_ok(ck) && !gf2_flag(ctx, GF2_F_SPARSE_GATHER) &&
+        (batch >= 32768 || gf2_flag(ctx, GF2_F_SPARSE_SLABS)))
         GF2_TRY(gf2_syndrome_slabs(ctx, ck, e_dev, batch, lde, hist_dev, ctx->stream, 2));
     else if (s_dev && hist_dev)
         launch_sparse<true, true>(ctx, ck, e_dev, batch, lde, (uint32_t*)s_dev, lds * 2, (u64*)hist_dev, (int)nbins);

@@ -25,6 +25,27 @@ def ctx():
     return _native.default_context()
 
 
+class Route(object):
+    """Forces one of the bit-identical implementations behind an entry point: routing flags of the process-wide context
+    (gf2_ctx_set_flags; "GF2_MC_DENSE" names GF2_F_MC_DENSE of include/gf2hip.h)."""
+
+    def __init__(self, context):
+        self.context = context
+
+    def force(self, name):
+        self.context.set_flags(self.context.get_flags() | getattr(_native, "F_" + name[4:]))
+
+    def release(self, name):
+        self.context.set_flags(self.context.get_flags() & ~getattr(_native, "F_" + name[4:]))
+
+
+@pytest.fixture
+def route():
+    context = _native.default_context()
+    yield Route(context)
+    context.set_flags(0)
+
+
 def test_native_library_is_loaded(ctx):
     assert _native.lib().gf2_version() >= 100
     assert _native.device_count() >= 1
@@ -481,7 +502,7 @@ def test_syndrome_sparse_kernel(case, ctx):
     assert np.array_equal(ctx.syndrome_batch(h, r, n, e, batch), want)
 
 
-def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, monkeypatch):
+def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, route):
     rng = np.random.default_rng(11)
     hm1, hm2 = rng.integers(0, 2, (2048, 4096)), rng.integers(0, 2, (2047, 4096))
     hm1[:, :2048] = np.identity(2048, dtype=int)
@@ -490,12 +511,12 @@ def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, monkeypatch):
     c1, c2 = ctx.check_create(h1, 2048, 4096), ctx.check_create(h2, 2047, 4096)
     args = (0xABC, 5 * 10**6, 20000, 0.004, 0.003, 0.002, _native.HIST_WEIGHT)
     fused = ctx.mc_run(c1, c2, *args)                         # sampler fused into the sparse kernel
-    monkeypatch.setenv("GF2_MC_UNFUSED", "1")
+    route.force("GF2_MC_UNFUSED")
     sparse = ctx.mc_run(c1, c2, *args)                        # sampler kernel -> sparse kernel
-    monkeypatch.delenv("GF2_MC_UNFUSED")
-    monkeypatch.setenv("GF2_MC_DENSE", "1")
+    route.release("GF2_MC_UNFUSED")
+    route.force("GF2_MC_DENSE")
     dense = ctx.mc_run(c1, c2, *args)                         # sampler kernel -> table kernel -> histogram kernel
-    monkeypatch.delenv("GF2_MC_DENSE")
+    route.release("GF2_MC_DENSE")
     want = c_oracle.mc(h1, 2048, h2, 2047, 4096, 0xABC, 5 * 10**6, 20000, 0.004, 0.003, 0.002, 1)
     for got in (fused, sparse, dense):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
@@ -505,19 +526,19 @@ def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, monkeypatch):
     big = (0xABC, 123, (1 << 21) + 77777, 0.004, 0.003, 0.002, _native.HIST_WEIGHT)
     piped = ctx.mc_run(c1, c2, *big)
     piped_again = ctx.mc_run(c1, c2, *big)
-    monkeypatch.setenv("GF2_MC_FUSED", "1")
+    route.force("GF2_MC_FUSED")
     fused_big = ctx.mc_run(c1, c2, *big)
-    monkeypatch.delenv("GF2_MC_FUSED")
-    monkeypatch.setenv("GF2_MC_UNFUSED", "1")
+    route.release("GF2_MC_FUSED")
+    route.force("GF2_MC_UNFUSED")
     serial_big = ctx.mc_run(c1, c2, *big)
-    monkeypatch.delenv("GF2_MC_UNFUSED")
+    route.release("GF2_MC_UNFUSED")
     assert int(piped[0].sum()) == big[2] and int(piped[1].sum()) == big[2]
     for got in (piped_again, fused_big, serial_big):
         assert np.array_equal(got[0], piped[0]) and np.array_equal(got[1], piped[1])
 
 
 @pytest.mark.parametrize("case", [(127, 63, 64), (255, 127, 127), (511, 255, 250), (300, 100, 150)])
-def test_monte_carlo_mid_size_checks_take_the_lane_kernel(case, ctx, monkeypatch):
+def test_monte_carlo_mid_size_checks_take_the_lane_kernel(case, ctx, route):
     # n <= 512, r <= 256: gf2_mc_run draws dense rows and runs the lane-per-sample kernel per component; same histograms
     # from the oracle, from the fused kernel and from the slab pipelines
     n, r1, r2 = case
@@ -531,9 +552,9 @@ def test_monte_carlo_mid_size_checks_take_the_lane_kernel(case, ctx, monkeypatch
     got = ctx.mc_run(c1, c2, *args)
     want = c_oracle.mc(h1, r1, h2, r2, n, 77, 1000, 70001, 0.004, 0.003, 0.005, 1)
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
-    monkeypatch.setenv("GF2_MC_FUSED", "1")
+    route.force("GF2_MC_FUSED")
     fused = ctx.mc_run(c1, c2, *args)
-    monkeypatch.delenv("GF2_MC_FUSED")
+    route.release("GF2_MC_FUSED")
     assert np.array_equal(fused[0], want[0]) and np.array_equal(fused[1], want[1])
 
 
@@ -563,14 +584,14 @@ def test_logical_error_rates_vs_oracle(steane_h, rm15):
     assert quiet['logical_any'] == 0 and quiet['uncorrectable_x'] == 0
 
 
-def test_small_code_fused_and_pipeline_agree(rm15, steane_h, monkeypatch):
+def test_small_code_fused_and_pipeline_agree(rm15, steane_h, route):
     # the fused small-code kernel and the sampler -> syndrome -> histogram pipeline give identical histograms
     for code in (CSSCode(steane_h, steane_h), CSSCode(*rm15)):
         for mode in ('full', 'weight'):
             fused = code.monte_carlo(200000, 0.04, 0.01, 0.02, seed=9, first_sample=77, mode=mode)
-            monkeypatch.setenv("GF2_MC_PIPELINE", "1")
+            route.force("GF2_MC_PIPELINE")
             piped = code.monte_carlo(200000, 0.04, 0.01, 0.02, seed=9, first_sample=77, mode=mode)
-            monkeypatch.delenv("GF2_MC_PIPELINE")
+            route.release("GF2_MC_PIPELINE")
             assert np.array_equal(fused['hist_z'], piped['hist_z']) and np.array_equal(fused['hist_x'], piped['hist_x'])
             assert int(fused['hist_z'].sum()) == 200000
 
@@ -724,7 +745,7 @@ def test_normalize_with_a_column_swap_at_every_step(case, ctx):
                                   # shapes: fewer rows than a slab holds, a bit offset inside the dword, a slab cut by r
                                   (1000, 3000, 1024, 1300, 0.005), (700, 2600, 1285, 2200, 0.006), (300, 1536, 1152, 900, 0.01),
                                   (1500, 4096, 2560, 777, 0.006), (513, 2048, 1408, 1000, 0.008), (2040, 4096, 2051, 650, 0.007)])
-def test_syndrome_slab_pipeline(case, ctx, monkeypatch):
+def test_syndrome_slab_pipeline(case, ctx, route):
     # histogram-only calls take the LDS row-slab pipeline (compact -> gather -> combine) when the check qualifies; it must
     # agree with the oracle and with the column-gather kernel on sparse samples, on samples beyond the record capacity
     # and on ragged batches
@@ -742,12 +763,12 @@ def test_syndrome_slab_pipeline(case, ctx, monkeypatch):
     lde = e.shape[1]
     e_buf = ctx.alloc(e.nbytes).upload(e)
     want = c_oracle.histogram(c_oracle.syndrome_batch(h, r, n, e, batch), batch, r, 1, r + 1)
-    monkeypatch.setenv("GF2_SPARSE_SLABS", "1")              # small batches default to the column-gather kernel
+    route.force("GF2_SPARSE_SLABS")              # small batches default to the column-gather kernel
     hist = ctx.alloc((r + 1) * 8).zero()
     ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist, r + 1)
     assert np.array_equal(hist.download((r + 1,), np.uint64), want)
-    monkeypatch.delenv("GF2_SPARSE_SLABS")
-    monkeypatch.setenv("GF2_SPARSE_GATHER", "1")
+    route.release("GF2_SPARSE_SLABS")
+    route.force("GF2_SPARSE_GATHER")
     hist2 = ctx.alloc((r + 1) * 8).zero()
     ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist2, r + 1)
     assert np.array_equal(hist2.download((r + 1,), np.uint64), want)
@@ -756,7 +777,7 @@ def test_syndrome_slab_pipeline(case, ctx, monkeypatch):
 @pytest.mark.parametrize("case", [(2047, 4096, 2048, 3000, 0.007, None), (2046, 4096, 2048, 1500, 0.01, None),
                                   (2047, 4096, 2049, 1500, 0.007, None), (2047, 4096, 2048, 700, 0.004, 4095),
                                   (1023, 2048, 1024, 2100, 0.01, None), (2045, 4096, 2048, 500, 0.01, None)])
-def test_slab_pipeline_columns_left_to_the_redo_pass(case, ctx, monkeypatch):
+def test_slab_pipeline_columns_left_to_the_redo_pass(case, ctx, route):
     # a check with one or two non-identity columns next to the identity block (H2 of a CSS code with k = 1, 2): compact leaves
     # their word out, the gather kernel flags the samples that have them and the redo kernel computes those from the row;
     # three columns (last case) stay in the records.  Same histogram with the redo pass switched off and from the oracle.
@@ -773,17 +794,17 @@ def test_slab_pipeline_columns_left_to_the_redo_pass(case, ctx, monkeypatch):
     lde = e.shape[1]
     e_buf = ctx.alloc(e.nbytes).upload(e)
     want = c_oracle.histogram(c_oracle.syndrome_batch(h, r, n, e, batch), batch, r, 1, r + 1)
-    monkeypatch.setenv("GF2_SPARSE_SLABS", "1")
+    route.force("GF2_SPARSE_SLABS")
     hist = ctx.alloc((r + 1) * 8).zero()
     ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist, r + 1)
     assert np.array_equal(hist.download((r + 1,), np.uint64), want)
-    monkeypatch.setenv("GF2_NO_REDO", "1")
+    route.force("GF2_NO_REDO")
     hist2 = ctx.alloc((r + 1) * 8).zero()
     ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist2, r + 1)
     assert np.array_equal(hist2.download((r + 1,), np.uint64), want)
 
 
-def test_syndrome_slab_pipeline_default_route_large_batch(ctx, monkeypatch):
+def test_syndrome_slab_pipeline_default_route_large_batch(ctx, route):
     # above the batch threshold the histogram-only call takes the slab pipeline by itself (64 sample shares per slab,
     # XCD-grouped); same histogram as the column-gather kernel and as the dense table kernel's syndromes
     r, n, ioff, batch = 2047, 4096, 2049, 70001
@@ -797,7 +818,7 @@ def test_syndrome_slab_pipeline_default_route_large_batch(ctx, monkeypatch):
     hists = []
     for force_gather in (False, True):
         if force_gather:
-            monkeypatch.setenv("GF2_SPARSE_GATHER", "1")
+            route.force("GF2_SPARSE_GATHER")
         hist = ctx.alloc((r + 1) * 8).zero()
         ctx.syndrome_sparse_dev(chk, ex, batch, 64, None, 0, hist, r + 1)
         hists.append(hist.download((r + 1,), np.uint64))
@@ -805,8 +826,8 @@ def test_syndrome_slab_pipeline_default_route_large_batch(ctx, monkeypatch):
     e = ex.download((batch, 64), "<u8")
     want = c_oracle.histogram(c_oracle.syndrome_batch(h, r, n, e[:3000].copy(), 3000), 3000, r, 1, r + 1)
     first = ctx.alloc((r + 1) * 8).zero()
-    monkeypatch.delenv("GF2_SPARSE_GATHER")
-    monkeypatch.setenv("GF2_SPARSE_SLABS", "1")
+    route.release("GF2_SPARSE_GATHER")
+    route.force("GF2_SPARSE_SLABS")
     ctx.syndrome_sparse_dev(chk, ex, 3000, 64, None, 0, first, r + 1)
     assert np.array_equal(first.download((r + 1,), np.uint64), want)
 
@@ -952,7 +973,7 @@ def test_encoders_of_the_n4096_code_prepare_its_stabilisers(ctx):
     assert np.array_equal(mat, expected)
 
 
-def test_slab_pipeline_padded_rows_and_several_workspace_passes(ctx, monkeypatch):
+def test_slab_pipeline_padded_rows_and_several_workspace_passes(ctx, route):
     # (a) rows padded to lde = 71 words (odd: the identity words are not 16-byte aligned) with garbage-free padding,
     # (b) a batch above the 2^21-sample workspace pass, so the pipeline runs twice and carries on at the right row;
     # both against the column-gather kernel on the same resident errors
@@ -971,11 +992,11 @@ def test_slab_pipeline_padded_rows_and_several_workspace_passes(ctx, monkeypatch
     for count in (batch, 5000):
         hists = []
         for force_gather in (False, True):
-            monkeypatch.setenv("GF2_SPARSE_GATHER" if force_gather else "GF2_SPARSE_SLABS", "1")
+            route.force("GF2_SPARSE_GATHER" if force_gather else "GF2_SPARSE_SLABS")
             hist = ctx.alloc((r + 1) * 8).zero()
             ctx.syndrome_sparse_dev(chk, e_buf, count, lde, None, 0, hist, r + 1)
             hists.append(hist.download((r + 1,), np.uint64))
-            monkeypatch.delenv("GF2_SPARSE_GATHER" if force_gather else "GF2_SPARSE_SLABS")
+            route.release("GF2_SPARSE_GATHER" if force_gather else "GF2_SPARSE_SLABS")
         assert np.array_equal(hists[0], hists[1]) and int(hists[0].sum()) == count
         if count == 5000:
             assert np.array_equal(hists[0], want)
@@ -989,7 +1010,7 @@ def test_slab_pipeline_padded_rows_and_several_workspace_passes(ctx, monkeypatch
     hists = []
     for force_gather in (False, True):
         if force_gather:
-            monkeypatch.setenv("GF2_SPARSE_GATHER", "1")
+            route.force("GF2_SPARSE_GATHER")
         hist = ctx.alloc((r + 1) * 8).zero()
         ctx.syndrome_sparse_dev(chk, ez, batch, 64, None, 0, hist, r + 1)
         hists.append(hist.download((r + 1,), np.uint64))
@@ -1113,7 +1134,7 @@ def test_two_contexts_share_checks_and_run_concurrently(ctx):
 
 @pytest.mark.parametrize("shape", [(1, 1), (3, 7), (64, 64), (64, 65), (33, 128), (64, 200), (64, 512), (60, 1000), (64, 1024),
                                    (65, 100), (128, 256), (100, 500), (128, 1024), (129, 250), (256, 256), (200, 512), (256, 512)])
-def test_rref_batch_small_matrix_kernel_every_variant(shape, ctx, monkeypatch):
+def test_rref_batch_small_matrix_kernel_every_variant(shape, ctx, route):
     # the wavefront-per-matrix kernel (rows in registers): every (rows per lane, words per row) instantiation, batches of
     # different matrices incl. rank-deficient and zero ones; pivots, ranks and matrices against the C oracle, and the
     # blocked path on the same input
@@ -1135,7 +1156,7 @@ def test_rref_batch_small_matrix_kernel_every_variant(shape, ctx, monkeypatch):
         want, want_piv, want_rank = c_oracle.rref(packed[b], m, n)
         assert int(ranks[b]) == want_rank and np.array_equal(piv[b][:want_rank], want_piv), (shape, b)
         assert np.array_equal(got[b], want), (shape, b)
-    monkeypatch.setenv("GF2_RREF_NO_SMALL", "1")
+    route.force("GF2_RREF_NO_SMALL")
     again = packed.copy()
     piv2, ranks2 = ctx.rref_batch(again, batch, m, n)
     assert np.array_equal(again, got) and np.array_equal(ranks2, ranks)

@@ -179,6 +179,136 @@ def test_golden_big512(golden):
     assert int(np.count_nonzero(red.any(axis=1))) == int(golden["big512_rank"])
 
 
+# ---- the packed C restatement (oracle/gf2_oracle.c) against the same reference outputs ---------------------------
+# It is the comparator of the GPU tests at sizes where the NumPy restatement takes minutes, so it is pinned here to every
+# array the reference produced for the functions it restates, and to oracle/cpu_ref.py for the build-defined pieces.
+
+def test_c_oracle_rref(golden):
+    from oracle import c_oracle
+    tags = [str(i) for i in golden["rref_shape_ids"]] + ["def", "zero", "norows", "nonbin", "u8", "i8"]
+    for tag in tags:
+        a, want = golden["rref_in_" + tag], golden["rref_out_" + tag]
+        m, n = a.shape
+        red, piv, rank = c_oracle.rref(c_oracle.pack_rows(a), m, n)
+        assert np.array_equal(c_oracle.unpack_rows(red, n, dtype=want.dtype), want), tag
+        assert rank == int(np.count_nonzero(want.any(axis=1))), tag
+        lead = [int(np.flatnonzero(row)[0]) for row in np.asarray(want)[:rank] & 1]
+        assert [int(c) for c in piv] == lead, tag
+    a = np.random.default_rng(1024).integers(0, 2, (512, 1024)).astype(np.int64)
+    red, _, rank = c_oracle.rref(c_oracle.pack_rows(a), 512, 1024)
+    assert sha(red) == str(golden["big512_rref_sha"]) and rank == int(golden["big512_rank"])
+
+
+def test_c_oracle_normalize(golden):
+    from oracle import c_oracle
+    for tag in golden["norm_tags"]:
+        tag = str(tag)
+        h, off = golden["norm_in_" + tag], int(golden["norm_off_" + tag])
+        r, n = h.shape
+        rc, out, swaps = c_oracle.normalize(c_oracle.pack_rows(h), r, n, off)
+        assert rc == 0, tag
+        assert np.array_equal(c_oracle.unpack_rows(out, n), golden["norm_out_" + tag]), tag
+        assert swaps == [tuple(int(v) for v in s) for s in golden["norm_swaps_" + tag]], tag
+    dep = golden["norm_dep_in"]
+    assert c_oracle.normalize(c_oracle.pack_rows(dep), dep.shape[0], dep.shape[1], 0)[0] == -3      # css_code.py:825-826
+    assert c_oracle.normalize(np.zeros((3, 1), dtype="<u8"), 3, 5, 3)[0] == -2                      # css_code.py:811-812
+
+
+def test_c_oracle_syndromes(golden):
+    from oracle import c_oracle
+    for tag in ("steane", "rm15", "r64x128", "r70x200"):
+        h, e, s = golden["syn_h_" + tag], golden["syn_e_" + tag], golden["syn_s_" + tag]
+        r, n = h.shape
+        got = c_oracle.syndrome_batch(c_oracle.pack_rows(h), r, n, c_oracle.pack_rows(e), e.shape[0])
+        assert np.array_equal(c_oracle.unpack_rows(got, r), s), tag
+        # the two histogram keys: vec_to_int of the syndrome (css_code.py:729) and its weight
+        if r <= 10:
+            want = np.bincount([int(ref.vec_to_int(row)) for row in s], minlength=1 << r)
+            assert np.array_equal(c_oracle.histogram(got, e.shape[0], r, 0, 1 << r), want.astype(np.uint64)), tag
+        want = np.bincount(s.sum(axis=1), minlength=r + 1)
+        assert np.array_equal(c_oracle.histogram(got, e.shape[0], r, 1, r + 1), want.astype(np.uint64)), tag
+
+
+def test_c_oracle_full_size_digests(golden):
+    # configs[3] of BASELINE.json: the reference's own 2048 x 4096 outputs (SHA-256 of the packed words)
+    from oracle import c_oracle
+    a = np.random.default_rng(4096).integers(0, 2, (2048, 4096)).astype(np.uint8)
+    packed = c_oracle.pack_rows(a)
+    red, _, rank = c_oracle.rref(packed, 2048, 4096)
+    assert sha(red) == str(golden["big4096_rref_sha"]) and rank == int(golden["big4096_rank"])
+    rc, out, swaps = c_oracle.normalize(packed, 2048, 4096, 0)
+    assert rc == 0 and sha(out) == str(golden["big4096_norm_sha"])
+    assert swaps == [tuple(int(v) for v in s) for s in golden["big4096_norm_swaps"]]
+    e = np.random.default_rng(77).integers(0, 2, (32, 4096)).astype(np.uint8)
+    s = c_oracle.syndrome_batch(packed, 2048, 4096, c_oracle.pack_rows(e), 32)
+    assert sha(s) == str(golden["big4096_syn_sha"])
+
+
+def test_c_oracle_nullspace(golden, steane_h):
+    from oracle import c_oracle
+    mats = [steane_h, golden["rref_in_4"], golden["rref_in_def"], golden["rref_in_5"], golden["rref_in_7"],
+            np.random.default_rng(3).integers(0, 2, (70, 200))]
+    for mat in mats:
+        mat = np.asarray(mat) & 1
+        m, n = mat.shape
+        got = c_oracle.nullspace(c_oracle.pack_rows(mat), m, n)
+        assert np.array_equal(c_oracle.unpack_rows(got, n), ref.nullspace(mat))
+
+
+@pytest.mark.parametrize("n", [7, 15, 64, 70, 130, 200])
+def test_c_oracle_sampler(n):
+    # three statements of one definition (DESIGN.md "Sampler"); this pins the C one to the NumPy one, ragged last words included
+    from oracle import c_oracle
+    for (p, seed, first, count) in (((0.05, 0.02, 0.1), 123, 1000, 40), ((0.004, 0.003, 0.003), 9, 0, 60),
+                                    ((0.3, 0.3, 0.4), 77, 5, 8), ((0.0, 0.0, 0.0), 1, 0, 3)):
+        ex, ez = c_oracle.sample_errors(n, seed, first, count, *p)
+        for i in range(count):
+            want_x, want_z = ref.sample_pauli_error(seed, first + i, n, *p)
+            assert np.array_equal(c_oracle.unpack_rows(ex[i:i + 1], n)[0], want_x), (n, p, i)
+            assert np.array_equal(c_oracle.unpack_rows(ez[i:i + 1], n)[0], want_z), (n, p, i)
+
+
+def test_c_oracle_sampler_n4096():
+    from oracle import c_oracle
+    p = (0.01 / 3, 0.01 / 3, 0.01 / 3)
+    ex, ez = c_oracle.sample_errors(4096, 0xC55C0DE, 12345, 6, *p)
+    for i in range(6):
+        want_x, want_z = ref.sample_pauli_error(0xC55C0DE, 12345 + i, 4096, *p)
+        assert np.array_equal(c_oracle.unpack_rows(ex[i:i + 1], 4096)[0], want_x)
+        assert np.array_equal(c_oracle.unpack_rows(ez[i:i + 1], 4096)[0], want_z)
+    assert ex.any() and ez.any()
+
+
+def test_c_oracle_monte_carlo(steane_h, rm15):
+    from oracle import c_oracle
+    rng = np.random.default_rng(8)
+    cases = [(ref.CSSCode(steane_h, steane_h), 'full', 300), (ref.CSSCode(*rm15), 'full', 200), (ref.CSSCode(*rm15), 'weight', 200)]
+    for code, mode, count in cases:
+        h1, h2 = code.parity_check_c1, code.parity_check_c2
+        want = ref.monte_carlo_histograms(h1, h2, 21, 1000, count, 0.06, 0.03, 0.05, mode)
+        got = c_oracle.mc(c_oracle.pack_rows(h1), code.r_1, c_oracle.pack_rows(h2), code.r_2, code.n, 21, 1000, count,
+                          0.06, 0.03, 0.05, 0 if mode == 'full' else 1)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    # multi-word rows with a ragged last word, weight histograms
+    for n, r1, r2 in ((70, 20, 30), (130, 64, 65), (200, 70, 100)):
+        h1, h2 = rng.integers(0, 2, (r1, n)), rng.integers(0, 2, (r2, n))
+        want = ref.monte_carlo_histograms(h1, h2, 5, 77, 60, 0.02, 0.03, 0.01, 'weight')
+        got = c_oracle.mc(c_oracle.pack_rows(h1), r1, c_oracle.pack_rows(h2), r2, n, 5, 77, 60, 0.02, 0.03, 0.01, 1)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
+def test_c_oracle_swap_columns():
+    from oracle import c_oracle
+    import ctypes
+    rng = np.random.default_rng(2)
+    mat = rng.integers(0, 2, (9, 150))
+    packed = c_oracle.pack_rows(mat)
+    for (i, j) in ((0, 149), (63, 64), (5, 5), (70, 3)):
+        c_oracle.lib().orc_swap_columns(packed.ctypes.data_as(ctypes.c_void_p), 9, packed.shape[1], i, j)
+        ref.swap_columns(mat, (i, j))
+        assert np.array_equal(c_oracle.unpack_rows(packed, 150), mat)
+
+
 # ---- build-defined pieces: internal consistency -------------------------------------------------
 
 def test_nullspace_properties(golden, steane_h):
