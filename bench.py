@@ -40,6 +40,7 @@ The JSON line also carries
                 32768 x 65536 matrix, and for 256 MiB of 64 x 512 and of 128 x 512 matrices.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -70,7 +71,15 @@ def build_code():
     h2 = bin_matrix.nullspace(h1)[:R2]
     code = CSSCode(h1, h2, max_table_weight=0)       # syndrome_table is exponential: capped
     assert code.k == 1
-    return code, _native.pack_rows(code.parity_check_c1), _native.pack_rows(code.parity_check_c2)
+    c1, c2 = _native.pack_rows(code.parity_check_c1), _native.pack_rows(code.parity_check_c2)
+    # the timed kernels' inputs are the reference's own: digests of what its constructor (css_code.py:32-75) made of the
+    # same H1, H2 (tests/golden/make_golden_config4.py ran it; the file holds data only)
+    with np.load(os.path.join(ROOT, "tests", "golden", "config4_golden.npz"), allow_pickle=False) as g:
+        digest = lambda arr: hashlib.sha256(np.ascontiguousarray(arr).tobytes()).hexdigest()
+        assert digest(_native.pack_rows(h1)) == str(g["h1_in_sha"]) and digest(_native.pack_rows(h2)) == str(g["h2_in_sha"])
+        assert digest(c1) == str(g["c1_sha"]) and digest(c2) == str(g["c2_sha"]), "standard forms differ from the reference's"
+        assert np.array_equal(code.z_operator_matrix(), g["zop"]) and np.array_equal(code.x_operator_matrix(), g["xop"])
+    return code, c1, c2
 
 
 def cpu_baseline(code, seconds_target=20.0, sample=2048):
@@ -111,7 +120,10 @@ class Path(object):
             # sample-major packed errors resident in HBM; histogram-only output (no syndromes written)
             lde = _native.words_for(N_QUBITS)
             self.ex, self.ez = ctx.alloc(batch * lde * 8), ctx.alloc(batch * lde * 8)
-            ctx.sample_errors_dev(N_QUBITS, SEED, first, batch, p, p, p, self.ex, self.ez, lde)
+            for done in range(0, batch, 1 << 21):                        # the sampler writes 2^21 samples per call
+                _native.check(_native.lib().gf2_sample_errors_dev(
+                    ctx.handle, N_QUBITS, SEED, first + done, min(1 << 21, batch - done), p, p, p,
+                    self.ex.ptr + done * lde * 8, self.ez.ptr + done * lde * 8, lde, _native.LAYOUT_SAMPLE_MAJOR))
             self.kernel = "slab_pipeline"                                # compact + gather + combine, gf2_slabs.hip
             self.alg_bytes_per_sample = N_QUBITS / 8.0                   # SURVEY.md 8d read-only variant, per component
             side = self.ctx2 if self.ctx2 is not None else ctx
@@ -369,6 +381,8 @@ def main():
     ap.add_argument("--algo", choices=("sparse", "dense"), default="sparse")
     ap.add_argument("--slab-pass-log2", type=int, default=None,
                     help="samples per pass of the slab pipeline through its workspace (GF2_OPT_SLAB_PASS_LOG2)")
+    ap.add_argument("--opt", action="append", default=[], metavar="K=V",
+                    help="set a context tunable (GF2_OPT_* number = value), e.g. --opt 2=0")
     ap.add_argument("--one-stream", action="store_true",
                     help="issue both components of a step on one HIP stream (default: H2.e_x goes to a second context)")
     args = ap.parse_args()
@@ -403,6 +417,9 @@ def main():
     for c in (ctx, ctx2):
         if c is not None and args.slab_pass_log2 is not None:
             c.set_option(_native.OPT_SLAB_PASS_LOG2, args.slab_pass_log2)
+        for kv in args.opt:
+            if c is not None:
+                c.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
     path = Path(ctx, args.algo, chk1, chk2, batch, first, ctx2)
     if rank == 0:
         path.check_against_oracle(h1, h2, first)        # correctness of what is about to be timed
@@ -478,6 +495,10 @@ def main():
                        "parallelism": "sample-range shards, 1 histogram all-reduce"},
             "roofline": (roofline_of_steps(path, gpu_ms / 1e3, args.steps, syn_ms / 1e3 / max(1, syn_n), syn_n)
                          if path.ctx2 is not None else roofline(path, syn_ms / 1e3 / max(1, syn_n), syn_n)),
+            "checks": {"histogram_total": int(hist_z.sum()), "expected_total": int(total),
+                       "oracle_prefix": "512 samples of this rank's batch through the timed path == oracle/gf2_oracle.c",
+                       "inputs": "H1, H2, both standard forms and logical operators == digests of the reference's own "
+                                 "constructor (tests/golden/config4_golden.npz)"},
             "kernel_ms": {"syndrome_calls": syn_ms, "syndrome_calls_counted": syn_n, "histogram": hist_ms,
                           "stream_total": gpu_ms},
         }

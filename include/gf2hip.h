@@ -88,7 +88,8 @@ int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
 /* Tunables of a context (value < 0 restores the default). */
 #define GF2_OPT_SLAB_PASS_LOG2  0   /* slab pipeline: 2^k samples per pass through the workspace, 12 <= k <= 21 (default 21) */
 #define GF2_OPT_COMBINE_BLOCKS  1   /* slab pipeline: workgroups of the combine kernel (default 128)                      */
-#define GF2_OPT_COUNT           2
+#define GF2_OPT_GATHER_REVERSE   2   /* slab pipeline: 1 (default) = the gather kernel walks the records last tile first  */
+#define GF2_OPT_COUNT           3
 int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value);
 
 /* Device memory and stream-ordered copies on the context's stream (copies are synchronous). */
@@ -111,6 +112,11 @@ int gf2_timer_stop(gf2_ctx* ctx, float* elapsed_ms_out);   /* synchronises on th
 int gf2_profile_enable(gf2_ctx* ctx, int on);
 int gf2_profile_reset(gf2_ctx* ctx);
 int gf2_profile_get(gf2_ctx* ctx, int kernel_family, double* total_ms_out, int64_t* launches_out);
+
+/* Memory-bandwidth probe: streams `bytes` (a multiple of 16) from src_dev with 16-byte loads; dst_dev null = read only,
+ * else the bytes are also stored there (copy).  Asynchronous on the context's stream; bracket it with gf2_timer_*.  It is
+ * what bench.py quotes roofline fractions against next to the 8 TB/s specification.  sink_dev: one device word. */
+int gf2_membw_probe_dev(gf2_ctx* ctx, const void* src_dev, void* dst_dev, size_t bytes, uint64_t* sink_dev);
 
 /* ---- host-side packing (pure host code, no GPU needed) -------------------------------------------
  * Dense integer arrays <-> packed words.  Packing applies `& 1` (the reference reduces lazily with

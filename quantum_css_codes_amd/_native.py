@@ -22,7 +22,7 @@ K_SYNDROME, K_HIST, K_SAMPLER, K_ELIM = 0, 1, 2, 3
 (F_SPARSE_GATHER, F_SPARSE_SLABS, F_NO_REDO, F_GATHER_GENERIC, F_MC_UNFUSED, F_MC_DENSE, F_MC_FUSED, F_MC_PIPELINE,
  F_RREF_SEQUENTIAL, F_RREF_NO_SMALL, F_NORMALIZE_SEQUENTIAL, F_SAMPLER_GENERIC, F_DIAG_CLOCKS,
  F_DIAG_MC_TIMES) = (1 << k for k in range(14))
-OPT_SLAB_PASS_LOG2, OPT_COMBINE_BLOCKS = 0, 1
+OPT_SLAB_PASS_LOG2, OPT_COMBINE_BLOCKS, OPT_GATHER_REVERSE = 0, 1, 2
 
 
 class GF2Error(RuntimeError):
@@ -61,6 +61,7 @@ SIGNATURES = {
     "gf2_profile_enable": [_p, ctypes.c_int],
     "gf2_profile_reset": [_p],
     "gf2_profile_get": [_p, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_i64)],
+    "gf2_membw_probe_dev": [_p, _p, _p, ctypes.c_size_t, _p],
     "gf2_pack_rows_u8": [_p, _c_i64, _c_i64, _c_i64, _p, _c_i64],
     "gf2_pack_rows_i64": [_p, _c_i64, _c_i64, _c_i64, _p, _c_i64],
     "gf2_unpack_rows_u8": [_p, _c_i64, _c_i64, _c_i64, _p, _c_i64],
@@ -351,6 +352,20 @@ class Context(object):
         ms, count = ctypes.c_double(0), _c_i64(0)
         check(lib().gf2_profile_get(self.handle, int(family), ctypes.byref(ms), ctypes.byref(count)))
         return float(ms.value), int(count.value)
+
+    def membw_probe(self, src_buf, nbytes, dst_buf=None, reps=5):
+        """GB/s of a plain streaming read (or copy) of `nbytes` of src_buf: the measured ceiling beside the 8 TB/s spec."""
+        sink = self.alloc(8).zero()
+        call = lambda: check(lib().gf2_membw_probe_dev(self.handle, src_buf.ptr, dst_buf.ptr if dst_buf is not None else None,
+                                                       int(nbytes), sink.ptr))
+        call()
+        self.sync()
+        self.timer_start()
+        for _ in range(reps):
+            call()
+        ms = self.timer_stop() / reps
+        sink.free()
+        return (2 if dst_buf is not None else 1) * nbytes / ms / 1e6
 
     # -- linear algebra on packed host arrays ------------------------------------------------------------
     def rref(self, packed, m, n):

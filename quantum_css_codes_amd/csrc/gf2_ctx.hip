@@ -34,6 +34,36 @@ int gf2_stream_wait(hipStream_t stream) {
     return GF2_OK;
 }
 
+// Streams `vecs` 16-byte pieces: four independent loads per lane and trip, XOR-ed into one word per workgroup (so that
+// nothing is optimised away); COPY also stores them.  The measured ceiling that roofline fractions are quoted against next to
+// the 8 TB/s specification.
+typedef unsigned int probe_vec __attribute__((ext_vector_type(4)));
+template <bool COPY>
+__global__ __launch_bounds__(512) void membw_probe_kernel(const probe_vec* __restrict__ src, probe_vec* __restrict__ dst, int64_t vecs,
+                                                          u64* __restrict__ sink) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    probe_vec acc = {0, 0, 0, 0};
+    for (; i + 3 * stride < vecs; i += 4 * stride) {
+        const probe_vec a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        const probe_vec c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        if (COPY) {
+            __builtin_nontemporal_store(a, dst + i);
+            __builtin_nontemporal_store(b, dst + i + stride);
+            __builtin_nontemporal_store(c, dst + i + 2 * stride);
+            __builtin_nontemporal_store(d, dst + i + 3 * stride);
+        }
+        acc ^= a ^ b ^ c ^ d;
+    }
+    for (; i < vecs; i += stride) {
+        const probe_vec a = src[i];
+        if (COPY) dst[i] = a;
+        acc ^= a;
+    }
+    const unsigned int folded = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (folded == 0x9E3779B9u) atomicXor(sink, (u64)folded);       // keeps the loads alive; practically never taken
+}
+
 // The context's streams and events.  On failure the caller destroys whatever was created (every handle starts out null).
 static int create_streams_and_events(gf2_ctx* ctx) {
     GF2_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -240,6 +270,23 @@ int gf2_profile_get(gf2_ctx* ctx, int kernel_family, double* total_ms_out, int64
     GF2_TRY(gf2_prof_drain(ctx));
     if (total_ms_out) *total_ms_out = ctx->prof_ms[kernel_family];
     if (launches_out) *launches_out = ctx->prof_launches[kernel_family];
+    return GF2_OK;
+}
+
+// ---- memory bandwidth probe ---------------------------------------------------------------------------
+
+int gf2_membw_probe_dev(gf2_ctx* ctx, const void* src_dev, void* dst_dev, size_t bytes, uint64_t* sink_dev) {
+    if (!ctx || !src_dev || !sink_dev || (bytes & 15)) GF2_FAIL(GF2_E_ARG, "gf2_membw_probe_dev: bad argument (bytes must be a multiple of 16)");
+    GF2_TRY(gf2_ctx_activate(ctx));
+    const int64_t vecs = (int64_t)(bytes >> 4);
+    const dim3 grid((unsigned)(ctx->num_cus * 8)), block(512);
+    if (dst_dev)
+        hipLaunchKernelGGL(membw_probe_kernel<true>, grid, block, 0, ctx->stream, (const probe_vec*)src_dev, (probe_vec*)dst_dev, vecs,
+                           (u64*)sink_dev);
+    else
+        hipLaunchKernelGGL(membw_probe_kernel<false>, grid, block, 0, ctx->stream, (const probe_vec*)src_dev, (probe_vec*)nullptr, vecs,
+                           (u64*)sink_dev);
+    GF2_HIP(hipGetLastError());
     return GF2_OK;
 }
 

@@ -331,9 +331,9 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
         int64_t k = 0;
         timespec t_begin;
         clock_gettime(CLOCK_MONOTONIC, &t_begin);
-        for (int64_t done = 0; done < count; done += chunk_s, ++k) {
-            const int64_t now = count - done < chunk_s ? count - done : chunk_s;
-            const int b = (int)(k & 1);
+        // One chunk: sampler on the context's stream, the two pipelines on the side streams.  A failure in the middle must not
+        // leave the side streams working on this call's buffers behind the caller's back: the loop joins them before returning.
+        auto enqueue_chunk = [&](int64_t done, int64_t now, int b) -> int {
             if (k >= 2) {                                          // the pipelines of chunk k - 2 are done with these buffers
                 GF2_HIP(hipStreamWaitEvent(ctx->stream, done_z[b], 0));
                 GF2_HIP(hipStreamWaitEvent(ctx->stream, done_x[b], 0));
@@ -347,6 +347,17 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
             GF2_TRY(gf2_syndrome_slabs(ctx, c2, sx[b], now, lde_s, dx, ctx->side[1], 3));
             GF2_HIP(hipEventRecord(done_z[b], ctx->side[0]));
             GF2_HIP(hipEventRecord(done_x[b], ctx->side[1]));
+            return GF2_OK;
+        };
+        for (int64_t done = 0; done < count; done += chunk_s, ++k) {
+            const int64_t now = count - done < chunk_s ? count - done : chunk_s;
+            const int rc = enqueue_chunk(done, now, (int)(k & 1));
+            if (rc != GF2_OK) {
+                (void)hipStreamSynchronize(ctx->side[0]);
+                (void)hipStreamSynchronize(ctx->side[1]);
+                (void)hipStreamSynchronize(ctx->stream);
+                return rc;
+            }
         }
         timespec t_enqueued;
         clock_gettime(CLOCK_MONOTONIC, &t_enqueued);

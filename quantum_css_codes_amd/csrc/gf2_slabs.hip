@@ -364,6 +364,7 @@ struct GatherArgs {
     int64_t batch, batch_pad, lde;   // batch_pad: stride of the partial weights; records exist for ceil(batch / 64) * 64 positions
     int tab_stride, nslabs, r, ident_off, null_ord;   // tab_stride: entries per row-part plane (= 4 mod 16)
     int stray_n, stray_col[2];   // columns compact left out (hand-scheduled kernel only): a sample that has one is flagged REC_STRAY
+    int reverse;               // hand-scheduled kernel: walk the records from the last tile to the first (see gf2_syndrome_slabs)
     u64* clk;                  // debugging (GF2_GATHER_CLOCK): earliest entry / latest exit of the workgroups at [2], [3], else null
 };
 
@@ -716,7 +717,9 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
         return (unsigned int)share * GAT_WAVES + (t & (GAT_WAVES - 1)) + (t / GAT_WAVES) * stride;
     };
-    auto rec_pos = [&](unsigned int g) { return g * 16 + lane_rec; };
+    // reverse: group g stands for group ngroups - 1 - g (groups past the end stay past the end: their records read as zeros)
+    const unsigned int last_group = a.reverse ? ngroups - 1u : 0u;
+    auto rec_pos = [&](unsigned int g) { return (a.reverse && g < ngroups ? last_group - g : g) * 16 + lane_rec; };
     unsigned int G0 = take(), G1 = take(), G2 = take(), G3 = take();
     issue_record(R0, rec_pos(G0));
     issue_record(R1, rec_pos(G1));
@@ -1065,6 +1068,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
         ga.stray_col[0] = stray.col[0];
         ga.stray_col[1] = stray.col[1];
         ga.clk = clk_dev;
+        ga.reverse = ctx->opt[GF2_OPT_GATHER_REVERSE] == 0 ? 0 : 1;
         int64_t shares = ctx->num_cus / ck->nslabs512;
         const int64_t max_shares = gf2_cdiv(gf2_cdiv(count, 16), GAT_WAVES);
         if (shares > max_shares) shares = max_shares;

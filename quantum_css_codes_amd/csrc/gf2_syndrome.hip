@@ -667,7 +667,15 @@ int gf2_syndrome_batch(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, in
     if (!ctx) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: null context");
     if (batch < 0 || r < 0 || n < 0) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: negative size");
     if (batch == 0 || r == 0) return GF2_OK;
-    if (!e || !s_out) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: null buffer");
+    if (!e || !s_out || !h) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: null buffer");
+    // every pitch is checked before a host buffer is touched (the density probe below reads e)
+    if (ldh < gf2_words(n) || ldh < 1) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: ldh too small");
+    if (layout == GF2_LAYOUT_SAMPLE_MAJOR && (lde < gf2_words(n) || lde < 1)) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: lde too small");
+    if (layout == GF2_LAYOUT_BIT_SLICED && (lde < gf2_cdiv(batch, 64) || lds < gf2_cdiv(batch, 64) || n > 64 || r > 64))
+        GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: bit-sliced layout needs n, r <= 64 and lde, lds >= ceil(batch / 64)");
+    if (layout == GF2_LAYOUT_TILED && lds < batch) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: slab-major syndromes need lds >= batch");
+    if (layout != GF2_LAYOUT_SAMPLE_MAJOR && layout != GF2_LAYOUT_BIT_SLICED && layout != GF2_LAYOUT_TILED)
+        GF2_FAIL(GF2_E_ARG, "gf2_syndrome_batch: unknown layout %d", layout);
     int64_t e_words, s_rows;
     if (layout == GF2_LAYOUT_BIT_SLICED) {
         e_words = n * lde;

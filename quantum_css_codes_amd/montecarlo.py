@@ -54,7 +54,9 @@ def all_reduce_histograms(hists, group=None, device=None):
     sizes = [int(h.size) for h in hists]
     flat = np.concatenate([np.asarray(h, dtype=np.uint64).view(np.int64) for h in hists])
     if device is None:
-        device = 'cuda' if dist.get_backend(group) == 'nccl' else 'cpu'
+        # RCCL needs the buffer on THIS rank's GPU: the one the compute context runs on (GF2_DEVICE / LOCAL_RANK), not
+        # torch's current device, which is cuda:0 in every rank unless the caller set it
+        device = torch.device('cuda', _native.default_context().device) if dist.get_backend(group) == 'nccl' else 'cpu'
     buf = torch.from_numpy(flat.copy()).to(device)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     total = buf.cpu().numpy().view(np.uint64)

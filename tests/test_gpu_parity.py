@@ -174,6 +174,46 @@ def test_normalize_random_vs_oracle(case, ctx):
     assert np.array_equal(packed, want)
 
 
+@pytest.fixture(scope="module")
+def config4_golden():
+    """Digests of the reference's own CSSCode(H1, H2) at n = 4096 (tests/golden/make_golden_config4.py)."""
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "config4_golden.npz"), allow_pickle=False) as data:
+        return {k: data[k] for k in data.files}
+
+
+def test_css_code_config4_against_the_reference_constructor(config4_golden, ctx):
+    # BASELINE.json configs[3]/[4]: the code the benchmark times.  H2 = first 2047 rows of nullspace(H1); both standard
+    # forms, both swap lists (css_code.py:51-61), the logical operators and the gate set as the reference's constructor
+    # produced them
+    g = config4_golden
+    h1 = np.random.default_rng(4096).integers(0, 2, (2048, 4096)).astype(np.int64)
+    assert sha(_native.pack_rows(h1)) == str(g["h1_in_sha"])
+    h2 = bin_matrix.nullspace(h1)[:2047]
+    assert sha(_native.pack_rows(h2)) == str(g["h2_in_sha"])
+    code = CSSCode(h1, h2, max_table_weight=0)
+    assert [code.n, code.k, code.r_1, code.r_2] == [int(v) for v in g["nk_r1_r2"]]
+    assert sha(_native.pack_rows(code.parity_check_c1)) == str(g["c1_sha"])
+    assert sha(_native.pack_rows(code.parity_check_c2)) == str(g["c2_sha"])
+    assert np.array_equal(code.z_operator_matrix(), g["zop"]) and np.array_equal(code.x_operator_matrix(), g["xop"])
+    assert sorted(code._transversal_gates) == [str(v) for v in g["gates"]]
+    # the constructor's steps one by one: swap lists of both normalisations
+    w1, w2 = np.array(h1), np.array(h2)
+    out1, swaps1 = css_code.normalize_parity_check(w1, 0)
+    for pair in swaps1:
+        css_code.swap_columns(w2, pair)
+    out2, swaps2 = css_code.normalize_parity_check(w2, 2048)
+    for pair in swaps2:
+        css_code.swap_columns(out1, pair)
+    assert [tuple(p) for p in swaps1] == [tuple(int(v) for v in p) for p in g["swaps_c1"]]
+    assert [tuple(p) for p in swaps2] == [tuple(int(v) for v in p) for p in g["swaps_c2"]]
+    assert np.array_equal(out1, code.parity_check_c1) and np.array_equal(out2, code.parity_check_c2)
+    # syndrome products of the standard forms (css_code.py:728)
+    e = _native.pack_rows(np.random.default_rng(78).integers(0, 2, (16, 4096)).astype(np.uint8))
+    s1 = ctx.syndrome_batch(_native.pack_rows(code.parity_check_c1), 2048, 4096, e, 16)
+    s2 = ctx.syndrome_batch(_native.pack_rows(code.parity_check_c2), 2047, 4096, e, 16)
+    assert sha(s1) == str(g["syn_c1_sha"]) and sha(s2) == str(g["syn_c2_sha"])
+
+
 def test_normalize_full_size_config4(golden, ctx):
     a = np.random.default_rng(4096).integers(0, 2, (2048, 4096)).astype(np.int64)
     packed = _native.pack_rows(a)
@@ -374,10 +414,11 @@ def test_monte_carlo_steane_config2(steane_h):
 
 
 def test_monte_carlo_rm15(rm15):
+    # BASELINE.json configs[2] at its full size: 10^7 samples, every bin against the oracle
     code = CSSCode(*rm15)
     h1, h2 = c_oracle.pack_rows(code.parity_check_c1), c_oracle.pack_rows(code.parity_check_c2)
-    got = code.monte_carlo(300000, 0.03, 0.01, 0.02, seed=15, first_sample=12345)
-    hz, hx = c_oracle.mc(h1, 4, h2, 10, 15, 15, 12345, 300000, 0.03, 0.01, 0.02, 0)
+    got = code.monte_carlo(10**7, 0.03, 0.01, 0.02, seed=15, first_sample=12345)
+    hz, hx = c_oracle.mc(h1, 4, h2, 10, 15, 15, 12345, 10**7, 0.03, 0.01, 0.02, 0)
     assert got['hist_z'].size == 16 and got['hist_x'].size == 1024
     assert np.array_equal(got['hist_z'], hz) and np.array_equal(got['hist_x'], hx)
     # weight mode and shard-independence: two halves add up to the whole
@@ -1098,6 +1139,32 @@ def test_two_rank_sharded_monte_carlo_on_the_gpu(tmp_path, steane_h):
         assert np.array_equal(r["hist_z"], want_z) and np.array_equal(r["hist_x"], want_x)
         assert np.array_equal(r["hist_z"], whole['hist_z'])
         assert list(r["decode"]) == [whole_dec[f] for f in montecarlo.DECODE_FIELDS]
+
+
+def test_bench_under_torchrun_two_ranks_share_the_gpu(tmp_path):
+    # the driver's N > 1 launch line (python -m torch.distributed.run ... bench.py --gpus N), rehearsed with two ranks that
+    # share this box's one GPU over gloo: a fresh child process, the JSON line checked.  (RCCL with N > 1 needs N GPUs.)
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GF2_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2",
+           "--warmup", "1", "--batch-log2", "17", "--no-cpu-baseline", "--no-secondary", "--no-settle"]
+    done = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert done.returncode == 0, done.stderr[-2000:]
+    lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                     # rank 0 prints the one line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["unit"] == "syndromes/s"
+    assert out["config"]["global_samples_per_step"] == 2 << 17
+    assert out["value"] > 0 and abs(out["value"] - 2 * (2 << 17) / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+    assert out["checks"]["histogram_total"] == 2 * (2 << 17)   # both shards' samples arrived in the all-reduced histogram
 
 
 def test_two_contexts_share_checks_and_run_concurrently(ctx):
