@@ -237,8 +237,9 @@ def roofline(path, mean_launch_s, launches):
     achieved = alg_bytes / mean_launch_s / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and path.batch == 1 << 20:
-        traffic = json.load(open(tpath)).get(path.kernel + "_bytes_per_launch")
+    if os.path.exists(tpath) and path.batch % (1 << 20) == 0:     # PMC bytes of a 2^20-sample call (profiles/traffic.json)
+        per = json.load(open(tpath)).get(path.kernel + "_bytes_per_launch")
+        traffic = per * (path.batch >> 20) if per else None
     return {"bound": "hbm", "kernel": path.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
             "mean_launch_ms": mean_launch_s * 1e3, "launches": launches}
@@ -252,9 +253,9 @@ def roofline_of_steps(path, gpu_s, steps, per_call_s, calls):
     achieved = alg_bytes / (gpu_s / steps) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and path.batch == 1 << 20:
+    if os.path.exists(tpath) and path.batch % (1 << 20) == 0:     # PMC bytes of a 2^20-sample call (profiles/traffic.json)
         one = json.load(open(tpath)).get(path.kernel + "_bytes_per_launch")
-        traffic = 2 * one if one else None
+        traffic = 2 * one * (path.batch >> 20) if one else None
     return {"bound": "hbm", "kernel": path.kernel + " x2: H1.e_z and H2.e_x on two HIP streams, one launch = one step",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": gpu_s / steps * 1e3, "launches": steps,
@@ -369,9 +370,9 @@ def small_code_numbers(ctx):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch-log2", type=int, default=20, help="samples per GPU per step (2^k)")
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-log2", type=int, default=24, help="samples per GPU per step (2^k); 2^24 = 16 GiB of packed errors")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-settle", action="store_true", help="skip the 0.1 s of untimed steps before the warm-up steps")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other syndrome kernel and the RREF timings")
@@ -381,6 +382,7 @@ def main():
     ap.add_argument("--algo", choices=("sparse", "dense"), default="sparse")
     ap.add_argument("--slab-pass-log2", type=int, default=None,
                     help="samples per pass of the slab pipeline through its workspace (GF2_OPT_SLAB_PASS_LOG2)")
+    ap.add_argument("--ctx-flags", type=lambda v: int(v, 0), default=0, help="routing flags (GF2_F_*) of both contexts")
     ap.add_argument("--opt", action="append", default=[], metavar="K=V",
                     help="set a context tunable (GF2_OPT_* number = value), e.g. --opt 2=0")
     ap.add_argument("--one-stream", action="store_true",
@@ -417,6 +419,8 @@ def main():
     for c in (ctx, ctx2):
         if c is not None and args.slab_pass_log2 is not None:
             c.set_option(_native.OPT_SLAB_PASS_LOG2, args.slab_pass_log2)
+        if c is not None and args.ctx_flags:
+            c.set_flags(args.ctx_flags)
         for kv in args.opt:
             if c is not None:
                 c.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
@@ -431,10 +435,20 @@ def main():
         torch.cuda.synchronize()
 
     # Part of the set-up, like the oracle check above: about 0.1 s of untimed steps bring the clocks to the state a long run
-    # sees (a cold start costs a 20-step measurement 6 %); the W warm-up steps of the contract follow.
-    for _ in range(0 if args.no_settle else 300):
+    # sees (from a cold start a short measurement reads up to 6 % low); reported as settle_steps.  The W warm-up steps of
+    # the contract follow.
+    settle_steps = 0
+    if not args.no_settle:
         path.step()
-    path.sync()
+        path.sync()
+        t_one = time.perf_counter()
+        path.step()
+        path.sync()
+        t_one = max(1e-5, time.perf_counter() - t_one)
+        settle_steps = 2 + max(1, min(400, int(0.1 / t_one)))
+        for _ in range(settle_steps - 2):
+            path.step()
+        path.sync()
     for _ in range(args.warmup):
         path.step()
     if world > 1:
@@ -443,7 +457,7 @@ def main():
     path.sync()
     path.hz.zero(), path.hx.zero()
     # per-call HIP events cost the two-stream step about 2.5 %: there the timed region runs without them (its roofline
-    # needs the step time only) and the per-call durations come from 20 further steps after it
+    # needs the step time only) and the per-call durations come from a few further steps after it
     call_events = path.ctx2 is None
     for c in path.contexts():
         c.profile(call_events)
@@ -472,7 +486,7 @@ def main():
         for c in path.contexts():
             c.profile(True)
             c.profile_reset()
-        for _ in range(20):
+        for _ in range(max(1, min(20, (1 << 24) // batch))):
             path.step()
         path.sync()
     syn_ms, syn_n, hist_ms = 0.0, 0, 0.0
@@ -483,9 +497,26 @@ def main():
         c.profile(False)
 
     if rank == 0:
+        roof = (roofline_of_steps(path, gpu_ms / 1e3, args.steps, syn_ms / 1e3 / max(1, syn_n), syn_n)
+                if path.ctx2 is not None else roofline(path, syn_ms / 1e3 / max(1, syn_n), syn_n))
+        # the chip's streaming ceiling measured in this run (plain 16-byte loads over the resident errors), next to the
+        # 8 TB/s specification the fraction is quoted against
+        probe_bytes = min(batch * 512, 1 << 32)
+        measured = ctx.membw_probe(path.ex, probe_bytes)
+        roof["measured_read_peak_GBs"] = measured
+        roof["frac_of_measured_peak"] = roof["achieved"] / measured
+        # integer work of the algorithm as it is run: per sample and component (w + 2) * r / 32 32-bit XOR
+        # and popcount lane-operations, w = expected listed columns (n - r)(p_x + p_y); peak = CUs x 64 lanes x 2.4 GHz
+        w_mean = (N_QUBITS - R1) * (2.0 * P_TOTAL / 3.0)
+        lane_ops = 2.0 * batch * (w_mean + 2.0) * (R1 / 32.0)
+        int_peak = 256 * 64 * 2.4e9
+        roof["int_op"] = {"lane_ops_per_launch": lane_ops, "achieved_per_s": lane_ops / (roof["mean_launch_ms"] / 1e3 * (1 if path.ctx2 is not None else 2)),
+                          "peak_per_s": int_peak, "frac": lane_ops / (roof["mean_launch_ms"] / 1e3 * (1 if path.ctx2 is not None else 2)) / int_peak,
+                          "what": "32-bit XOR/popcount lane-operations of the sparse algorithm ((w + 2) r / 32 per sample and "
+                                  "component, w = %.2f listed columns) against 256 CUs x 64 lanes x 2.4 GHz" % w_mean}
         out = {
             "metric": "syndromes/sec (n=4096 CSS)", "value": total / elapsed, "unit": "syndromes/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle_steps,
             "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[4]: n=4096 CSS Monte-Carlo, random dual code (H1 2048x4096, H2 2047x4096, "
@@ -493,8 +524,7 @@ def main():
                        "algo": args.algo, "samples_per_gpu_per_step": batch, "global_samples_per_step": batch * world,
                        "streams": 2 if path.ctx2 is not None else 1,
                        "parallelism": "sample-range shards, 1 histogram all-reduce"},
-            "roofline": (roofline_of_steps(path, gpu_ms / 1e3, args.steps, syn_ms / 1e3 / max(1, syn_n), syn_n)
-                         if path.ctx2 is not None else roofline(path, syn_ms / 1e3 / max(1, syn_n), syn_n)),
+            "roofline": roof,
             "checks": {"histogram_total": int(hist_z.sum()), "expected_total": int(total),
                        "oracle_prefix": "512 samples of this rank's batch through the timed path == oracle/gf2_oracle.c",
                        "inputs": "H1, H2, both standard forms and logical operators == digests of the reference's own "
@@ -506,49 +536,75 @@ def main():
             out["cpu_baseline"] = cpu_baseline(code)
         if world == 1 and not args.no_secondary:
             single_z = (hist_z // np.uint64(args.steps)).astype(np.uint64)      # same batch every step
-            gather, single = None, None
-            if args.algo == "sparse":
-                # the same resident errors with both components on ONE stream: the slab pipeline by itself (per-call
-                # roofline), then the wavefront-per-sample column-gather kernel (gf2_sparse.hip)
-                plain = Path(ctx, "sparse", chk1, chk2, batch, first)
-                s_ms, s_launch, s_n, _ = timed(ctx, plain, 50, 5)
-                assert np.array_equal(plain.hz.download((R1 + 1,), np.uint64), single_z * np.uint64(50)), \
-                    "one-stream and two-stream steps disagree"
-                single = {"value": 50 * batch / (s_ms / 1e3), "unit": "syndromes/s", "ms_per_step": s_ms / 50,
-                          "roofline": roofline(plain, s_launch, s_n)}
-                with ctx.flags(_native.F_SPARSE_GATHER):
-                    g_ms, g_launch, g_n, _ = timed(ctx, plain, 10, 2)
-                    assert np.array_equal(plain.hz.download((R1 + 1,), np.uint64), single_z * np.uint64(10)), \
-                        "column-gather kernel and slab pipeline disagree"
-                plain.kernel = "syndrome_sparse_kernel"
-                gather = {"value": 10 * batch / (g_ms / 1e3), "unit": "syndromes/s", "ms_per_step": g_ms / 10,
-                          "roofline": roofline(plain, g_launch, g_n)}
-                plain.free()
+            # end to end: nothing resident, gf2_mc_run draws the errors itself (sampler || slab pipelines, three streams); its
+            # histogram over this rank's batch must be the timed path's
+            mc_count = max(batch, 1 << 24)
+            ctx.mc_run(chk1, chk2, SEED, 0, 1 << 20, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)
+            t_mc = time.perf_counter()
+            mc_z, _ = ctx.mc_run(chk1, chk2, SEED, first, mc_count, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)
+            t_mc = time.perf_counter() - t_mc
+            assert int(mc_z.sum()) == mc_count
+            if mc_count == batch:
+                assert np.array_equal(mc_z, single_z), "end-to-end Monte-Carlo and the resident-error path disagree"
+            else:
+                assert np.array_equal(ctx.mc_run(chk1, chk2, SEED, first, batch, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3,
+                                                 _native.HIST_WEIGHT)[0], single_z)
             path.free()
-            other = Path(ctx, "dense" if args.algo == "sparse" else "sparse", chk1, chk2, batch, first)
+            # the other implementations on 2^20 resident samples of the same stream (one stream, per-call rooflines)
+            sec = min(batch, 1 << 20)
+            gather, single, stored = None, None, None
+            plain = Path(ctx, "sparse", chk1, chk2, sec, first)
+            s_ms, s_launch, s_n, _ = timed(ctx, plain, 50, 5)
+            sec_z = (plain.hz.download((R1 + 1,), np.uint64) // np.uint64(50)).astype(np.uint64)
+            assert int(sec_z.sum()) == sec
+            single = {"value": 50 * sec / (s_ms / 1e3), "unit": "syndromes/s", "ms_per_step": s_ms / 50,
+                      "roofline": roofline(plain, s_launch, s_n)}
+            with ctx.flags(_native.F_SPARSE_GATHER):
+                g_ms, g_launch, g_n, _ = timed(ctx, plain, 10, 2)
+                assert np.array_equal(plain.hz.download((R1 + 1,), np.uint64), sec_z * np.uint64(10)), \
+                    "column-gather kernel and slab pipeline disagree"
+            plain.kernel = "syndrome_sparse_kernel"
+            gather = {"value": 10 * sec / (g_ms / 1e3), "unit": "syndromes/s", "ms_per_step": g_ms / 10,
+                      "roofline": roofline(plain, g_launch, g_n)}
+            # SURVEY.md 8d's read + write variant: the same kernel with the syndromes stored, 1536 B per sample
+            # (2 x 512 read, 256 + 255.9 written) instead of 1024 read
+            s1, s2 = ctx.alloc(sec * plain.ls1 * 8), ctx.alloc(sec * plain.ls2 * 8)
+            lde = _native.words_for(N_QUBITS)
+            for _ in range(2):
+                ctx.syndrome_sparse_dev(chk1, plain.ez, sec, lde, s1, plain.ls1)
+                ctx.syndrome_sparse_dev(chk2, plain.ex, sec, lde, s2, plain.ls2)
+            ctx.sync()
+            ctx.timer_start()
+            for _ in range(10):
+                ctx.syndrome_sparse_dev(chk1, plain.ez, sec, lde, s1, plain.ls1)
+                ctx.syndrome_sparse_dev(chk2, plain.ex, sec, lde, s2, plain.ls2)
+            rw_ms = ctx.timer_stop() / 10
+            from oracle import c_oracle
+            e_head = plain.ez.download((64, lde), "<u8")
+            assert np.array_equal(s1.download((64, plain.ls1), "<u8"), c_oracle.syndrome_batch(h1, R1, N_QUBITS, e_head, 64)), \
+                "stored syndromes differ from the oracle"
+            rw_bytes = sec * (2 * N_QUBITS / 8.0 + (R1 + R2) / 8.0)
+            stored = {"value": sec / (rw_ms / 1e3), "unit": "syndromes/s", "ms_per_step": rw_ms,
+                      "bytes_per_syndrome": 2 * N_QUBITS / 8.0 + (R1 + R2) / 8.0,
+                      "roofline": {"bound": "hbm", "kernel": "syndrome_sparse_kernel (syndromes stored)", "achieved": rw_bytes / rw_ms / 1e6,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rw_bytes / rw_ms / 1e6 / HBM_PEAK_GBS}}
+            s1.free(), s2.free()
+            plain.free()
+            other = Path(ctx, "dense" if args.algo == "sparse" else "sparse", chk1, chk2, sec, first)
             other.check_against_oracle(h1, h2, first)
             o_ms, o_launch, o_n, o_hist = timed(ctx, other, 10, 2)
             other_z = other.hz.download((R1 + 1,), np.uint64)
-            assert np.array_equal(other_z, single_z * np.uint64(10)), "the two syndrome kernels disagree"
-            # end to end: nothing resident, gf2_mc_run draws the errors itself (sampler || slab pipelines, three streams)
-            mc_count = 1 << 24
-            ctx.mc_run(chk1, chk2, SEED, 0, 1 << 20, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)
-            t_mc = time.perf_counter()
-            mc_z, _ = ctx.mc_run(chk1, chk2, SEED, 0, mc_count, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)
-            t_mc = time.perf_counter() - t_mc
-            assert int(mc_z.sum()) == mc_count and np.array_equal(
-                ctx.mc_run(chk1, chk2, SEED, first, batch, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)[0], single_z)
+            assert np.array_equal(other_z, sec_z * np.uint64(10)), "the two syndrome kernels disagree"
             out["secondary"] = {
                 "monte_carlo_end_to_end": {"value": mc_count / t_mc, "unit": "syndromes/s",
                                            "what": "gf2_mc_run: sampler of chunk k+1 overlapping the two slab pipelines of chunk k on three streams, no resident input, "
                                                    "host wall time incl. histogram download, %d samples" % mc_count},
-                other.algo + "_kernel": {"value": 10 * batch / (o_ms / 1e3), "unit": "syndromes/s", "ms_per_step": o_ms / 10,
+                other.algo + "_kernel": {"value": 10 * sec / (o_ms / 1e3), "unit": "syndromes/s", "ms_per_step": o_ms / 10,
                                          "roofline": roofline(other, o_launch, o_n), "histogram_ms_per_step": o_hist / 10},
                 "rref": rref_numbers(ctx)}
-            if gather is not None:
-                out["secondary"]["column_gather_kernel"] = gather
-            if single is not None:
-                out["secondary"]["one_stream"] = single
+            out["secondary"]["column_gather_kernel"] = gather
+            out["secondary"]["one_stream"] = single
+            out["secondary"]["read_write_1536B"] = stored
             out["secondary"]["small_codes"] = small_code_numbers(ctx)
             other.free()
         print(json.dumps(out))
