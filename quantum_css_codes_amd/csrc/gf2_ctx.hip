@@ -155,8 +155,8 @@ int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out) {
 int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value) {
     if (!ctx || option < 0 || option >= GF2_OPT_COUNT) GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: bad argument");
     if (value >= 0) {
-        if (option == GF2_OPT_SLAB_PASS_LOG2 && (value < 12 || value > 21))
-            GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_SLAB_PASS_LOG2 must be in 12..21");
+        if (option == GF2_OPT_SLAB_PASS_LOG2 && (value < 12 || value > 22))
+            GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_SLAB_PASS_LOG2 must be in 12..22");
         if (option == GF2_OPT_COMBINE_BLOCKS && (value < 1 || value > 65535))
             GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_COMBINE_BLOCKS must be in 1..65535");
     }

@@ -39,7 +39,8 @@
 #define SLAB_ROWS 512
 #define SLAB_MAX_COLS 2400                    // (cols + 1) * 64 bytes of LDS <= 150 KiB
 #define SLAB_MAX_BINS 2304
-#define SLAB_MAX_BATCH (1 << 21)              // samples per pass through the workspace
+#define SLAB_MAX_BATCH (1 << 22)              // most samples per pass through the workspace (32-bit byte offsets of 512-byte rows)
+#define SLAB_DEFAULT_BATCH (1 << 21)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_ptr;
@@ -976,7 +977,7 @@ static StrayPlan plan_stray(const gf2_ctx* ctx, const gf2_check* ck) {
 
 // Samples per pass through the workspace (records, partial weights, redo list).
 static int64_t slab_pass(const gf2_ctx* ctx, int64_t batch) {
-    const int64_t cap = ctx->opt[GF2_OPT_SLAB_PASS_LOG2] > 0 ? (1ll << ctx->opt[GF2_OPT_SLAB_PASS_LOG2]) : SLAB_MAX_BATCH;
+    const int64_t cap = ctx->opt[GF2_OPT_SLAB_PASS_LOG2] > 0 ? (1ll << ctx->opt[GF2_OPT_SLAB_PASS_LOG2]) : SLAB_DEFAULT_BATCH;
     return batch < cap ? batch : cap;
 }
 
