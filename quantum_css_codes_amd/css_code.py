@@ -14,9 +14,10 @@ Drop-in surface (same names, arguments, mutation and exception behaviour):
     CSSCode.noisy_encode_zero / noisy_encode_plus    css_code.py:203-312   (gate arrays, see below)
     transform_stabilisers, conjugate_h_with_check_mat, conjugate_cnot_with_check_mat   css_code.py:737-781
 
-Other Quil program emission (error_correct, measure, ...) is out of scope.  The two encoders
-are returned as gate arrays -- rows (kind, a, b), GATE_H on qubit a or GATE_CNOT control a target b, in the
-reference's instruction order -- which is what transform_stabilisers takes here [SURVEY.md 8f item 3].
+The two encoders are returned as gate arrays -- rows (kind, a, b), GATE_H on qubit a or GATE_CNOT control a target b, in
+the reference's instruction order -- which is what transform_stabilisers takes here [SURVEY.md 8f item 3].  The other
+emitters (encode_zero / encode_plus, apply_gate, error_correct, measure, noisy_measure, quil_classical_correct /
+quil_classical_detect; css_code.py:314-713) build pyQuil-free instruction tuples (quil.py, css_emit.py) [8f item 4].
 pyQuil is not required: Pauli operators are returned as text labels ("X0*X3*X4*X5") unless pyQuil is
 importable, in which case PauliTerm objects are returned as in the reference.
 
@@ -29,6 +30,8 @@ import numpy as np
 
 from . import _native
 from . import bin_matrix
+from . import css_emit
+from .css_emit import apply_transversally, quil_classical_correct, quil_classical_detect  # noqa: F401  (module-level in the reference)
 from .errors import InvalidCodeError
 from .qecc import QECC
 
@@ -210,6 +213,51 @@ class CSSCode(QECC):
     def noisy_encode_plus(self, qubits):
         """css_code.py:261-312 as a gate array (see encode_plus_gates); qubits must be integers."""
         return self.encode_plus_gates(qubits)
+
+    # -- program emission (css_code.py:314-646), pyQuil-free: quantum_css_codes_amd/css_emit.py ------------------------------
+    def noisy_encode_zero_program(self, qubits):
+        """noisy_encode_zero (css_code.py:203-259) as instruction tuples on `qubits` (integers or placeholders)."""
+        return css_emit.noisy_encode_zero_program(self, qubits)
+
+    def noisy_encode_plus_program(self, qubits):
+        """noisy_encode_plus (css_code.py:261-312) as instruction tuples."""
+        return css_emit.noisy_encode_plus_program(self, qubits)
+
+    def encode_zero(self, prog, block, ancilla, scratch):
+        css_emit.encode_zero(self, prog, block, ancilla, scratch)
+
+    def encode_plus(self, prog, block, ancilla, scratch):
+        css_emit.encode_plus(self, prog, block, ancilla, scratch)
+
+    def apply_gate(self, prog, gate_name, *blocks):
+        css_emit.apply_gate(self, prog, gate_name, *blocks)
+
+    def error_correct(self, prog, data, ancilla_1, ancilla_2, scratch):
+        css_emit.error_correct(self, prog, data, ancilla_1, ancilla_2, scratch)
+
+    def _error_detect_x(self, prog, data, ancilla, outcome, scratch, include_operators):
+        css_emit.error_detect_x(self, prog, data, ancilla, outcome, scratch, include_operators)
+
+    def _error_detect_z(self, prog, data, ancilla, outcome, scratch, include_operators):
+        css_emit.error_detect_z(self, prog, data, ancilla, outcome, scratch, include_operators)
+
+    def measure(self, prog, data, index, outcome, ancilla_1, ancilla_2, scratch, scratch_int):
+        return css_emit.measure(self, prog, data, index, outcome, ancilla_1, ancilla_2, scratch, scratch_int)
+
+    def noisy_measure(self, prog, data, index, outcome, ancilla_1, ancilla_2, scratch):
+        css_emit.noisy_measure(self, prog, data, index, outcome, ancilla_1, ancilla_2, scratch)
+
+    @property
+    def encode_scratch_size(self):
+        return css_emit.encode_scratch_size(self)
+
+    @property
+    def error_correct_scratch_size(self):
+        return css_emit.error_correct_scratch_size(self)
+
+    @property
+    def measure_scratch_size(self):
+        return css_emit.measure_scratch_size(self)
 
     def _device_checks(self):
         if self._checks is None:

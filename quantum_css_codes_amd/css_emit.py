@@ -1,0 +1,268 @@
+"""
+The program emitters of CSSCode, pyQuil-free: encode_zero / encode_plus, apply_gate, error_correct,
+the error detectors, measure / noisy_measure and the classical decode quil_classical_correct / quil_classical_detect
+(css_code.py:314-713 of the reference), emitting quantum_css_codes_amd.quil instruction tuples in the reference's order.
+
+The arithmetic these programs carry -- parity checks, syndrome tables, logical operators, encoder gate lists -- comes from the
+GPU-built CSSCode; what is generated here is straight-line code around it.  tests/test_quil_emission.py executes the programs
+(oracle/quil_sim.py: classical interpreter + stabiliser simulator) and compares with the GPU path.
+"""
+import numpy as np
+
+from . import bin_matrix, quil_classical
+from .errors import UnsupportedGateError
+from .quil import MemoryReference, Program, gates
+from .quil_classical import MemoryChunk
+
+GATE_H, GATE_CNOT = 0, 1
+
+
+def apply_transversally(gate, *blocks):
+    """css_code.py:852-853: the gate on the i-th qubits of every block, i ascending."""
+    prog = Program()
+    for qubits in zip(*blocks):
+        prog += gate(*qubits)
+    return prog
+
+
+def gate_program(gate_array, qubits):
+    """A gate array of CSSCode.encode_*_gates (indices into the block) as instructions on `qubits` (integers or placeholders)."""
+    prog = Program()
+    for kind, a, b in np.asarray(gate_array).reshape(-1, 3):
+        prog += gates.H(qubits[int(a)]) if int(kind) == GATE_H else gates.CNOT(qubits[int(a)], qubits[int(b)])
+    return prog
+
+
+def noisy_encode_zero_program(code, qubits):
+    """css_code.py:203-259 as instructions."""
+    return gate_program(code.encode_zero_gates(), list(qubits))
+
+
+def noisy_encode_plus_program(code, qubits):
+    """css_code.py:261-312 as instructions."""
+    return gate_program(code.encode_plus_gates(), list(qubits))
+
+
+# ---- classical decode ----------------------------------------------------------------------------------------------------
+
+def _syndrome_prologue(prog, codeword, errors, scratch, parity_check):
+    """Shared head of the two routines below (css_code.py:664-672, 698-706): fold the known errors in, multiply by the check
+    matrix into scratch[2 : m + 2], fold them out again.  Returns the syndrome chunk."""
+    m, n = parity_check.shape
+    if len(codeword) != n:
+        raise ValueError("codeword is of incorrect size")
+    if len(errors) != n:
+        raise ValueError("errors is of incorrect size")
+    if len(scratch) < m + 2:
+        raise ValueError("scratch buffer is too small")
+    prog += (gates.XOR(codeword[i], errors[i]) for i in range(n))
+    syndrome = scratch[2:m + 2]
+    quil_classical.matmul(prog, parity_check, codeword, syndrome, scratch[:2])
+    prog += (gates.XOR(codeword[i], errors[i]) for i in range(n))
+    return syndrome
+
+
+def quil_classical_correct(prog, codeword, errors, scratch, parity_check, syndromes):
+    """css_code.py:649-685.  The syndrome of codeword ^ errors is compared with every key of the syndrome table in the
+    table's own order (string_match into scratch[1]); the entry that matches XORs its correction into `errors`
+    (conditional_xor); finally the codeword takes the updated errors.  No match: errors stay as they were."""
+    m, _ = parity_check.shape
+    n = len(codeword)
+    syndrome = _syndrome_prologue(prog, codeword, errors, scratch, parity_check)
+    matches = scratch[1:2]
+    for key, correction in syndromes.items():
+        pattern = bin_matrix.int_to_vec(key, m)
+        quil_classical.string_match(prog, syndrome, pattern, matches, scratch[:1])
+        quil_classical.conditional_xor(prog, errors, np.asarray(correction), matches, scratch[:1])
+    prog += (gates.XOR(codeword[i], errors[i]) for i in range(n))
+
+
+def quil_classical_detect(prog, codeword, errors, outcome, scratch, parity_check):
+    """css_code.py:687-713: outcome = 1 iff the syndrome of codeword ^ errors is non-zero."""
+    m, _ = parity_check.shape
+    syndrome = _syndrome_prologue(prog, codeword, errors, scratch, parity_check)
+    prog += gates.MOVE(outcome, 0)
+    prog += (gates.IOR(outcome, syndrome[i]) for i in range(m))
+
+
+# ---- methods of CSSCode -----------------------------------------------------------------------------------------------------
+
+def encode_scratch_size(code):
+    return 2 * code.n - max(code.r_1, code.r_2) + 4           # css_code.py:595-597
+
+
+def error_correct_scratch_size(code):
+    return encode_scratch_size(code)                          # css_code.py:535-540
+
+
+def measure_scratch_size(code):
+    return encode_scratch_size(code) + 2 * code.t + 1         # css_code.py:591-593
+
+
+def _verified_encode(code, prog, block, ancilla, scratch, plus):
+    """encode_zero (css_code.py:314-342) / encode_plus (:344-366): noisy preparation, X and Z error DETECTION against a
+    noisy ancilla, repeated until nothing is detected (Gottesman, section 4.6)."""
+    if len(scratch) < error_correct_scratch_size(code):
+        raise ValueError("scratch buffer is too small")
+    flag, outcome, rest = scratch[0], scratch[1], scratch[2:]
+    loop = Program()
+    loop += gates.MOVE(flag, 0)
+    block.reset(loop)
+    loop += noisy_encode_plus_program(code, block.qubits) if plus else noisy_encode_zero_program(code, block.qubits)
+    error_detect_x(code, loop, block, ancilla, outcome, rest, include_operators=not plus)
+    loop += gates.IOR(flag, outcome)
+    error_detect_z(code, loop, block, ancilla, outcome, rest, include_operators=plus)
+    loop += gates.IOR(flag, outcome)
+    prog += gates.MOVE(flag, 1)
+    prog.while_do(flag, loop)
+
+
+def encode_zero(code, prog, block, ancilla, scratch):
+    _verified_encode(code, prog, block, ancilla, scratch, plus=False)
+
+
+def encode_plus(code, prog, block, ancilla, scratch):
+    _verified_encode(code, prog, block, ancilla, scratch, plus=True)
+
+
+def _pauli_program(code, gate_name, blocks):
+    """css_code.py:386-409: the logical Pauli as physical Paulis read off the operator matrices (Y where X and Z meet)."""
+    if gate_name == 'I':
+        return Program()
+    if gate_name not in ('X', 'Y', 'Z'):
+        return None
+    assert len(blocks) == 1
+    x_row = code.x_operator_matrix()[0] if gate_name in ('X', 'Y') else np.zeros(code.n, dtype=int)
+    z_row = code.z_operator_matrix()[0] if gate_name in ('Z', 'Y') else np.zeros(code.n, dtype=int)
+    prog = Program()
+    for q in range(code.n):
+        if x_row[q] and z_row[q]:
+            prog += gates.Y(blocks[0].qubits[q])
+        elif x_row[q]:
+            prog += gates.X(blocks[0].qubits[q])
+        elif z_row[q]:
+            prog += gates.Z(blocks[0].qubits[q])
+    return prog
+
+
+def _transversal_program(code, gate_name, blocks):
+    """css_code.py:411-432."""
+    if not code.is_transversal(gate_name):
+        return None
+    qubits = [block.qubits for block in blocks]
+    if gate_name in ('I', 'CNOT', 'H', 'CZ'):
+        return apply_transversally(getattr(gates, gate_name), *qubits)
+    if gate_name == 'S':
+        return apply_transversally(lambda qubit: [gates.Z(qubit), gates.S(qubit)], *qubits)
+    raise NotImplementedError("transversal {} not implemented".format(gate_name))
+
+
+def apply_gate(code, prog, gate_name, *blocks):
+    """css_code.py:368-384: Pauli, else transversal, else UnsupportedGateError (the reference has no universal gate set)."""
+    for build in (_pauli_program, _transversal_program):
+        part = build(code, gate_name, blocks)
+        if part is not None:
+            prog += part
+            return
+    raise UnsupportedGateError("logical gate {} not implemented".format(gate_name))
+
+
+def _check_blocks(code, data, ancilla_1, ancilla_2):
+    if data.n != code.n:
+        raise ValueError("data code word is of incorrect size")
+    if ancilla_1.n != code.n:
+        raise ValueError("ancilla_1 code word is of incorrect size")
+    if ancilla_2.n != code.n:
+        raise ValueError("ancilla_2 code word is of incorrect size")
+
+
+def error_correct(code, prog, data, ancilla_1, ancilla_2, scratch):
+    """css_code.py:436-470 (Steane error correction, Gottesman section 4.4): X errors are copied onto a |+> ancilla and caught
+    by parity_check_c2, Z errors onto a |0> ancilla, measured in the X basis, and caught by parity_check_c1."""
+    n = code.n
+    _check_blocks(code, data, ancilla_1, ancilla_2)
+    if len(scratch) < error_correct_scratch_size(code):
+        raise ValueError("scratch buffer is too small")
+    mem, correct_scratch = scratch[:n], scratch[n:]
+    encode_plus(code, prog, ancilla_1, ancilla_2, scratch)
+    prog += apply_transversally(gates.CNOT, data.qubits, ancilla_1.qubits)
+    prog += (gates.MEASURE(ancilla_1.qubits[i], mem[i]) for i in range(n))
+    quil_classical_correct(prog, mem, data.x_errors, correct_scratch, code.parity_check_c2, code._c2_syndromes)
+    encode_zero(code, prog, ancilla_1, ancilla_2, scratch)
+    prog += apply_transversally(gates.CNOT, ancilla_1.qubits, data.qubits)
+    prog += apply_transversally(gates.H, ancilla_1.qubits)
+    prog += (gates.MEASURE(ancilla_1.qubits[i], mem[i]) for i in range(n))
+    quil_classical_correct(prog, mem, data.z_errors, correct_scratch, code.parity_check_c1, code._c1_syndromes)
+
+
+def error_detect_x(code, prog, data, ancilla, outcome, scratch, include_operators):
+    """css_code.py:472-502."""
+    n = code.n
+    if len(scratch) < (n + code.r_2 + 2):
+        raise ValueError("scratch buffer is too small")
+    mem, rest = scratch[:n], scratch[n:]
+    ancilla.reset(prog)
+    prog += noisy_encode_zero_program(code, ancilla.qubits) if include_operators else noisy_encode_plus_program(code, ancilla.qubits)
+    prog += apply_transversally(gates.CNOT, data.qubits, ancilla.qubits)
+    prog += (gates.MEASURE(ancilla.qubits[i], mem[i]) for i in range(n))
+    check = code.parity_check_c2
+    if include_operators:
+        check = np.concatenate([check, code.z_operator_matrix()], axis=0)
+    quil_classical_detect(prog, mem, data.x_errors, outcome, rest, check)
+
+
+def error_detect_z(code, prog, data, ancilla, outcome, scratch, include_operators):
+    """css_code.py:504-533."""
+    n = code.n
+    if len(scratch) < (n + code.r_1 + 2):
+        raise ValueError("scratch buffer is too small")
+    mem, rest = scratch[:n], scratch[n:]
+    ancilla.reset(prog)
+    prog += noisy_encode_plus_program(code, ancilla.qubits) if include_operators else noisy_encode_zero_program(code, ancilla.qubits)
+    prog += apply_transversally(gates.CNOT, ancilla.qubits, data.qubits)
+    prog += apply_transversally(gates.H, ancilla.qubits)
+    prog += (gates.MEASURE(ancilla.qubits[i], mem[i]) for i in range(n))
+    check = code.parity_check_c1
+    if include_operators:
+        check = np.concatenate([check, code.x_operator_matrix()], axis=0)
+    quil_classical_detect(prog, mem, data.z_errors, outcome, rest, check)
+
+
+def noisy_measure(code, prog, data, index, outcome, ancilla_1, ancilla_2, scratch):
+    """css_code.py:599-646: logical Z measurement by copying onto a |0> ancilla and measuring it (Steane 1998, section 3);
+    X errors seen on the way are corrected opportunistically; the outcome is z_operator . measured bits."""
+    n, r_2 = code.n, code.r_2
+    if index != 0:
+        raise ValueError("only one logical qubit per code block")
+    _check_blocks(code, data, ancilla_1, ancilla_2)
+    if len(scratch) < error_correct_scratch_size(code):
+        raise ValueError("scratch buffer is too small")
+    encode_zero(code, prog, ancilla_1, ancilla_2, scratch)
+    mem, rest = scratch[:n], scratch[n:(n + r_2 + 2)]
+    prog += apply_transversally(gates.CNOT, data.qubits, ancilla_1.qubits)
+    prog += (gates.MEASURE(ancilla_1.qubits[i], mem[i]) for i in range(n))
+    quil_classical_correct(prog, mem, data.x_errors, rest, code.parity_check_c2, code._c2_syndromes)
+    z_operator = code.z_operator_matrix()[index:(index + 1), :]
+    outcome_chunk = MemoryChunk(MemoryReference(outcome.name), outcome.offset, outcome.offset + 1)
+    quil_classical.matmul(prog, z_operator, mem, outcome_chunk, rest)
+
+
+def measure(code, prog, data, index, outcome, ancilla_1, ancilla_2, scratch, scratch_int):
+    """css_code.py:542-589: 2t + 1 noisy measurements and a majority vote.  A generator, as in the reference: it yields after
+    every noisy measurement so that the caller can run a round of error correction."""
+    if index != 0:
+        raise ValueError("only one logical qubit per code block")
+    _check_blocks(code, data, ancilla_1, ancilla_2)
+    if len(scratch) < measure_scratch_size(code):
+        raise ValueError("scratch buffer is too small")
+    if len(scratch_int) < 1:
+        raise ValueError("scratch_int buffer is too small")
+    trials = 2 * code.t + 1
+    noisy_outcomes, noisy_scratch = scratch[:trials], scratch[trials:]
+    for i in range(trials):
+        noisy_measure(code, prog, data, index, noisy_outcomes[i], ancilla_1, ancilla_2, noisy_scratch)
+        yield
+    outcome_bit = noisy_scratch[0]
+    quil_classical.majority_vote(prog, noisy_outcomes, outcome_bit, scratch_int)
+    prog += gates.MEASURE(ancilla_1.qubits[0], outcome)       # the QVM wants a MEASURE to initialise the register (:584-586)
+    prog += gates.MOVE(outcome, outcome_bit)

@@ -8,4 +8,12 @@ class InvalidCodeError(Exception):
 
 
 class UnsupportedGateError(Exception):
-    """Kept for interface compatibility (errors.py:8-9); gate emission is outside this package."""
+    """errors.py:8-9: raised by CSSCode.apply_gate for a logical gate that is neither a Pauli nor transversal."""
+
+
+class UnsupportedQECCError(Exception):
+    """ftqc.py:44 raises this name without defining it (a NameError in the reference); defined here."""
+
+
+class UnsupportedProgramError(Exception):
+    """ftqc.py:47,118 raise this name without defining it (a NameError in the reference); defined here."""
