@@ -176,6 +176,13 @@ int gf2_matmul_abt(gf2_ctx* ctx, const uint64_t* a, int64_t ra, int64_t lda,
 int gf2_syndrome_table(gf2_ctx* ctx, const uint64_t* h_rows, int64_t r, int64_t n, int64_t max_weight,
                        uint64_t* table_out, int64_t* t_out, int64_t* entries_out);
 
+/* The same search for 64 < n <= 128 (SURVEY.md 8f item 2 names n = 23..127).  h_rows: r rows of two words.  A slot of table_out
+ * (2^r words) holds (weight << 32) | rank -- the error's rank inside its weight class in the combinatorial number system
+ * (positions c_1 < ... < c_w have rank C(c_1, 1) + ... + C(c_w, w)) -- or all ones; the caller unranks.  t_out, entries_out and
+ * max_weight as above. */
+int gf2_syndrome_table_wide(gf2_ctx* ctx, const uint64_t* h_rows, int64_t r, int64_t n, int64_t max_weight,
+                            uint64_t* table_out, int64_t* t_out, int64_t* entries_out);
+
 /* css_code.transform_stabilisers (css_code.py:737-781) [SURVEY.md 8f item 3].  mat: k rows of ld words holding the k x 2n
  * stabiliser matrix [X | Z] (column j = bit j), rewritten in place.  gates: ngates rows of three int32 (kind, a, b):
  * kind 0 = H on qubit a (conjugate_h_with_check_mat, :757-767), kind 1 = CNOT control a target b

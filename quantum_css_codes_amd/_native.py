@@ -77,6 +77,7 @@ SIGNATURES = {
     "gf2_row_weights": [_p, _p, _c_i64, _c_i64, _c_i64, _p],
     "gf2_conjugate_gates": [_p, _p, _c_i64, _c_i64, _c_i64, _p, _c_i64, ctypes.POINTER(_c_i64)],
     "gf2_syndrome_table": [_p, _p, _c_i64, _c_i64, _c_i64, _p, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)],
+    "gf2_syndrome_table_wide": [_p, _p, _c_i64, _c_i64, _c_i64, _p, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)],
     "gf2_check_create": [_p, _p, _c_i64, _c_i64, _c_i64, _pp],
     "gf2_check_destroy": [_p, _p],
     "gf2_syndrome_batch": [_p, _p, _c_i64, _c_i64, _c_i64, _p, _c_i64, _c_i64, ctypes.c_int, _p, _c_i64],
@@ -184,6 +185,20 @@ def unpack_rows_into(words, out):
         check(fn(_ptr(words), m, n, words.shape[1], _ptr(out), n))
     else:
         out[...] = unpack_rows(words, n, dtype=out.dtype)
+    return out
+
+
+def unrank_supports(ranks, n, w):
+    """Supports (count x w, ascending positions) of the weight-w errors with the given ranks in the combinatorial number system:
+    positions c_1 < ... < c_w have rank C(c_1, 1) + ... + C(c_w, w) (the order gf2_syndrome_table_wide enumerates in)."""
+    import math
+    ranks = np.array(ranks, dtype=np.uint64)
+    out = np.zeros((ranks.size, w), dtype=np.int64)
+    for k in range(w, 0, -1):
+        column = np.array([min(math.comb(c, k), 1 << 63) for c in range(n + 1)], dtype=np.uint64)   # C(c, k), ascending in c
+        c = np.searchsorted(column, ranks, side='right').astype(np.int64) - 1                        # largest c with C(c, k) <= rank
+        out[:, k - 1] = c
+        ranks = ranks - column[c]
     return out
 
 
@@ -442,6 +457,20 @@ class Context(object):
         check(lib().gf2_syndrome_table(self.handle, _ptr(rows) if r else None, r, n,
                                        -1 if max_weight is None else max_weight, _ptr(dense), ctypes.byref(t),
                                        ctypes.byref(entries)))
+        return int(t.value), dense
+
+    TABLE_WIDE_MAX_N = 128
+
+    def syndrome_table_wide(self, packed, r, n, max_weight=None):
+        """The same for 64 < n <= 128: dense[key] = (weight << 32) | rank of the error inside its weight class (combinatorial
+        number system), or TABLE_EMPTY; unrank with unrank_supports."""
+        rows = np.zeros((max(1, r), 2), dtype="<u8")
+        rows[:r, :packed.shape[1]] = packed[:r, :2]
+        dense = np.empty(1 << r, dtype="<u8")
+        t, entries = _c_i64(), _c_i64()
+        check(lib().gf2_syndrome_table_wide(self.handle, _ptr(rows) if r else None, r, n,
+                                            -1 if max_weight is None else max_weight, _ptr(dense), ctypes.byref(t),
+                                            ctypes.byref(entries)))
         return int(t.value), dense
 
     # -- syndromes ----------------------------------------------------------------------------------------

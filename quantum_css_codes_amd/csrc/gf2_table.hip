@@ -1,4 +1,4 @@
-// css_code.syndrome_table (css_code.py:715-735) on the device for codes of at most 64 bits and 24 checks (gfx950).
+// css_code.syndrome_table (css_code.py:715-735) on the device for codes of at most 128 bits and 24 checks (gfx950).
 //
 // The reference walks the weight classes w = 0, 1, 2, ..., maps every error of weight w to vec_to_int(H e mod 2)
 // (bin_matrix.py:36-43: row 0 is the most significant bit) and stops at the first class that contains a syndrome
@@ -73,6 +73,150 @@ __global__ void table_sweep_kernel(u64* __restrict__ table, u64 entries, int w) 
 __global__ void table_fill_kernel(u64* __restrict__ table, u64 entries) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < entries) table[i] = TBL_EMPTY;
+}
+
+// ---- 64 < n <= 128 -------------------------------------------------------------------------------------------------------
+// The same search with two-word errors.  A table slot cannot hold a 128-bit error and be claimed by one atomic, so it holds
+// (weight << 32) | rank, the error's rank inside its weight class in the combinatorial number system: a class with more than
+// 2^24 errors cannot fit a table of at most 2^24 syndromes (pigeonhole, checked on the host), so every rank that is ever
+// written fits 32 bits.  The host unranks the entries it reads back.
+typedef unsigned __int128 u128;
+
+struct TableRowsWide {
+    u64 lo[TBL_MAX_R], hi[TBL_MAX_R];
+};
+
+__global__ __launch_bounds__(256) void table_class_wide_kernel(TableRowsWide h, int r, int n, int w, u64 total,
+                                                               const u64* __restrict__ binom, u64* __restrict__ table,
+                                                               int* __restrict__ collide) {
+    __shared__ u64 cw[129];                                         // C(c, k), c <= 128, for the k being unranked
+    const u64 lane_first = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * TBL_RUN;
+    u128 e = 0;
+    u64 rank = lane_first;
+    for (int k = w; k >= 1; --k) {
+        __syncthreads();
+        if (threadIdx.x < 129) cw[threadIdx.x] = binom[threadIdx.x * 129 + k];
+        __syncthreads();
+        if (lane_first < total) {
+            int c = k - 1;
+            while (c + 1 < n && cw[c + 1] <= rank) ++c;
+            e |= (u128)1 << c;
+            rank -= cw[c];
+        }
+    }
+    if (lane_first >= total) return;
+    u64 left = total - lane_first < TBL_RUN ? total - lane_first : TBL_RUN;
+    u64 my_rank = lane_first;
+    for (; left; --left, ++my_rank) {
+        if (*reinterpret_cast<volatile int*>(collide)) return;
+        const u64 elo = (u64)e, ehi = (u64)(e >> 64);
+        u64 key = 0;
+#pragma unroll
+        for (int i = 0; i < TBL_MAX_R; ++i)
+            if (i < r) key = (key << 1) | (u64)((__popcll(h.lo[i] & elo) + __popcll(h.hi[i] & ehi)) & 1);
+        if (atomicCAS(&table[key], TBL_EMPTY, ((u64)w << 32) | my_rank) != TBL_EMPTY) {
+            atomicExch(collide, 1);
+            return;
+        }
+        if (left > 1) {                                             // Gosper on 128 bits: next word with the same popcount
+            const u128 lowest = e & (~e + 1);
+            const u128 ripple = e + lowest;
+            const int tz = (u64)lowest ? __ffsll((long long)(u64)lowest) - 1 : 64 + __ffsll((long long)(u64)(lowest >> 64)) - 1;
+            e = (((ripple ^ e) >> 2) >> tz) | ripple;
+        }
+    }
+}
+
+__global__ void table_sweep_wide_kernel(u64* __restrict__ table, u64 entries, int w) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < entries && table[i] != TBL_EMPTY && (int)(table[i] >> 32) == w) table[i] = TBL_EMPTY;
+}
+
+extern "C" int gf2_syndrome_table_wide(gf2_ctx* ctx, const uint64_t* h_rows, int64_t r, int64_t n, int64_t max_weight,
+                                       uint64_t* table_out, int64_t* t_out, int64_t* entries_out) {
+    if (!ctx || !table_out || !t_out) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_table_wide: null argument");
+    if (r < 0 || r > TBL_MAX_R || n < 0 || n > 128) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_table_wide: needs n <= 128 and r <= %d", TBL_MAX_R);
+    if (r > 0 && !h_rows) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_table_wide: null rows");
+    GF2_TRY(gf2_ctx_activate(ctx));
+    TableRowsWide rows;
+    for (int i = 0; i < TBL_MAX_R; ++i) {
+        rows.lo[i] = i < r ? h_rows[2 * i] : 0ull;
+        rows.hi[i] = i < r ? h_rows[2 * i + 1] : 0ull;
+    }
+    std::vector<u64> binom_vec(129 * 129);                          // Pascal's triangle, saturated just above 2^63
+    u64* const binom_host = binom_vec.data();
+    for (int c = 0; c <= 128; ++c)
+        for (int k = 0; k <= 128; ++k) {
+            u64 v;
+            if (k == 0)
+                v = 1;
+            else if (c == 0)
+                v = 0;
+            else {
+                const u64 a = binom_host[(c - 1) * 129 + k - 1], b = binom_host[(c - 1) * 129 + k];
+                v = (a > (1ull << 63) || b > (1ull << 63) || a + b > (1ull << 63)) ? (1ull << 63) + 1 : a + b;
+            }
+            binom_host[c * 129 + k] = v;
+        }
+    const size_t binom_bytes = binom_vec.size() * sizeof(u64);
+    const u64 entries = 1ull << r;
+    u64 *table_dev = nullptr, *binom_dev = nullptr;
+    int* collide_dev = nullptr;
+    GF2_TRY(gf2_dev_alloc(ctx, entries * 8, (void**)&table_dev));
+    int rc = gf2_dev_alloc(ctx, binom_bytes, (void**)&binom_dev);
+    if (rc == GF2_OK) rc = gf2_dev_alloc(ctx, 4, (void**)&collide_dev);
+    int64_t t = n, kept = 0;
+    if (rc == GF2_OK) {
+        hipLaunchKernelGGL(table_fill_kernel, dim3((unsigned)gf2_cdiv((int64_t)entries, 256)), dim3(256), 0, ctx->stream,
+                           table_dev, entries);
+        if (hipMemcpyAsync(binom_dev, binom_host, binom_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+            hipMemsetAsync(collide_dev, 0, 4, ctx->stream) != hipSuccess)
+            rc = GF2_E_HIP;
+    }
+    for (int64_t w = 0; rc == GF2_OK && w <= n; ++w) {
+        if (max_weight >= 0 && w > max_weight) {
+            t = max_weight;
+            break;
+        }
+        const u64 total = binom_host[n * 129 + w];
+        bool collided = total > entries - (u64)kept;                // pigeonhole: more errors than free syndromes
+        if (!collided) {
+            const u64 lanes = (total + TBL_RUN - 1) / TBL_RUN;
+            hipLaunchKernelGGL(table_class_wide_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, ctx->stream, rows,
+                               (int)r, (int)n, (int)w, total, binom_dev, table_dev, collide_dev);
+            int flag = 0;
+            if (hipGetLastError() != hipSuccess ||
+                hipMemcpyAsync(&flag, collide_dev, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) {
+                gf2_set_error("gf2_syndrome_table_wide: weight class %lld failed on the device", (long long)w);
+                rc = GF2_E_HIP;
+                break;
+            }
+            collided = flag != 0;
+            if (collided)
+                hipLaunchKernelGGL(table_sweep_wide_kernel, dim3((unsigned)gf2_cdiv((int64_t)entries, 256)), dim3(256), 0,
+                                   ctx->stream, table_dev, entries, (int)w);
+        }
+        if (collided) {
+            t = w - 1;
+            break;
+        }
+        kept += (int64_t)total;
+    }
+    if (rc == GF2_OK) {
+        if (hipMemcpyAsync(table_out, table_dev, entries * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            gf2_set_error("gf2_syndrome_table_wide: copying the table back failed");
+            rc = GF2_E_HIP;
+        }
+    }
+    (void)gf2_dev_free(ctx, table_dev);
+    (void)gf2_dev_free(ctx, binom_dev);
+    (void)gf2_dev_free(ctx, collide_dev);
+    if (rc != GF2_OK) return rc;
+    *t_out = t;
+    if (entries_out) *entries_out = kept;
+    return GF2_OK;
 }
 
 extern "C" int gf2_syndrome_table(gf2_ctx* ctx, const uint64_t* h_rows, int64_t r, int64_t n, int64_t max_weight,

@@ -318,7 +318,7 @@ def syndrome_table(parity_check, max_weight=None):
     return it along with a lookup table from syndromes (as bin_matrix.vec_to_int keys) to error vectors
     of weight at most t (css_code.py:715-735).
 
-    Codes of at most 64 bits and 24 checks are searched entirely on the device (gf2_table.hip).  Otherwise each
+    Codes of at most 128 bits and 24 checks are searched entirely on the device (gf2_table.hip).  Otherwise each
     weight class is enumerated in bin_matrix.weight_w_vectors order, in chunks, and its syndromes are computed on the GPU; a class containing a syndrome already seen (in an earlier class or earlier in the
     same class) ends the search and is discarded as a whole, exactly as the reference's loop does.  Keys are
     formed and compared as machine words when r <= 63 (the reference's own keys are only meaningful there,
@@ -341,6 +341,23 @@ def syndrome_table(parity_check, max_weight=None):
         order = np.lexsort((~rev, np.bitwise_count(words)))
         errs = _native.unpack_rows(words[order].reshape(-1, 1), n, dtype=np.uint8).astype('int')
         return t, dict(zip(keys[order].tolist(), errs))
+    if ctx.TABLE_MAX_N < n <= ctx.TABLE_WIDE_MAX_N and r <= ctx.TABLE_MAX_R:
+        # two-word errors (n up to 127): the device table holds (weight, rank in the class)
+        t, dense = ctx.syndrome_table_wide(packed_h, r, n, max_weight)
+        keys = np.nonzero(dense != ctx.TABLE_EMPTY)[0]
+        weight = (dense[keys] >> np.uint64(32)).astype(np.int64)
+        rank = dense[keys] & np.uint64(0xFFFFFFFF)
+        table = {}
+        for w in range(int(weight.max()) + 1 if keys.size else 0):
+            sel = np.flatnonzero(weight == w)
+            supports = _native.unrank_supports(rank[sel], n, w)
+            # the reference's insertion order inside a class: supports ascending lexicographically (bin_matrix.py:57-72)
+            order = np.lexsort(tuple(supports[:, k] for k in range(w - 1, -1, -1))) if w else np.arange(sel.size)
+            errs = np.zeros((sel.size, n), dtype='int')
+            if w:
+                errs[np.arange(sel.size)[:, None], supports] = 1
+            table.update(zip(keys[sel][order].tolist(), errs[order]))
+        return t, table
     chk = ctx.check_create(packed_h, r, n) if r else None
     table = {}
     seen = np.zeros(0, dtype=np.uint64)                       # keys of `table`, sorted (r <= 63)

@@ -691,6 +691,26 @@ def test_syndrome_table_mid_size_codes_vs_oracle():
         assert key == bin_matrix.vec_to_int(np.mod(h @ err, 2))
 
 
+@pytest.mark.parametrize("case", [(65, 10, None), (96, 12, None), (127, 14, None), (127, 20, 2), (128, 24, 2), (100, 0, 1), (70, 7, None)])
+def test_syndrome_table_two_word_codes_on_the_device(case):
+    # SURVEY.md 8f item 2 names n = 23..127: 64 < n <= 128 is searched on the device with two-word errors (gf2_syndrome_table_wide);
+    # same threshold, same keys in the same insertion order, same error vectors as the oracle's restatement of css_code.py:715-735
+    n, r, cap = case
+    rng = np.random.default_rng(n * 31 + r)
+    h = rng.integers(0, 2, (r, n))
+    if r >= 14 and cap is None:
+        # a BCH-like check: columns are distinct and pairwise sums distinct for most draws; whatever t comes out must agree
+        h[:, :r] = np.identity(r, dtype=int)
+    t, table = css_code.syndrome_table(h, max_weight=cap)
+    want_t, want = cpu_ref.syndrome_table(h, max_weight=cap)
+    assert t == want_t
+    assert list(table.keys()) == [int(k) for k in want.keys()]
+    for k in list(table.keys())[::max(1, len(table) // 500)]:
+        assert np.array_equal(table[k], want[k])
+    for key, err in list(table.items())[::97]:
+        assert key == bin_matrix.vec_to_int(np.mod(h @ err, 2))
+
+
 def test_abi_argument_errors(ctx):
     # error codes and messages of the C ABI (include/gf2hip.h): nothing is computed, nothing crashes
     import ctypes

@@ -348,7 +348,7 @@ def test_emitted_decode_equals_the_gpu_syndrome_path(steane_h, rm15):
         ctx.sample_errors_dev(n, 77, 1000, 64, 0.06, 0.03, 0.05, ex, ez, 1)
         for buf, check, table in ((ex, code.parity_check_c2, code._c2_syndromes), (ez, code.parity_check_c1, code._c1_syndromes)):
             words = _native.unpack_rows(buf.download((64, 1), "<u8"), n)
-            syn = syndrome_batch(check, words.T).T                          # the GPU product, css_code.py:728
+            syn = syndrome_batch(check, words)                              # the GPU product, css_code.py:728
             for (errs, _), word, s in zip(decode_with_emitted_code(check, table, words), words, syn):
                 key = int(cpu_ref.vec_to_int(s))
                 want = np.asarray(table[key]) if key in table else np.zeros(n, dtype=int)
