@@ -344,8 +344,8 @@ def pauli_thresholds(p_x, p_y, p_z):
 
 
 def binomial_cdf_table(t_any, nb):
-    """cdf[k] = floor(2^32 * P(Bin(nb, q) <= k)), q = t_any / 2^32, in IEEE doubles with the operation order of
-    DESIGN.md "Sampler".  The number of errors of a word is K = #{k < nb : u >= cdf[k]}."""
+    """cdf[k] = 2^32 * P(Bin(nb, q) <= k) rounded to nearest and clamped to 2^32, q = t_any / 2^32, in IEEE doubles with the
+    operation order of DESIGN.md "Sampler".  The number of errors of a word is K = #{k < nb : u >= cdf[k]}."""
     cdf = [1 << 32] * 65
     if nb <= 0:
         return cdf
@@ -361,7 +361,7 @@ def binomial_cdf_table(t_any, nb):
     cum = 0.0
     for k in range(nb):
         cum += pmf
-        c = float(np.floor(cum * 4294967296.0))
+        c = float(np.floor(cum * 4294967296.0 + 0.5))
         if c > 4294967296.0:
             c = 4294967296.0
         cdf[k] = int(c)

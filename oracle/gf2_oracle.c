@@ -167,8 +167,8 @@ static u64 quantise(double x) {
     return (u64)t;
 }
 
-/* Inverse binomial CDF table: cdf[k] = floor(2^32 * P(Bin(nb, q) <= k)), q = t_any / 2^32, IEEE doubles in exactly
- * this operation order (DESIGN.md "Sampler").  K = number of k < nb with u >= cdf[k]. */
+/* Inverse binomial CDF table: cdf[k] = round-to-nearest(2^32 * P(Bin(nb, q) <= k)) clamped to 2^32, q = t_any / 2^32, IEEE
+ * doubles in exactly this operation order (DESIGN.md "Sampler").  K = number of k < nb with u >= cdf[k]. */
 static void binomial_cdf(u64 t_any, int nb, u64* cdf) {
     for (int k = 0; k < 65; ++k) cdf[k] = 4294967296ull;
     if (nb <= 0) return;
@@ -182,7 +182,7 @@ static void binomial_cdf(u64 t_any, int nb, u64* cdf) {
     double cum = 0.0;
     for (int k = 0; k < nb; ++k) {
         cum += pmf;
-        double c = __builtin_floor(cum * 4294967296.0);
+        double c = __builtin_floor(cum * 4294967296.0 + 0.5);
         if (c > 4294967296.0) c = 4294967296.0;
         cdf[k] = (u64)c;
         pmf = pmf * (double)(nb - k) / (double)(k + 1) * q / om;

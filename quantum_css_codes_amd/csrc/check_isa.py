@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""
+Build-time guard for the hand-scheduled kernels of gf2_slabs.hip (run by `make`, see Makefile: build/slabs_isa.ok).
+
+slab_compact_kernel<T> and slab_gather_fast_kernel<EXTRA> issue their loads through inline assembly and wait with hand-counted
+`s_waitcnt vmcnt(N)`.  The compiler neither sees those loads nor knows that their destination registers are still being filled,
+so two things must hold in the generated code, and a compiler upgrade or an innocent edit can break either:
+
+  1. Counts.  Vector memory operations complete in order; `vmcnt(N)` is right only if exactly the assumed operations are issued
+     between two counted waits.  Checked: in the gather kernel's step loop every counted wait is followed by exactly
+     1 store + 1 record load + 1 identity load (+ 1 for EXTRA) before the next one; in the compact kernel every sub-pass issues
+     exactly T loads between counted waits (plus the tile's 4 record stores once per tile); no scratch (spill) traffic at all.
+  2. Registers in flight.  Between a load's issue and the wait that covers it no instruction may read or write its destination
+     registers (DESIGN.md section 3 records a compiler-placed v_mov of such a register that produced wrong syndromes).
+     Checked by replaying every kernel's instructions in text order against a FIFO of outstanding operations: `vmcnt(N)`
+     retires all but the youngest N; any other access to a register of an operation still in the FIFO is an error (see replay).
+
+Usage: check_isa.py <file.s> (the output of hipcc -S --cuda-device-only gf2_slabs.hip).  Exit code 1 on a violation.
+"""
+import re
+import sys
+
+KERNELS = {
+    "slab_gather_fast_kernelILb0E": {"step_vmem": 3, "wait": 3},
+    "slab_gather_fast_kernelILb1E": {"step_vmem": 4, "wait": 4},
+    "slab_compact_kernelILi4E": {"rounds": 4},
+    "slab_compact_kernelILi5E": {"rounds": 5},
+    "slab_compact_kernelILi6E": {"rounds": 6},
+    "slab_compact_kernelILi8E": {"rounds": 8},
+}
+VMEM = re.compile(r"^(global|buffer|scratch|flat)_(load|store|atomic)")
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def kernels_in(path):
+    """{mangled name: [(line number, instruction text, inside inline asm)]}"""
+    found, name, in_asm = {}, None, False
+    for no, line in enumerate(open(path), 1):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            name = m.group(1)
+            found[name] = []
+            continue
+        if name is None:
+            continue
+        text = line.split(";")[0].strip() if "#ASM" not in line else line.strip()
+        if "#ASMSTART" in line:
+            in_asm = True
+            continue
+        if "#ASMEND" in line:
+            in_asm = False
+            continue
+        if not text or text.startswith("."):
+            if text.startswith(".LBB") or re.match(r"^\.LBB\w+:", line):
+                found[name].append((no, line.strip().split(":")[0] + ":", False))
+            continue
+        found[name].append((no, text, in_asm))
+        if text.startswith("s_endpgm"):
+            name = None
+    return found
+
+
+def step(fifo, inst, errors, kernel):
+    """Applies one instruction to the FIFO of outstanding vector memory operations (tuples (destination registers, line))."""
+    no, text, _ = inst
+    op = text.split()[0]
+    operands = text[len(op):]
+    if op == "s_waitcnt":
+        m = re.search(r"vmcnt\((\d+)\)", text)
+        return fifo[max(0, len(fifo) - int(m.group(1))):] if m else fifo
+    touched = regs_of(operands)
+    for dst, where in fifo:
+        clash = dst & touched
+        if clash:
+            errors.add("%s line %d: `%s` touches v%s, still being filled by the load of line %d"
+                       % (kernel, no, text, sorted(clash), where))
+    if VMEM.match(op):
+        first = operands.split(",")[0]
+        dst = frozenset(regs_of(first)) if "_load" in op or "rtn" in op else frozenset()
+        fifo = (fifo + ((dst, no),))[-MAX_FIFO:]
+    return fifo
+
+
+MAX_FIFO = 48
+
+
+def replay(stream, errors, kernel):
+    """Replays the kernel in text order.  The hand-scheduled loops are unrolled (four gather steps, two compact sub-passes) over
+    the same rotating registers and laid out in execution order, so the text shows every steady-state overlap of a load in
+    flight with the code of the following steps, except the one across the back edge, which repeats the pattern inside.
+    if / else diamonds are exclusive paths: the else part starts from the FIFO as it was at the branch."""
+    fifo = ()
+    at_branch = {}
+    prev = ""
+    for inst in stream:
+        no, text, in_asm = inst
+        if text.endswith(":"):
+            label = text[:-1]
+            if prev.startswith("s_branch") and label in at_branch:
+                fifo = at_branch[label]
+            prev = text
+            continue
+        m = re.match(r"s_cbranch\w*\s+(\.LBB\w+)", text)
+        if m:
+            at_branch.setdefault(m.group(1), fifo)
+        fifo = step(fifo, inst, errors, kernel)
+        prev = text
+
+
+def check_counts(name, stream, spec, errors):
+    ops = [(no, text, in_asm) for no, text, in_asm in stream if not text.endswith(":")]
+    if any(text.startswith("scratch_") for _, text, _ in ops):
+        errors.add("%s: scratch (spill) traffic in a hand-scheduled kernel" % name)
+    waits = [i for i, (_, text, in_asm) in enumerate(ops) if in_asm and text.startswith("s_waitcnt vmcnt(")]
+    if "step_vmem" in spec:
+        counted = [i for i in waits if ops[i][1] == "s_waitcnt vmcnt(%d)" % spec["wait"]]
+        if len(counted) < 4:
+            errors.add("%s: expected the four counted waits of the unrolled step loop, found %d" % (name, len(counted)))
+        for a, b in zip(counted, counted[1:]):
+            between = [text.split()[0] for _, text, _ in ops[a:b] if VMEM.match(text.split()[0])]
+            stores = sum(1 for o in between if "_store" in o)
+            loads = sum(1 for o in between if "_load" in o)
+            if (stores, loads) != (1, spec["step_vmem"] - 1):
+                errors.add("%s line %d: a step issues %d stores and %d loads, the wait counts assume 1 and %d"
+                              % (name, ops[a][0], stores, loads, spec["step_vmem"] - 1))
+    else:
+        rounds = spec["rounds"]
+        loads_between = []
+        for a, b in zip(waits, waits[1:] + [len(ops)]):
+            between = [text.split()[0] for _, text, asm in ops[a:b] if asm and VMEM.match(text.split()[0])]
+            loads_between.append((ops[a][0], sum(1 for o in between if "_load" in o and "dwordx2" in o), ops[a][1]))
+        inside = [(no, n, w) for no, n, w in loads_between if w in ("s_waitcnt vmcnt(%d)" % rounds, "s_waitcnt vmcnt(%d)" % (rounds + 4))]
+        if sum(1 for _, n, _ in inside if n) < 2:
+            errors.add("%s: the two unrolled sub-passes with their counted waits were not found" % name)
+        for no, n, w in inside:
+            if n == 0:                                  # the two alternative waits of a sub-pass (first two / later ones) stand next to each other
+                continue
+            if n not in (rounds, 2 * rounds):          # one sub-pass refill (uniform path and clamped path are both in the text)
+                errors.add("%s line %d: %d row loads follow `%s`, a sub-pass refills exactly %d" % (name, no, n, w, rounds))
+
+
+def main(path):
+    errors = set()
+    found = kernels_in(path)
+    seen = 0
+    for name, stream in found.items():
+        spec = next((v for k, v in KERNELS.items() if k in name), None)
+        if spec is None:
+            continue
+        seen += 1
+        check_counts(name, stream, spec, errors)
+        replay(stream, errors, name)
+    if seen < 3:
+        errors.add("only %d of the hand-scheduled kernels were found in %s" % (seen, path))
+    for e in sorted(errors):
+        print("check_isa: " + e)
+    print("check_isa: %d kernels, %d problems" % (seen, len(errors)))
+    return 1 if errors else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1]))

@@ -66,8 +66,10 @@ __device__ __forceinline__ void stage_cdf(const SamplerTables& tb, u64* cdf_lds)
     __syncthreads();
 }
 
-// Inverse binomial CDF as integers: cdf[k] = floor(2^32 * P(Bin(nb, q) <= k)), q = T / 2^32, in IEEE doubles with
-// this exact operation order (oracle/gf2_oracle.c and oracle/cpu_ref.py repeat it).  K = #{k < nb : u >= cdf[k]}.
+// Inverse binomial CDF as integers: cdf[k] = round(2^32 * P(Bin(nb, q) <= k)) (to nearest, clamped to 2^32), q = T / 2^32, in
+// IEEE doubles with this exact operation order (oracle/gf2_oracle.c and oracle/cpu_ref.py repeat it).
+// K = #{k < nb : u >= cdf[k]}.  Rounding to nearest matters in the tail: a sum that ends one ulp short of 1.0 must still give
+// 2^32 (never reached by u <= 2^32 - 1), not 2^32 - 1, or u = 2^32 - 1 would make all nb qubits of the word err.
 static inline void binomial_cdf_table(uint64_t t_any, int nb, u64* cdf) {
     for (int k = 0; k < 65; ++k) cdf[k] = 4294967296ull;
     if (nb <= 0) return;
@@ -81,7 +83,7 @@ static inline void binomial_cdf_table(uint64_t t_any, int nb, u64* cdf) {
     double cum = 0.0;
     for (int k = 0; k < nb; ++k) {
         cum += pmf;
-        double c = __builtin_floor(cum * 4294967296.0);
+        double c = __builtin_floor(cum * 4294967296.0 + 0.5);
         if (c > 4294967296.0) c = 4294967296.0;
         cdf[k] = (u64)c;
         pmf = pmf * (double)(nb - k) / (double)(k + 1) * q / om;

@@ -341,6 +341,25 @@ def test_sampler_is_a_function_of_seed_and_index():
     assert ez.all() and not ex.any()
 
 
+def test_sampler_count_table_tail():
+    # the inverse-CDF table is non-decreasing, ends at 2^32 and no draw (u <= 2^32 - 1) can yield more errors than the
+    # binomial's own 2^-32 quantile: a sum that ends an ulp short of 1.0 must not leave 2^32 - 1 in the tail
+    from math import comb
+    for p_t, nb in ((0.012, 64), (0.01, 33), (0.01, 64), (0.3, 64), (1e-6, 64), (0.5, 7), (0.999, 64)):
+        t_any = ref.quantise_probability(p_t)
+        cdf = ref.binomial_cdf_table(t_any, nb)
+        q = t_any / 2.0**32
+        assert all(cdf[k] <= cdf[k + 1] for k in range(nb)) and cdf[nb] == 1 << 32
+        assert abs(((1 << 32) - cdf[nb - 1]) - q**nb * 2.0**32) <= 1.0          # P(all nb qubits err) = q^nb, to one unit
+        tail = 1.0
+        for k in range(nb):
+            tail -= comb(nb, k) * q**k * (1 - q)**(nb - k)        # P(K > k)
+            if tail < 2.0**-34:
+                assert cdf[k] == 1 << 32, (p_t, nb, k)
+        worst = sum(1 for k in range(nb) if (1 << 32) - 1 >= cdf[k])          # errors drawn by the largest u
+        assert worst < nb or q**nb >= 2.0**-33
+
+
 def test_sampler_rates():
     n, count = 64 * 4, 300
     tot = np.zeros(3)
