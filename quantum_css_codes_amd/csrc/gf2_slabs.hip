@@ -32,6 +32,7 @@
 #define CMP_SUB 8                             // samples per compaction sub-pass
 #define REC_SLOTS 32                          // 16-bit slots per record: count + 31 columns
 #define REC_OVER 0xFFu                        // count byte of a sample that was finished by the slow routine
+#define REC_DONE 0x4000u                      // slot 0 of a sample finished by the slow routine whose count byte still stands
 #define REC_FLAG 0xFFFFu                      // its partial weights
 #define REC_STRAY 0xFF80u                     // | tile-local sample index: partial weight of a sample that has a column compact left out
 #define GAT_THREADS 1024
@@ -41,6 +42,17 @@
 #define SLAB_MAX_BINS 2304
 #define SLAB_MAX_BATCH (1 << 22)              // most samples per pass through the workspace (32-bit byte offsets of 512-byte rows)
 #define SLAB_DEFAULT_BATCH (1 << 21)
+
+// Records of a tile of 64 samples, sorted by count: the 32 shortest as 32-byte records (slot 0 + 15 columns), the 32 longest
+// as 64-byte records (slot 0 + 31 columns) -- 3 KiB per tile instead of 4.  Seven samples in ten list at most 15 columns at the
+// benchmark's rate, so the lower half of a sorted tile fits (a tile where it does not -- more than 32 samples with 16 or more
+// columns -- has the misfits finished on the spot like samples beyond 31 columns).  Group g = tile * 4 + quartile holds 16 records.
+#define TILE_REC_BYTES 3072
+#define SHORT_SLOTS 16
+__device__ __forceinline__ unsigned int record_quarter_offset(unsigned int g, unsigned int lane_rec, unsigned int part) {
+    const unsigned int tile = g >> 2, q = g & 3u;
+    return tile * TILE_REC_BYTES + (q < 2 ? q * 512u + lane_rec * 32u + (part & 1u) * 16u : (q - 1u) * 1024u + lane_rec * 64u + part * 16u);
+}
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(3))) u32x4* lds_u32x4_ptr;
@@ -135,7 +147,7 @@ __device__ __forceinline__ void wait_pairs(u64 (&w)[T]) {
 }
 
 template <int T>
-__global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 6 ? 4 : 3)) void slab_compact_kernel(CompactArgs a) {
+__global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void slab_compact_kernel(CompactArgs a) {
     __shared__ CompactWaveLds lds_all[CMP_WAVES];
     __shared__ unsigned int wlist[64];
     __shared__ u64 wmask[64];
@@ -312,20 +324,9 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 6 ? 4 : 3)) void sl
         // lane = sample from here on
         const unsigned int c = L.cnt[lane];
         const bool over = c >= REC_SLOTS;
-        {
-            u64 todo = __ballot(over && s0 + lane < a.batch);
-            unsigned int* const slow_list = reinterpret_cast<unsigned int*>(&L);    // the item list is free now
-            while (todo) {
-                const int j = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const u64 ww = lane < words ? a.e[(s0 + j) * a.lde + lane] : 0ull;
-                const unsigned int wt = sparse_component_weight(ww, side, a.n, lane, slow_list);
-                if (lane == 0) atomicAdd(&a.hist[wt], 1ull);
-            }
-            wave_lds_sync();
-        }
         // Records leave the tile sorted by count (counting sort over the 64 samples): the gather kernel walks 16 records
-        // per step up to the largest count among them.  Slot 0 = count (REC_OVER: finished by the slow routine) | tile-local sample << 8.
+        // per step up to the largest count among them, and the lower half of the tile is stored as 32-byte records.
+        // Slot 0 = count (REC_OVER: finished by the slow routine) | tile-local sample << 8.
         const unsigned int key = over ? 0u : c;
         unsigned int* const sort_bins = reinterpret_cast<unsigned int*>(&L);          // 32 bins + 32 offsets, item list is free
         if (lane < 32) sort_bins[lane] = 0;
@@ -343,13 +344,36 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 6 ? 4 : 3)) void sl
         }
         wave_lds_sync();
         const unsigned int rank = sort_bins[32 + key] + in_bucket;
-        u32x4 R[4];
+        wave_lds_sync();
+        // finished here and now: more columns than a record holds, or too many for the 32-byte record its rank gives it
+        const bool misfit = over || (rank < 32 && c >= SHORT_SLOTS);
+        {
+            u64 todo = __ballot(misfit && s0 + lane < a.batch);
+            unsigned int* const slow_list = reinterpret_cast<unsigned int*>(&L);    // the item list is free now
+            while (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const u64 ww = lane < words ? a.e[(s0 + j) * a.lde + lane] : 0ull;
+                const unsigned int wt = sparse_component_weight(ww, side, a.n, lane, slow_list);
+                if (lane == 0) atomicAdd(&a.hist[wt], 1ull);
+            }
+            wave_lds_sync();
+        }
+        u32x4 R[4];                                                 // the records themselves were not touched by the sort or the slow routine
 #pragma unroll
         for (int q = 0; q < 4; ++q) R[q] = reinterpret_cast<const u32x4*>(L.rec)[lane * 4 + q];
-        R[0].x = (R[0].x & 0xFFFF0000u) | (over ? REC_OVER : c) | ((unsigned int)lane << 8);
-        u32x4* out = a.rec + (s0 + rank) * 4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) out[q] = R[q];
+        // a misfit of the lower half keeps its place and its (truncated) count, so that the last record of its step still
+        // carries the step's largest count; the gather kernel does its lookups and throws the result away
+        R[0].x = (R[0].x & 0xFFFF0000u) | (over ? REC_OVER : (misfit ? REC_DONE | (SHORT_SLOTS - 1) : c)) | ((unsigned int)lane << 8);
+        // four store instructions per tile whatever the data (the wait counts above): two for every record, two more for the long ones
+        char* const tile_out = reinterpret_cast<char*>(a.rec) + tile * TILE_REC_BYTES;
+        u32x4* const out = reinterpret_cast<u32x4*>(tile_out + (rank < 32 ? rank * 32u : 1024u + (rank - 32u) * 64u));
+        out[0] = R[0];
+        out[1] = R[1];
+        if (rank >= 32) {
+            out[2] = R[2];
+            out[3] = R[3];
+        }
         wave_lds_sync();
     }
     if (a.clk && lane == 0) atomicMax(&a.clk[1], (u64)wall_clock64());
@@ -390,8 +414,8 @@ __device__ __forceinline__ unsigned int entry_addr_hi(unsigned int part_base, un
 // and hand the slots to each other with DPP quad broadcasts -- one memory instruction per step instead of four (address
 // processing of a wave-wide load with scattered addresses costs about as much as the whole lookup loop).  Positions past
 // the end read zeros.
-__device__ __forceinline__ u32x4 fetch_record(__amdgpu_buffer_rsrc_t rec_rsrc, unsigned int pos, unsigned int part16) {
-    return __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, (pos << 6) | part16, 0, 0);
+__device__ __forceinline__ u32x4 fetch_record(__amdgpu_buffer_rsrc_t rec_rsrc, unsigned int group, unsigned int lane_rec, unsigned int part) {
+    return __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc, record_quarter_offset(group, lane_rec, part), 0, 0);
 }
 
 // Value of `v` in lane Q of this lane's quad.
@@ -517,7 +541,7 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
     bool mask_ident = a.ident_off >= 0 && (slab + 1) * SLAB_ROWS > a.r;              // uniform: rows past r in this slab
     if (a.ident_off >= 0 && slab_dw0 + 17 > row_dwords) mask_ident = true;           // or dwords past the end of the row
     const __amdgpu_buffer_rsrc_t rec_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.rec), 0, (int)(a.batch_pad * 64), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(a.rec), 0, (int)(((a.batch + 63) >> 6) * TILE_REC_BYTES), 0x00020000);
     unsigned short* const pw = a.pw + (int64_t)slab * a.batch_pad;
 
     const unsigned int ngroups = (unsigned int)(((a.batch + 63) >> 6) << 2);   // 16 records per wavefront step, whole tiles
@@ -529,27 +553,29 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
     // (the loop is unrolled by three), so nothing is copied between stages.
     u32x4 RA, RB, RC;
     unsigned int iwA[5], iwB[5], iwC[5];
-    const unsigned int part16 = (unsigned int)part * 16u;
     unsigned int grp = (unsigned int)share * GAT_WAVES + wave, k = 0;
     // A tile's four groups of 16 records ascend by count and a wavefront's group index keeps its residue mod 4 (the stride is a
     // multiple of 4), so without a rotation wavefront w would meet quartile w mod 4 of every tile -- the same quarter of the
     // wavefronts (one SIMD's, as they are dealt out) would get all the long records.  Step k takes quartile (w + k) mod 4.
-    auto rec_pos = [&](unsigned int g, unsigned int rot) { return ((g & ~3u) | ((g + rot) & 3u)) * 16 + lane_rec; };
-    RA = fetch_record(rec_rsrc, rec_pos(grp, 0), part16);
-    RB = fetch_record(rec_rsrc, rec_pos(grp + stride, 1), part16);
+    auto rec_grp = [&](unsigned int g, unsigned int rot) { return (g & ~3u) | ((g + rot) & 3u); };
+    auto rec_pos = [&](unsigned int g, unsigned int rot) { return rec_grp(g, rot) * 16 + lane_rec; };
+    RA = fetch_record(rec_rsrc, rec_grp(grp, 0), lane_rec, (unsigned int)part);
+    RB = fetch_record(rec_rsrc, rec_grp(grp + stride, 1), lane_rec, (unsigned int)part);
     fetch_ident(a, record_sample(rec_pos(grp, 0), quad_bcast<0>(RA.x)), row_bytes, dw0, row_dwords, aligned16, id_sh,
                 part == 3, iwA);
 
     auto step = [&](const u32x4& R, unsigned int (&iw)[5], const u32x4& Rnext, u32x4& Rfar, unsigned int (&iwnext)[5]) {
         const unsigned int pos = rec_pos(grp, k);
-        Rfar = fetch_record(rec_rsrc, rec_pos(grp + 2 * stride, k + 2), part16);
+        Rfar = fetch_record(rec_rsrc, rec_grp(grp + 2 * stride, k + 2), lane_rec, (unsigned int)part);
         fetch_ident(a, record_sample(rec_pos(grp + stride, k + 1), quad_bcast<0>(Rnext.x)), row_bytes, dw0, row_dwords, aligned16, id_sh,
                     part == 3, iwnext);
         const unsigned int head = quad_bcast<0>(R.x);               // slot 0 (count, tile-local sample) and slot 1
         const unsigned int slot0 = head & 0xFFFFu;
-        const bool flagged = (slot0 & 0xFFu) == REC_OVER;
+        // finished by the compact kernel: REC_OVER sorts first (count 0); a REC_DONE record sits where its count put it, at
+        // the top of the tile's lower half, and keeps the count byte, because the step's last record sets the lookups of all
+        const bool flagged = (slot0 & 0xFFu) == REC_OVER || (slot0 & REC_DONE) != 0;
         const bool valid = record_sample(pos, slot0) < (unsigned int)a.batch;
-        const unsigned int c = flagged || !valid ? 0u : (slot0 & 0xFFu);
+        const unsigned int c = (slot0 & 0xFFu) == REC_OVER || !valid ? 0u : (slot0 & 0xFFu);
         if (from_neighbour) {                                       // quad_perm [1,2,3,3]: lane p takes lane p + 1's first dword
             const unsigned int nb = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)iw[0], 0xF9, 0xF, 0xF, false);
             if (part != 3) iw[4] = nb;
@@ -687,7 +713,7 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
     const u64 rec_base = reinterpret_cast<u64>(a.rec);
     const i32x4 rsrc = {__builtin_amdgcn_readfirstlane((int)(unsigned int)rec_base),
                         __builtin_amdgcn_readfirstlane((int)((unsigned int)(rec_base >> 32) & 0xFFFFu)),
-                        __builtin_amdgcn_readfirstlane((int)(a.batch_pad * 64)), 0x00020000};
+                        __builtin_amdgcn_readfirstlane((int)(((a.batch + 63) >> 6) * TILE_REC_BYTES)), 0x00020000};
     const char* const ident_base = reinterpret_cast<const char*>(a.e) + dw0 * 4u;
     const unsigned int fifth_off = ((dw0 + 4 < row_dwords ? dw0 + 4 : 0u) - dw0) * 4u;       // from ident_base, wraps
 
@@ -696,8 +722,15 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
     const unsigned int lane_rec = lane >> 2;
     const unsigned int part16 = (unsigned int)part * 16u;
 
-    auto issue_record = [&](u32x4& R, unsigned int pos) {
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(R) : "v"((pos << 6) | part16), "s"(rsrc) : "memory");
+    // reverse: group g stands for group ngroups - 1 - g (groups past the end stay past the end: their records read as zeros)
+    const unsigned int last_group = a.reverse ? ngroups - 1u : 0u;
+    // the record quarter of this lane in group g (uniform): 32-byte records in the lower half of a tile, 64-byte ones above
+    const unsigned int short_lane = lane_rec * 32u + ((unsigned int)part & 1u) * 16u, long_lane = lane_rec * 64u + part16;
+    auto issue_record = [&](u32x4& R, unsigned int g) {
+        const unsigned int group = a.reverse && g < ngroups ? last_group - g : g;
+        const unsigned int q = group & 3u;
+        const unsigned int off = (group >> 2) * TILE_REC_BYTES + (q < 2 ? q * 512u + short_lane : (q - 1u) * 1024u + long_lane);
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(R) : "v"(off), "s"(rsrc) : "memory");
     };
     auto issue_ident = [&](u32x4& I, unsigned int& E, unsigned int pos, unsigned int slot0_dword) {
         const unsigned int sample = record_sample(pos, slot0_dword);
@@ -718,14 +751,12 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
         return (unsigned int)share * GAT_WAVES + (t & (GAT_WAVES - 1)) + (t / GAT_WAVES) * stride;
     };
-    // reverse: group g stands for group ngroups - 1 - g (groups past the end stay past the end: their records read as zeros)
-    const unsigned int last_group = a.reverse ? ngroups - 1u : 0u;
     auto rec_pos = [&](unsigned int g) { return (a.reverse && g < ngroups ? last_group - g : g) * 16 + lane_rec; };
     unsigned int G0 = take(), G1 = take(), G2 = take(), G3 = take();
-    issue_record(R0, rec_pos(G0));
-    issue_record(R1, rec_pos(G1));
-    issue_record(R2, rec_pos(G2));
-    issue_record(R3, rec_pos(G3));
+    issue_record(R0, G0);
+    issue_record(R1, G1);
+    issue_record(R2, G2);
+    issue_record(R3, G3);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(R0), "+v"(R1), "+v"(R2), "+v"(R3)::"memory");
     issue_ident(I0, E0, rec_pos(G0), quad_bcast<0>(R0.x));
     issue_ident(I1, E1, rec_pos(G1), quad_bcast<0>(R1.x));
@@ -741,9 +772,11 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         const unsigned int pos = rec_pos(G);
         const unsigned int head = quad_bcast<0>(R.x);               // slot 0 (count, tile-local sample) and slot 1
         const unsigned int slot0 = head & 0xFFFFu;
-        const bool flagged = (slot0 & 0xFFu) == REC_OVER;
+        // finished by the compact kernel: REC_OVER sorts first (count 0); a REC_DONE record sits where its count put it, at
+        // the top of the tile's lower half, and keeps the count byte, because the step's last record sets the lookups of all
+        const bool flagged = (slot0 & 0xFFu) == REC_OVER || (slot0 & REC_DONE) != 0;
         const bool valid = record_sample(pos, slot0) < (unsigned int)a.batch;
-        const unsigned int c = flagged || !valid ? 0u : (slot0 & 0xFFu);
+        const unsigned int c = (slot0 & 0xFFu) == REC_OVER || !valid ? 0u : (slot0 & 0xFFu);
         unsigned int stray = 0;
         if (has_stray) {
             stray = (I.x & sm[0]) | (I.y & sm[1]) | (I.z & sm[2]) | (I.w & sm[3]);
@@ -785,7 +818,7 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         // per step, in this order -- the wait counts above depend on it
         asm volatile("" ::: "memory");
         G = take();
-        issue_record(R, rec_pos(G));
+        issue_record(R, G);
         issue_ident(I, E, rec_pos(Gp2), quad_bcast<0>(Rp2.x));
     };
 #pragma unroll 1
@@ -1038,7 +1071,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
         // rounds per sub-pass: ceil(8 * words with non-identity columns / 64); workgroups per CU as the variant's registers allow
         {
             const int rounds = (CMP_SUB * non_identity_words(ck, stray.skip_words) + 63) / 64;
-            const int per_cu = rounds <= 4 ? 5 : (rounds <= 6 ? 4 : 3);
+            const int per_cu = rounds <= 4 ? 5 : (rounds <= 5 ? 4 : 3);
             if (cblocks > (int64_t)ctx->num_cus * per_cu) cblocks = (int64_t)ctx->num_cus * per_cu;
             const dim3 cgrid((unsigned)cblocks), cblock(CMP_THREADS);
             if (rounds <= 4)

@@ -805,7 +805,10 @@ def test_normalize_with_a_column_swap_at_every_step(case, ctx):
                                   # the hand-scheduled gather kernel (identity words = 16-byte pieces) away from the benchmark's
                                   # shapes: fewer rows than a slab holds, a bit offset inside the dword, a slab cut by r
                                   (1000, 3000, 1024, 1300, 0.005), (700, 2600, 1285, 2200, 0.006), (300, 1536, 1152, 900, 0.01),
-                                  (1500, 4096, 2560, 777, 0.006), (513, 2048, 1408, 1000, 0.008), (2040, 4096, 2051, 650, 0.007)])
+                                  (1500, 4096, 2560, 777, 0.006), (513, 2048, 1408, 1000, 0.008), (2040, 4096, 2051, 650, 0.007),
+                                  # records of the lower half of a sorted tile are 32 bytes (15 columns): at these rates most tiles
+                                  # have more than 32 samples beyond that, and the misfits are finished by the compact kernel
+                                  (2048, 4096, 0, 3000, 0.0085), (2047, 4096, 2048, 2500, 0.008), (1024, 2304, 1024, 1500, 0.014)])
 def test_syndrome_slab_pipeline(case, ctx, route):
     # histogram-only calls take the LDS row-slab pipeline (compact -> gather -> combine) when the check qualifies; it must
     # agree with the oracle and with the column-gather kernel on sparse samples, on samples beyond the record capacity
