@@ -268,6 +268,8 @@ def rref_numbers(ctx):
     from quantum_css_codes_amd import _native
     res = {}
     rng = np.random.default_rng(4096)
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    traffic = json.load(open(tpath)).get("rref_bytes_per_call", {}) if os.path.exists(tpath) else {}
 
     def random_packed(m, n):
         ld = (n + 63) // 64
@@ -288,7 +290,15 @@ def rref_numbers(ctx):
             best = ms if best is None else min(best, ms)
         assert int(rk.download((batch,), np.int64)[0]) == min(m, n)
         gbs = batch * 2 * a.nbytes / best / 1e6
-        res["%dx%d_x%d" % (m, n, batch)] = {"ms": best, "GB/s": gbs, "frac_hbm_peak": gbs / HBM_PEAK_GBS}
+        key = "%dx%d_x%d" % (m, n, batch)
+        # integer work of Gauss-Jordan on packed words (what bin_matrix.py:27-29 does bit by bit): per pivot about m / 2 rows
+        # take the pivot row over the 3/4 of the words that can still change = rank * m/2 * ld * 3/4 64-bit XORs, two 32-bit
+        # lane-operations each, against 256 CUs x 64 lanes x 2.4 GHz; traffic = PMC bytes of the whole call (profiles/traffic.json)
+        lane_ops = batch * 2.0 * min(m, n) * (m / 2.0) * a.shape[1] * 0.75
+        moved = traffic.get(key)
+        res[key] = {"ms": best, "GB/s": gbs, "frac_hbm_peak": gbs / HBM_PEAK_GBS, "algorithmic_bytes": batch * 2 * a.nbytes,
+                    "traffic": moved, "moved_GB/s": (moved / best / 1e6) if moved else None,
+                    "int_op": {"lane_ops": lane_ops, "frac": lane_ops / (best / 1e3) / (256 * 64 * 2.4e9)}}
         buf.free(), piv.free(), rk.free()
     # many small matrices (one wavefront each, rows in registers): 256 MiB of 64 x 512 and of 128 x 512 matrices, read once
     # and written once
