@@ -196,14 +196,31 @@ __device__ __forceinline__ u64 readlane64(u64 v, int src) {
            (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, src);
 }
 
+// 64 x 64 bit transpose across a wavefront: lane i holds row i, on return lane j holds column j (six butterfly stages).
+template <int S>
+__device__ __forceinline__ u64 transpose_stage(u64 x, int lane, u64 m) {
+    const u64 y = __shfl_xor(x, S);
+    return (lane & S) ? ((x & ~m) | ((y >> S) & m)) : ((x & m) | ((y << S) & ~m));
+}
+__device__ __forceinline__ u64 transpose64(u64 x, int lane) {
+    x = transpose_stage<32>(x, lane, 0x00000000FFFFFFFFull);
+    x = transpose_stage<16>(x, lane, 0x0000FFFF0000FFFFull);
+    x = transpose_stage<8>(x, lane, 0x00FF00FF00FF00FFull);
+    x = transpose_stage<4>(x, lane, 0x0F0F0F0F0F0F0F0Full);
+    x = transpose_stage<2>(x, lane, 0x3333333333333333ull);
+    x = transpose_stage<1>(x, lane, 0x5555555555555555ull);
+    return x;
+}
+
 template <int RPT>
 __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict__ base, int64_t m, int64_t n, int64_t ld,
                                                                int64_t pw, int64_t* __restrict__ pivots_base, int64_t cap,
                                                                int32_t* __restrict__ pivrow_base, RrefState* __restrict__ states,
                                                                unsigned char* __restrict__ used_base, u64* __restrict__ d_base,
                                                                u64* __restrict__ snap_base) {
-    __shared__ u64 VT[2048];
-    __shared__ u64 V[64], csel[64], pword[64], win_w[RB_WIN], win_c[RB_WIN];
+    __shared__ u64 VT[2048];                                            // byte tables: of the probe rows' coefficients per round, of V at the end
+    __shared__ u64 TW[2048];                                            // byte tables of the probe rows' words (rounds that are followed by another)
+    __shared__ u64 V[64], csel[64], pword[64], win_w[RB_WIN], win_c[RB_WIN], fin_w[RB_WIN], fin_c[RB_WIN], CP[64], WP[64];
     __shared__ int win_row[RB_WIN], win_piv[RB_WIN], pbit[64], prow_l[64], wave_tot[RB_THREADS / 64], misc[4];
 
     const int64_t mat = blockIdx.x;
@@ -277,58 +294,106 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
         __syncthreads();
         const int nwin = total < RB_WIN ? total : RB_WIN;
         if (wave == 0) {
-            // Gauss-Jordan on the window inside one wavefront: entries lane and lane + 64
-            u64 ew[2], ec[2];
-            int er[2];
-            bool ep[2] = {false, false};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int idx = lane + 64 * h;
-                const bool live = idx < nwin;
-                ew[h] = live ? win_w[idx] : 0ull;
-                ec[h] = live ? win_c[idx] : 0ull;
-                er[h] = live ? win_row[idx] : -1;
+            // Gauss-Jordan on the window inside one wavefront, COLUMN-sliced: lane = panel column, bit i of (colw0, colw1) = window
+            // row i's bit in that column.  A step is a handful of scalar operations -- the column of bit b comes by readlane, its
+            // first row that is not a pivot yet becomes the pivot, every lane whose column has the pivot row's bit toggles the
+            // other rows of column b -- instead of two ballots over the rows and five readlanes of the pivot row's data.
+            // Coefficients are kept the same way (lane p: bit i = window row i took pivot p).  64 PROBE rows e_0 .. e_63 (third
+            // word) are eliminated along: row e_j ends with the coefficients and the word any row gets for having bit j, and
+            // elimination is linear in the row, so every row outside the pivots is finished with two table lookups instead of
+            // replaying the pivots one by one.
+            const u64 ew0 = lane < nwin ? win_w[lane] : 0ull, ew1 = lane + 64 < nwin ? win_w[lane + 64] : 0ull;
+            u64 colw0 = transpose64(ew0, lane), colw1 = transpose64(ew1, lane), colw2 = 1ull << lane;
+            u64 ccol0 = 0, ccol1 = 0, ccol2 = 0;
+            if (t > 0) {                                              // uniform: coefficients of earlier rounds
+                ccol0 = transpose64(lane < nwin ? win_c[lane] : 0ull, lane);
+                ccol1 = transpose64(lane + 64 < nwin ? win_c[lane + 64] : 0ull, lane);
             }
-            u64 newbits = 0;
+            u64 piv0 = 0, piv1 = 0, newbits = 0, todo = unresolved;
+            // what lane p keeps about pivot p: the pivot row's word and coefficients when chosen, its column, its window index.
+            // Lane tt's slots (and its coefficient words: no pivot tt before this round) are zero until step tt sets them: one
+            // v_writelane_b32 per dword with the lane in M0 (a select costs two instructions each: an SGPR value and an SGPR mask
+            // do not fit one VOP3; the compiler has no builtin for writelane and does not use M0 in this kernel).
+            unsigned int pw_lo = 0, pw_hi = 0, cs_lo = 0, cs_hi = 0, my_pbit = 0, my_prow = 0;
+            unsigned int x0l = (unsigned int)colw0, x0h = (unsigned int)(colw0 >> 32), x1l = (unsigned int)colw1, x1h = (unsigned int)(colw1 >> 32);
+            unsigned int x2l = (unsigned int)colw2, x2h = (unsigned int)(colw2 >> 32);
+            unsigned int c0l = (unsigned int)ccol0, c0h = (unsigned int)(ccol0 >> 32), c1l = (unsigned int)ccol1, c1h = (unsigned int)(ccol1 >> 32);
+            unsigned int c2l = 0, c2h = 0;
             int tt = t;
-            for (int b = 0; b < 64; ++b) {
-                if (!((unresolved >> b) & 1ull)) continue;
-                if (tt >= 64 || rank + tt >= m) break;
-                const u64 bal0 = __ballot(!ep[0] && ((ew[0] >> b) & 1ull));
-                const u64 bal1 = __ballot(!ep[1] && ((ew[1] >> b) & 1ull));
-                if (!(bal0 | bal1)) continue;
-                const int h = bal0 ? 0 : 1;
-                const int src = __ffsll((long long)(bal0 ? bal0 : bal1)) - 1;
-                const u64 pwd = readlane64(h ? ew[1] : ew[0], src);
-                const u64 pcs = readlane64(h ? ec[1] : ec[0], src);
-                const int prw = __builtin_amdgcn_readlane(h ? er[1] : er[0], src);
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    if (hh == h && lane == src) {
-                        ep[hh] = true;
-                    } else if ((ew[hh] >> b) & 1ull) {
-                        ew[hh] ^= pwd;
-                        ec[hh] |= 1ull << tt;
-                    }
+            // a ^ (b & c) in one instruction (v_bitop3_b32, truth table 0x78)
+            auto xor_and = [](unsigned int a, unsigned int bb, unsigned int cc) { return __builtin_amdgcn_bitop3_b32(a, bb, cc, 0x78); };
+            auto rl = [](unsigned int v, int src) { return (unsigned int)__builtin_amdgcn_readlane((int)v, src); };
+            while (todo && tt < 64 && rank + tt < m) {
+                const int b = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const unsigned int b0l = rl(x0l, b), b0h = rl(x0h, b), b1l = rl(x1l, b), b1h = rl(x1h, b);     // column b, rows 0..127
+                const u64 cb0 = ((u64)b0h << 32) | b0l, cb1 = ((u64)b1h << 32) | b1l;
+                const u64 cand0 = cb0 & ~piv0, cand1 = cb1 & ~piv1;
+                if (!(cand0 | cand1)) continue;                       // no pivot for this column inside the window
+                const unsigned int b2l = rl(x2l, b), b2h = rl(x2h, b);                                          // ... and the probe rows
+                unsigned int m0l = b0l, m0h = b0h, m1l = b1l, m1h = b1h;     // rows that take the pivot row: all with the bit but itself
+                unsigned int hit, pcs_src_l, pcs_src_h;                      // hit: all ones in the lanes whose column the pivot row has
+                int r;
+                if (cand0) {                                          // uniform; the usual case: a pivot among the first 64 window rows
+                    r = __ffsll((long long)cand0) - 1;
+                    const u64 keep = ~(1ull << r);
+                    m0l &= (unsigned int)keep;
+                    m0h &= (unsigned int)(keep >> 32);
+                    hit = (unsigned int)__builtin_amdgcn_sbfe((int)(r < 32 ? x0l : x0h), (unsigned int)(r & 31), 1u);
+                    pcs_src_l = c0l, pcs_src_h = c0h;
+                    piv0 |= 1ull << r;
+                } else {
+                    const int r1 = __ffsll((long long)cand1) - 1;
+                    r = 64 + r1;
+                    const u64 keep = ~(1ull << r1);
+                    m1l &= (unsigned int)keep;
+                    m1h &= (unsigned int)(keep >> 32);
+                    hit = (unsigned int)__builtin_amdgcn_sbfe((int)(r1 < 32 ? x1l : x1h), (unsigned int)(r1 & 31), 1u);
+                    pcs_src_l = c1l, pcs_src_h = c1h;
+                    piv1 |= 1ull << r1;
                 }
-                if (lane == 0) {
-                    pword[tt] = pwd;
-                    csel[tt] = pcs;
-                    pbit[tt] = b;
-                    prow_l[tt] = prw;
-                }
+                const u64 pwd = __ballot(hit != 0);                                                            // = the pivot row's word
+                const u64 pcs = __ballot((((r & 32) ? pcs_src_h : pcs_src_l) >> (r & 31)) & 1u);                // = its coefficients so far
+                x0l = xor_and(x0l, m0l, hit), x0h = xor_and(x0h, m0h, hit);
+                x1l = xor_and(x1l, m1l, hit), x1h = xor_and(x1h, m1h, hit);
+                x2l = xor_and(x2l, b2l, hit), x2h = xor_and(x2h, b2h, hit);
+                asm volatile(
+                    "s_mov_b32 m0, %12\n\t"
+                    "v_writelane_b32 %0, %13, m0\n\tv_writelane_b32 %1, %14, m0\n\tv_writelane_b32 %2, %15, m0\n\t"
+                    "v_writelane_b32 %3, %16, m0\n\tv_writelane_b32 %4, %17, m0\n\tv_writelane_b32 %5, %18, m0\n\t"
+                    "v_writelane_b32 %6, %19, m0\n\tv_writelane_b32 %7, %20, m0\n\tv_writelane_b32 %8, %21, m0\n\t"
+                    "v_writelane_b32 %9, %22, m0\n\tv_writelane_b32 %10, %23, m0\n\tv_writelane_b32 %11, %24, m0"
+                    : "+v"(c0l), "+v"(c0h), "+v"(c1l), "+v"(c1h), "+v"(c2l), "+v"(c2h), "+v"(pw_lo), "+v"(pw_hi), "+v"(cs_lo),
+                      "+v"(cs_hi), "+v"(my_pbit), "+v"(my_prow)
+                    : "s"(tt), "s"(m0l), "s"(m0h), "s"(m1l), "s"(m1h), "s"(b2l), "s"(b2h), "s"((unsigned int)pwd),
+                      "s"((unsigned int)(pwd >> 32)), "s"((unsigned int)pcs), "s"((unsigned int)(pcs >> 32)), "s"((unsigned int)b),
+                      "s"((unsigned int)r)
+                    : "m0");
                 newbits |= 1ull << b;
                 tt += 1;
             }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int idx = lane + 64 * h;
-                if (idx < nwin) {
-                    win_w[idx] = ew[h];
-                    win_c[idx] = ec[h];
-                    win_piv[idx] = ep[h] ? 1 : 0;
+            colw0 = ((u64)x0h << 32) | x0l, colw1 = ((u64)x1h << 32) | x1l, colw2 = ((u64)x2h << 32) | x2l;
+            ccol0 = ((u64)c0h << 32) | c0l, ccol1 = ((u64)c1h << 32) | c1l, ccol2 = ((u64)c2h << 32) | c2l;
+            const u64 my_pword = ((u64)pw_hi << 32) | pw_lo, my_csel = ((u64)cs_hi << 32) | cs_lo;
+            // the new pivot rows as they stand at the end of the round: word and coefficients (bit r across the lanes)
+            for (int p = t; p < tt; ++p) {
+                const int r = __builtin_amdgcn_readlane((int)my_prow, p);
+                const u64 wf = __ballot(r < 64 ? (colw0 >> r) & 1ull : (colw1 >> (r - 64)) & 1ull);
+                const u64 cf = __ballot(r < 64 ? (ccol0 >> r) & 1ull : (ccol1 >> (r - 64)) & 1ull);
+                if (lane == 0) {
+                    fin_w[r] = wf;
+                    fin_c[r] = cf;
+                    win_piv[r] = 1;
                 }
             }
+            if (lane >= t && lane < tt) {
+                pword[lane] = my_pword;
+                csel[lane] = my_csel;
+                pbit[lane] = (int)my_pbit;
+                prow_l[lane] = win_row[my_prow];
+            }
+            CP[lane] = transpose64(ccol2, lane);                     // row j: the coefficients a row takes for having bit j
+            WP[lane] = transpose64(colw2, lane);                     // row j: what becomes of bit j
             if (lane == 0) {
                 misc[0] = tt;
                 misc[1] = (int)(unsigned int)newbits;
@@ -338,18 +403,37 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
         __syncthreads();
         const int t_new = misc[0];
         const u64 newbits = ((u64)(unsigned int)misc[2] << 32) | (unsigned int)misc[1];
+        // another round may follow (uniform): only then are the rows' words needed again
+        const bool again = (unresolved & ~newbits) != 0 && t_new < 64 && rank + t_new < m;
+        for (int idx = tid; idx < 2048; idx += RB_THREADS) {
+            const int g = idx >> 8, vv = idx & 255;
+            u64 x = 0, y = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const u64 hit = 0ull - (u64)((vv >> k) & 1);
+                x ^= CP[8 * g + k] & hit;
+                y ^= WP[8 * g + k] & hit;
+            }
+            VT[idx] = x;
+            if (again) TW[idx] = y;
+        }
+        __syncthreads();
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
-            if (slot[k] >= 0) {                                       // window rows: take the wavefront's result
-                w[k] = win_w[slot[k]];
-                c[k] = win_c[slot[k]];
-                if (win_piv[slot[k]]) usedmask |= 1u << k;
-            } else {                                                  // everyone else replays the new pivots
-#pragma unroll 4
-                for (int p = t; p < t_new; ++p) {
-                    const u64 hit = 0ull - ((w[k] >> pbit[p]) & 1ull);
-                    w[k] ^= pword[p] & hit;
-                    c[k] |= (1ull << p) & hit;
+            if (slot[k] >= 0 && win_piv[slot[k]]) {                   // a new pivot row: as the wavefront left it
+                w[k] = fin_w[slot[k]];
+                c[k] = fin_c[slot[k]];
+                usedmask |= 1u << k;
+            } else {                                                  // every other row: linear in its word
+                const u64 w0 = w[k];
+                u64 dc = 0, nw = 0;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) dc ^= VT[g * 256 + (int)((w0 >> (8 * g)) & 255ull)];
+                c[k] |= dc;
+                if (again) {
+#pragma unroll
+                    for (int g = 0; g < 8; ++g) nw ^= TW[g * 256 + (int)((w0 >> (8 * g)) & 255ull)];
+                    w[k] = nw;
                 }
             }
         }

@@ -1124,7 +1124,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
                            ck->nslabs512, (u64*)hist_dev, nbins, redo_count, redo_list, clk_dev ? clk_dev + 4 : nullptr);
         GF2_HIP(hipGetLastError());
         if (stray.n_cols) {
-            hipLaunchKernelGGL(slab_redo_kernel, dim3((unsigned)ctx->num_cus * 8), dim3(256), 0, stream, (const u64*)e, count, lde,
+            hipLaunchKernelGGL(slab_redo_kernel, dim3((unsigned)(ctx->num_cus * (ctx->opt[GF2_OPT_REDO_BLOCKS_PER_CU] > 0 ? ctx->opt[GF2_OPT_REDO_BLOCKS_PER_CU] : 8))), dim3(256), 0, stream, (const u64*)e, count, lde,
                                (const unsigned int*)redo_count, (const unsigned int*)redo_list, ck->ht_dev,
                                (int)ck->r, (int)ck->n, (int)ck->ident_off, (u64*)hist_dev);
             GF2_HIP(hipGetLastError());
