@@ -38,6 +38,7 @@ struct RrefState {                                  // per matrix, in global scr
     int64_t zero_lo, zero_hi;                       // rows [zero_lo, zero_hi) are rebuilt from zero (normalisation)
     int32_t t;                                      // pivots of the current panel
     int32_t stalled;                                // normalisation: the panel stopped early, a single step must follow
+    int32_t pending;                                // streamed RREF panel: the last round's table waits in tabs (panel_coeff_kernel)
 };
 
 template <int MODE>
@@ -212,6 +213,143 @@ __device__ __forceinline__ u64 transpose64(u64 x, int lane) {
     return x;
 }
 
+// One round of the panel factorisation on the window (wavefront 0 of the panel kernels).  In: win_w / win_c / win_row (nwin <= 128
+// rows), the unresolved panel columns, t pivots so far.  Out: for every new pivot p its word and coefficients when chosen, its
+// column and its row (pword, csel, pbit, prow_l); fin_w / fin_c / win_piv for the window rows that became pivots; CP / WP, the
+// probe rows; misc = {pivots now, new columns lo, hi}.
+__device__ __forceinline__ void window_round(int lane, int nwin, int t, int64_t rank, int64_t m, u64 unresolved, const u64* win_w,
+                                             const u64* win_c, const int* win_row, int* win_piv, u64* fin_w, u64* fin_c, u64* pword,
+                                             u64* csel, int* pbit, int* prow_l, u64* CP, u64* WP, int* misc) {
+        // Gauss-Jordan on the window inside one wavefront, COLUMN-sliced: lane = panel column, bit i of (colw0, colw1) = window
+        // row i's bit in that column.  A step is a handful of scalar operations -- the column of bit b comes by readlane, its
+        // first row that is not a pivot yet becomes the pivot, every lane whose column has the pivot row's bit toggles the
+        // other rows of column b -- instead of two ballots over the rows and five readlanes of the pivot row's data.
+        // Coefficients are kept the same way (lane p: bit i = window row i took pivot p).  64 PROBE rows e_0 .. e_63 (third
+        // word) are eliminated along: row e_j ends with the coefficients and the word any row gets for having bit j, and
+        // elimination is linear in the row, so every row outside the pivots is finished with two table lookups instead of
+        // replaying the pivots one by one.
+        const u64 ew0 = lane < nwin ? win_w[lane] : 0ull, ew1 = lane + 64 < nwin ? win_w[lane + 64] : 0ull;
+        u64 colw0 = transpose64(ew0, lane), colw1 = transpose64(ew1, lane), colw2 = 1ull << lane;
+        u64 ccol0 = 0, ccol1 = 0, ccol2 = 0;
+        if (t > 0) {                                              // uniform: coefficients of earlier rounds
+            ccol0 = transpose64(lane < nwin ? win_c[lane] : 0ull, lane);
+            ccol1 = transpose64(lane + 64 < nwin ? win_c[lane + 64] : 0ull, lane);
+        }
+        u64 piv0 = 0, piv1 = 0, newbits = 0, todo = unresolved;
+        // what lane p keeps about pivot p: the pivot row's word and coefficients when chosen, its column, its window index.
+        // Lane tt's slots (and its coefficient words: no pivot tt before this round) are zero until step tt sets them: one
+        // v_writelane_b32 per dword with the lane in M0 (a select costs two instructions each: an SGPR value and an SGPR mask
+        // do not fit one VOP3; the compiler has no builtin for writelane and does not use M0 in this kernel).
+        unsigned int pw_lo = 0, pw_hi = 0, cs_lo = 0, cs_hi = 0, my_pbit = 0, my_prow = 0;
+        unsigned int x0l = (unsigned int)colw0, x0h = (unsigned int)(colw0 >> 32), x1l = (unsigned int)colw1, x1h = (unsigned int)(colw1 >> 32);
+        unsigned int x2l = (unsigned int)colw2, x2h = (unsigned int)(colw2 >> 32);
+        unsigned int c0l = (unsigned int)ccol0, c0h = (unsigned int)(ccol0 >> 32), c1l = (unsigned int)ccol1, c1h = (unsigned int)(ccol1 >> 32);
+        unsigned int c2l = 0, c2h = 0;
+        int tt = t;
+        // a ^ (b & c) in one instruction (v_bitop3_b32, truth table 0x78)
+        auto xor_and = [](unsigned int a, unsigned int bb, unsigned int cc) { return __builtin_amdgcn_bitop3_b32(a, bb, cc, 0x78); };
+        auto rl = [](unsigned int v, int src) { return (unsigned int)__builtin_amdgcn_readlane((int)v, src); };
+        while (todo && tt < 64 && rank + tt < m) {
+            const int b = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const unsigned int b0l = rl(x0l, b), b0h = rl(x0h, b), b1l = rl(x1l, b), b1h = rl(x1h, b);     // column b, rows 0..127
+            const u64 cb0 = ((u64)b0h << 32) | b0l, cb1 = ((u64)b1h << 32) | b1l;
+            const u64 cand0 = cb0 & ~piv0, cand1 = cb1 & ~piv1;
+            if (!(cand0 | cand1)) continue;                       // no pivot for this column inside the window
+            const unsigned int b2l = rl(x2l, b), b2h = rl(x2h, b);                                          // ... and the probe rows
+            unsigned int m0l = b0l, m0h = b0h, m1l = b1l, m1h = b1h;     // rows that take the pivot row: all with the bit but itself
+            unsigned int hit, pcs_src_l, pcs_src_h;                      // hit: all ones in the lanes whose column the pivot row has
+            int r;
+            if (cand0) {                                          // uniform; the usual case: a pivot among the first 64 window rows
+                r = __ffsll((long long)cand0) - 1;
+                const u64 keep = ~(1ull << r);
+                m0l &= (unsigned int)keep;
+                m0h &= (unsigned int)(keep >> 32);
+                hit = (unsigned int)__builtin_amdgcn_sbfe((int)(r < 32 ? x0l : x0h), (unsigned int)(r & 31), 1u);
+                pcs_src_l = c0l, pcs_src_h = c0h;
+                piv0 |= 1ull << r;
+            } else {
+                const int r1 = __ffsll((long long)cand1) - 1;
+                r = 64 + r1;
+                const u64 keep = ~(1ull << r1);
+                m1l &= (unsigned int)keep;
+                m1h &= (unsigned int)(keep >> 32);
+                hit = (unsigned int)__builtin_amdgcn_sbfe((int)(r1 < 32 ? x1l : x1h), (unsigned int)(r1 & 31), 1u);
+                pcs_src_l = c1l, pcs_src_h = c1h;
+                piv1 |= 1ull << r1;
+            }
+            const u64 pwd = __ballot(hit != 0);                                                            // = the pivot row's word
+            const u64 pcs = __ballot((((r & 32) ? pcs_src_h : pcs_src_l) >> (r & 31)) & 1u);                // = its coefficients so far
+            x0l = xor_and(x0l, m0l, hit), x0h = xor_and(x0h, m0h, hit);
+            x1l = xor_and(x1l, m1l, hit), x1h = xor_and(x1h, m1h, hit);
+            x2l = xor_and(x2l, b2l, hit), x2h = xor_and(x2h, b2h, hit);
+            asm volatile(
+                "s_mov_b32 m0, %12\n\t"
+                "v_writelane_b32 %0, %13, m0\n\tv_writelane_b32 %1, %14, m0\n\tv_writelane_b32 %2, %15, m0\n\t"
+                "v_writelane_b32 %3, %16, m0\n\tv_writelane_b32 %4, %17, m0\n\tv_writelane_b32 %5, %18, m0\n\t"
+                "v_writelane_b32 %6, %19, m0\n\tv_writelane_b32 %7, %20, m0\n\tv_writelane_b32 %8, %21, m0\n\t"
+                "v_writelane_b32 %9, %22, m0\n\tv_writelane_b32 %10, %23, m0\n\tv_writelane_b32 %11, %24, m0"
+                : "+v"(c0l), "+v"(c0h), "+v"(c1l), "+v"(c1h), "+v"(c2l), "+v"(c2h), "+v"(pw_lo), "+v"(pw_hi), "+v"(cs_lo),
+                  "+v"(cs_hi), "+v"(my_pbit), "+v"(my_prow)
+                : "s"(tt), "s"(m0l), "s"(m0h), "s"(m1l), "s"(m1h), "s"(b2l), "s"(b2h), "s"((unsigned int)pwd),
+                  "s"((unsigned int)(pwd >> 32)), "s"((unsigned int)pcs), "s"((unsigned int)(pcs >> 32)), "s"((unsigned int)b),
+                  "s"((unsigned int)r)
+                : "m0");
+            newbits |= 1ull << b;
+            tt += 1;
+        }
+        colw0 = ((u64)x0h << 32) | x0l, colw1 = ((u64)x1h << 32) | x1l, colw2 = ((u64)x2h << 32) | x2l;
+        ccol0 = ((u64)c0h << 32) | c0l, ccol1 = ((u64)c1h << 32) | c1l, ccol2 = ((u64)c2h << 32) | c2l;
+        const u64 my_pword = ((u64)pw_hi << 32) | pw_lo, my_csel = ((u64)cs_hi << 32) | cs_lo;
+        // the new pivot rows as they stand at the end of the round: word and coefficients (bit r across the lanes)
+        for (int p = t; p < tt; ++p) {
+            const int r = __builtin_amdgcn_readlane((int)my_prow, p);
+            const u64 wf = __ballot(r < 64 ? (colw0 >> r) & 1ull : (colw1 >> (r - 64)) & 1ull);
+            const u64 cf = __ballot(r < 64 ? (ccol0 >> r) & 1ull : (ccol1 >> (r - 64)) & 1ull);
+            if (lane == 0) {
+                fin_w[r] = wf;
+                fin_c[r] = cf;
+                win_piv[r] = 1;
+            }
+        }
+        if (lane >= t && lane < tt) {
+            pword[lane] = my_pword;
+            csel[lane] = my_csel;
+            pbit[lane] = (int)my_pbit;
+            prow_l[lane] = win_row[my_prow];
+        }
+        CP[lane] = transpose64(ccol2, lane);                     // row j: the coefficients a row takes for having bit j
+        WP[lane] = transpose64(colw2, lane);                     // row j: what becomes of bit j
+        if (lane == 0) {
+            misc[0] = tt;
+            misc[1] = (int)(unsigned int)newbits;
+            misc[2] = (int)(unsigned int)(newbits >> 32);
+        }
+}
+
+// Byte tables of the probe rows: VT of their coefficients, TW of their words (only when another round follows).
+__device__ __forceinline__ void round_tables(int tid, const u64* CP, const u64* WP, u64* VT, u64* TW, bool again) {
+    for (int idx = tid; idx < 2048; idx += RB_THREADS) {
+        const int g = idx >> 8, vv = idx & 255;
+        u64 x = 0, y = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const u64 hit = 0ull - (u64)((vv >> k) & 1);
+            x ^= CP[8 * g + k] & hit;
+            y ^= WP[8 * g + k] & hit;
+        }
+        VT[idx] = x;
+        if (again) TW[idx] = y;
+    }
+}
+
+__device__ __forceinline__ u64 byte_lookup(const u64* T, u64 w) {
+    u64 x = 0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) x ^= T[g * 256 + (int)((w >> (8 * g)) & 255ull)];
+    return x;
+}
+
 template <int RPT>
 __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict__ base, int64_t m, int64_t n, int64_t ld,
                                                                int64_t pw, int64_t* __restrict__ pivots_base, int64_t cap,
@@ -293,130 +431,14 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
             }
         __syncthreads();
         const int nwin = total < RB_WIN ? total : RB_WIN;
-        if (wave == 0) {
-            // Gauss-Jordan on the window inside one wavefront, COLUMN-sliced: lane = panel column, bit i of (colw0, colw1) = window
-            // row i's bit in that column.  A step is a handful of scalar operations -- the column of bit b comes by readlane, its
-            // first row that is not a pivot yet becomes the pivot, every lane whose column has the pivot row's bit toggles the
-            // other rows of column b -- instead of two ballots over the rows and five readlanes of the pivot row's data.
-            // Coefficients are kept the same way (lane p: bit i = window row i took pivot p).  64 PROBE rows e_0 .. e_63 (third
-            // word) are eliminated along: row e_j ends with the coefficients and the word any row gets for having bit j, and
-            // elimination is linear in the row, so every row outside the pivots is finished with two table lookups instead of
-            // replaying the pivots one by one.
-            const u64 ew0 = lane < nwin ? win_w[lane] : 0ull, ew1 = lane + 64 < nwin ? win_w[lane + 64] : 0ull;
-            u64 colw0 = transpose64(ew0, lane), colw1 = transpose64(ew1, lane), colw2 = 1ull << lane;
-            u64 ccol0 = 0, ccol1 = 0, ccol2 = 0;
-            if (t > 0) {                                              // uniform: coefficients of earlier rounds
-                ccol0 = transpose64(lane < nwin ? win_c[lane] : 0ull, lane);
-                ccol1 = transpose64(lane + 64 < nwin ? win_c[lane + 64] : 0ull, lane);
-            }
-            u64 piv0 = 0, piv1 = 0, newbits = 0, todo = unresolved;
-            // what lane p keeps about pivot p: the pivot row's word and coefficients when chosen, its column, its window index.
-            // Lane tt's slots (and its coefficient words: no pivot tt before this round) are zero until step tt sets them: one
-            // v_writelane_b32 per dword with the lane in M0 (a select costs two instructions each: an SGPR value and an SGPR mask
-            // do not fit one VOP3; the compiler has no builtin for writelane and does not use M0 in this kernel).
-            unsigned int pw_lo = 0, pw_hi = 0, cs_lo = 0, cs_hi = 0, my_pbit = 0, my_prow = 0;
-            unsigned int x0l = (unsigned int)colw0, x0h = (unsigned int)(colw0 >> 32), x1l = (unsigned int)colw1, x1h = (unsigned int)(colw1 >> 32);
-            unsigned int x2l = (unsigned int)colw2, x2h = (unsigned int)(colw2 >> 32);
-            unsigned int c0l = (unsigned int)ccol0, c0h = (unsigned int)(ccol0 >> 32), c1l = (unsigned int)ccol1, c1h = (unsigned int)(ccol1 >> 32);
-            unsigned int c2l = 0, c2h = 0;
-            int tt = t;
-            // a ^ (b & c) in one instruction (v_bitop3_b32, truth table 0x78)
-            auto xor_and = [](unsigned int a, unsigned int bb, unsigned int cc) { return __builtin_amdgcn_bitop3_b32(a, bb, cc, 0x78); };
-            auto rl = [](unsigned int v, int src) { return (unsigned int)__builtin_amdgcn_readlane((int)v, src); };
-            while (todo && tt < 64 && rank + tt < m) {
-                const int b = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                const unsigned int b0l = rl(x0l, b), b0h = rl(x0h, b), b1l = rl(x1l, b), b1h = rl(x1h, b);     // column b, rows 0..127
-                const u64 cb0 = ((u64)b0h << 32) | b0l, cb1 = ((u64)b1h << 32) | b1l;
-                const u64 cand0 = cb0 & ~piv0, cand1 = cb1 & ~piv1;
-                if (!(cand0 | cand1)) continue;                       // no pivot for this column inside the window
-                const unsigned int b2l = rl(x2l, b), b2h = rl(x2h, b);                                          // ... and the probe rows
-                unsigned int m0l = b0l, m0h = b0h, m1l = b1l, m1h = b1h;     // rows that take the pivot row: all with the bit but itself
-                unsigned int hit, pcs_src_l, pcs_src_h;                      // hit: all ones in the lanes whose column the pivot row has
-                int r;
-                if (cand0) {                                          // uniform; the usual case: a pivot among the first 64 window rows
-                    r = __ffsll((long long)cand0) - 1;
-                    const u64 keep = ~(1ull << r);
-                    m0l &= (unsigned int)keep;
-                    m0h &= (unsigned int)(keep >> 32);
-                    hit = (unsigned int)__builtin_amdgcn_sbfe((int)(r < 32 ? x0l : x0h), (unsigned int)(r & 31), 1u);
-                    pcs_src_l = c0l, pcs_src_h = c0h;
-                    piv0 |= 1ull << r;
-                } else {
-                    const int r1 = __ffsll((long long)cand1) - 1;
-                    r = 64 + r1;
-                    const u64 keep = ~(1ull << r1);
-                    m1l &= (unsigned int)keep;
-                    m1h &= (unsigned int)(keep >> 32);
-                    hit = (unsigned int)__builtin_amdgcn_sbfe((int)(r1 < 32 ? x1l : x1h), (unsigned int)(r1 & 31), 1u);
-                    pcs_src_l = c1l, pcs_src_h = c1h;
-                    piv1 |= 1ull << r1;
-                }
-                const u64 pwd = __ballot(hit != 0);                                                            // = the pivot row's word
-                const u64 pcs = __ballot((((r & 32) ? pcs_src_h : pcs_src_l) >> (r & 31)) & 1u);                // = its coefficients so far
-                x0l = xor_and(x0l, m0l, hit), x0h = xor_and(x0h, m0h, hit);
-                x1l = xor_and(x1l, m1l, hit), x1h = xor_and(x1h, m1h, hit);
-                x2l = xor_and(x2l, b2l, hit), x2h = xor_and(x2h, b2h, hit);
-                asm volatile(
-                    "s_mov_b32 m0, %12\n\t"
-                    "v_writelane_b32 %0, %13, m0\n\tv_writelane_b32 %1, %14, m0\n\tv_writelane_b32 %2, %15, m0\n\t"
-                    "v_writelane_b32 %3, %16, m0\n\tv_writelane_b32 %4, %17, m0\n\tv_writelane_b32 %5, %18, m0\n\t"
-                    "v_writelane_b32 %6, %19, m0\n\tv_writelane_b32 %7, %20, m0\n\tv_writelane_b32 %8, %21, m0\n\t"
-                    "v_writelane_b32 %9, %22, m0\n\tv_writelane_b32 %10, %23, m0\n\tv_writelane_b32 %11, %24, m0"
-                    : "+v"(c0l), "+v"(c0h), "+v"(c1l), "+v"(c1h), "+v"(c2l), "+v"(c2h), "+v"(pw_lo), "+v"(pw_hi), "+v"(cs_lo),
-                      "+v"(cs_hi), "+v"(my_pbit), "+v"(my_prow)
-                    : "s"(tt), "s"(m0l), "s"(m0h), "s"(m1l), "s"(m1h), "s"(b2l), "s"(b2h), "s"((unsigned int)pwd),
-                      "s"((unsigned int)(pwd >> 32)), "s"((unsigned int)pcs), "s"((unsigned int)(pcs >> 32)), "s"((unsigned int)b),
-                      "s"((unsigned int)r)
-                    : "m0");
-                newbits |= 1ull << b;
-                tt += 1;
-            }
-            colw0 = ((u64)x0h << 32) | x0l, colw1 = ((u64)x1h << 32) | x1l, colw2 = ((u64)x2h << 32) | x2l;
-            ccol0 = ((u64)c0h << 32) | c0l, ccol1 = ((u64)c1h << 32) | c1l, ccol2 = ((u64)c2h << 32) | c2l;
-            const u64 my_pword = ((u64)pw_hi << 32) | pw_lo, my_csel = ((u64)cs_hi << 32) | cs_lo;
-            // the new pivot rows as they stand at the end of the round: word and coefficients (bit r across the lanes)
-            for (int p = t; p < tt; ++p) {
-                const int r = __builtin_amdgcn_readlane((int)my_prow, p);
-                const u64 wf = __ballot(r < 64 ? (colw0 >> r) & 1ull : (colw1 >> (r - 64)) & 1ull);
-                const u64 cf = __ballot(r < 64 ? (ccol0 >> r) & 1ull : (ccol1 >> (r - 64)) & 1ull);
-                if (lane == 0) {
-                    fin_w[r] = wf;
-                    fin_c[r] = cf;
-                    win_piv[r] = 1;
-                }
-            }
-            if (lane >= t && lane < tt) {
-                pword[lane] = my_pword;
-                csel[lane] = my_csel;
-                pbit[lane] = (int)my_pbit;
-                prow_l[lane] = win_row[my_prow];
-            }
-            CP[lane] = transpose64(ccol2, lane);                     // row j: the coefficients a row takes for having bit j
-            WP[lane] = transpose64(colw2, lane);                     // row j: what becomes of bit j
-            if (lane == 0) {
-                misc[0] = tt;
-                misc[1] = (int)(unsigned int)newbits;
-                misc[2] = (int)(unsigned int)(newbits >> 32);
-            }
-        }
+        if (wave == 0)
+            window_round(lane, nwin, t, rank, m, unresolved, win_w, win_c, win_row, win_piv, fin_w, fin_c, pword, csel, pbit, prow_l, CP, WP, misc);
         __syncthreads();
         const int t_new = misc[0];
         const u64 newbits = ((u64)(unsigned int)misc[2] << 32) | (unsigned int)misc[1];
         // another round may follow (uniform): only then are the rows' words needed again
         const bool again = (unresolved & ~newbits) != 0 && t_new < 64 && rank + t_new < m;
-        for (int idx = tid; idx < 2048; idx += RB_THREADS) {
-            const int g = idx >> 8, vv = idx & 255;
-            u64 x = 0, y = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const u64 hit = 0ull - (u64)((vv >> k) & 1);
-                x ^= CP[8 * g + k] & hit;
-                y ^= WP[8 * g + k] & hit;
-            }
-            VT[idx] = x;
-            if (again) TW[idx] = y;
-        }
+        round_tables(tid, CP, WP, VT, TW, again);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
@@ -426,15 +448,8 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
                 usedmask |= 1u << k;
             } else {                                                  // every other row: linear in its word
                 const u64 w0 = w[k];
-                u64 dc = 0, nw = 0;
-#pragma unroll
-                for (int g = 0; g < 8; ++g) dc ^= VT[g * 256 + (int)((w0 >> (8 * g)) & 255ull)];
-                c[k] |= dc;
-                if (again) {
-#pragma unroll
-                    for (int g = 0; g < 8; ++g) nw ^= TW[g * 256 + (int)((w0 >> (8 * g)) & 255ull)];
-                    w[k] = nw;
-                }
+                c[k] |= byte_lookup(VT, w0);
+                if (again) w[k] = byte_lookup(TW, w0);
             }
         }
         unresolved &= ~newbits;
@@ -504,6 +519,52 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
 }
 
 
+// Two chores of the streamed panel step (m > 8192) that ONE workgroup is slow at and the whole chip does in microseconds:
+// the panel's column (one word out of every row: strided by the row pitch) into the contiguous round-0 state, and, after the
+// panel, the snapshot of its pivot rows (64 rows of ld words).
+__global__ __launch_bounds__(256) void panel_column_kernel(const u64* __restrict__ base, int64_t m, int64_t ld, int64_t pw,
+                                                           u64* __restrict__ wpan_base, u64* __restrict__ cco_base,
+                                                           int32_t* __restrict__ slot_base) {
+    const int64_t mat = blockIdx.y, row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= m) return;
+    wpan_base[mat * m + row] = base[(mat * m + row) * ld + pw];
+    cco_base[mat * m + row] = 0;
+    slot_base[mat * m + row] = -1;
+}
+
+__global__ __launch_bounds__(256) void panel_snapshot_kernel(const u64* __restrict__ base, int64_t m, int64_t ld,
+                                                             const RrefState* __restrict__ states, const int32_t* __restrict__ prow_base,
+                                                             u64* __restrict__ snap_base) {
+    const int64_t mat = blockIdx.y;
+    const int p = blockIdx.x;
+    if (p >= states[mat].t) return;
+    const u64* src = base + (mat * m + prow_base[mat * 64 + p]) * ld;
+    u64* dst = snap_base + (mat * 64 + p) * ld;
+    for (int64_t wd = threadIdx.x; wd < ld; wd += blockDim.x) dst[wd] = src[wd];
+}
+
+// After the streamed panel kernel: the coefficients of every row (the last round's table applied to the row's word, unless the
+// panel kernel has settled the row: slot -2) and d_i = c_i . V, one row per lane on as many workgroups as there are rows for.
+__global__ __launch_bounds__(1024) void panel_coeff_kernel(int64_t m, const RrefState* __restrict__ states,
+                                                           const u64* __restrict__ wpan_base, const u64* __restrict__ cco_base,
+                                                           const int32_t* __restrict__ slot_base, const u64* __restrict__ tabs_base,
+                                                           u64* __restrict__ d_base) {
+    __shared__ u64 TC[2048], TV[2048];
+    const int64_t mat = blockIdx.y;
+    const RrefState st = states[mat];
+    if (st.t == 0) return;
+    for (int idx = threadIdx.x; idx < 2048; idx += 1024) {
+        TC[idx] = st.pending ? tabs_base[mat * 4096 + idx] : 0ull;
+        TV[idx] = tabs_base[mat * 4096 + 2048 + idx];
+    }
+    __syncthreads();
+    const int64_t row = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (row >= m) return;
+    u64 c = cco_base[mat * m + row];
+    if (st.pending && slot_base[mat * m + row] != -2) c |= byte_lookup(TC, wpan_base[mat * m + row]);
+    d_base[mat * m + row] = byte_lookup(TV, c);
+}
+
 // The same panel step for matrices with more than 8192 rows: rows are streamed instead of held in registers.  The
 // current panel word and coefficient of every row live in global scratch (wpan, cco); the window is filled through an
 // LDS counter (any unused rows with a bit in an unresolved column will do -- the RREF does not depend on the choice).
@@ -511,10 +572,11 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
                                                                       int64_t pw, int64_t* __restrict__ pivots_base, int64_t cap,
                                                                       int32_t* __restrict__ pivrow_base, RrefState* __restrict__ states,
                                                                       unsigned char* __restrict__ used_base, u64* __restrict__ d_base,
-                                                                      u64* __restrict__ snap_base, u64* __restrict__ wpan_base,
-                                                                      u64* __restrict__ cco_base, int32_t* __restrict__ slot_base) {
-    __shared__ u64 VT[2048];
-    __shared__ u64 V[64], csel[64], pword[64], win_w[RB_WIN], win_c[RB_WIN];
+                                                                      int32_t* __restrict__ prow_base, u64* __restrict__ wpan_base,
+                                                                      u64* __restrict__ cco_base, int32_t* __restrict__ slot_base,
+                                                                      u64* __restrict__ tabs_base) {
+    __shared__ u64 VT[2048], TW[2048];
+    __shared__ u64 V[64], csel[64], pword[64], win_w[RB_WIN], win_c[RB_WIN], fin_w[RB_WIN], fin_c[RB_WIN], CP[64], WP[64];
     __shared__ int win_row[RB_WIN], win_piv[RB_WIN], pbit[64], prow_l[64], misc[4];
     __shared__ int win_count;
 
@@ -522,10 +584,11 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
     u64* a = base + mat * m * ld;
     RrefState* st = states + mat;
     unsigned char* used = used_base + mat * m;
-    u64* dout = d_base + mat * m;
+    (void)d_base;
     u64* wpan = wpan_base + mat * m;
     u64* cco = cco_base + mat * m;
     int32_t* slot_of = slot_base + mat * m;                             // -1, or the row's window slot in this round
+    (void)a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t rank = st->rank;
     int64_t first_free = st->first_free;
@@ -538,13 +601,8 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
     const int64_t cols_here = n - pw * 64;
     const u64 panel_cols = cols_here >= 64 ? ~0ull : ((1ull << cols_here) - 1ull);
     u64 unresolved = panel_cols;
-    int t = 0;
-    for (int64_t row = tid; row < m; row += RB_THREADS) {               // round 0 state: the matrix itself
-        wpan[row] = a[row * ld + pw];
-        cco[row] = 0;
-        slot_of[row] = -1;
-    }
-    __syncthreads();
+    int t = 0, pending = 0;                                            // pending: the last round's rows are left to panel_coeff_kernel
+    // round 0 state (wpan = the panel's column, cco = 0, slot_of = -1): panel_column_kernel, launched before this one
     while (unresolved && t < 64 && rank + t < m) {
         if (tid == 0) win_count = 0;
         __syncthreads();
@@ -566,84 +624,41 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
         const int total = win_count;
         if (total == 0) break;
         const int nwin = total < RB_WIN ? total : RB_WIN;
-        if (wave == 0) {
-            u64 ew[2], ec[2];
-            int er[2];
-            bool ep[2] = {false, false};
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int idx = lane + 64 * h;
-                const bool live = idx < nwin;
-                ew[h] = live ? win_w[idx] : 0ull;
-                ec[h] = live ? win_c[idx] : 0ull;
-                er[h] = live ? win_row[idx] : -1;
-            }
-            u64 newbits = 0;
-            int tt = t;
-            for (int b = 0; b < 64; ++b) {
-                if (!((unresolved >> b) & 1ull)) continue;
-                if (tt >= 64 || rank + tt >= m) break;
-                const u64 bal0 = __ballot(!ep[0] && ((ew[0] >> b) & 1ull));
-                const u64 bal1 = __ballot(!ep[1] && ((ew[1] >> b) & 1ull));
-                if (!(bal0 | bal1)) continue;
-                const int h = bal0 ? 0 : 1;
-                const int src = __ffsll((long long)(bal0 ? bal0 : bal1)) - 1;
-                const u64 pwd = readlane64(h ? ew[1] : ew[0], src);
-                const u64 pcs = readlane64(h ? ec[1] : ec[0], src);
-                const int prw = __builtin_amdgcn_readlane(h ? er[1] : er[0], src);
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    if (hh == h && lane == src) {
-                        ep[hh] = true;
-                    } else if ((ew[hh] >> b) & 1ull) {
-                        ew[hh] ^= pwd;
-                        ec[hh] |= 1ull << tt;
-                    }
-                }
-                if (lane == 0) {
-                    pword[tt] = pwd;
-                    csel[tt] = pcs;
-                    pbit[tt] = b;
-                    prow_l[tt] = prw;
-                }
-                newbits |= 1ull << b;
-                tt += 1;
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int idx = lane + 64 * h;
-                if (idx < nwin) {
-                    win_w[idx] = ew[h];
-                    win_c[idx] = ec[h];
-                    win_piv[idx] = ep[h] ? 1 : 0;
-                }
-            }
-            if (lane == 0) {
-                misc[0] = tt;
-                misc[1] = (int)(unsigned int)newbits;
-                misc[2] = (int)(unsigned int)(newbits >> 32);
-            }
-        }
+        if (wave == 0)
+            window_round(lane, nwin, t, rank, m, unresolved, win_w, win_c, win_row, win_piv, fin_w, fin_c, pword, csel, pbit, prow_l, CP, WP, misc);
         __syncthreads();
         const int t_new = misc[0];
         const u64 newbits = ((u64)(unsigned int)misc[2] << 32) | (unsigned int)misc[1];
+        const bool again = (unresolved & ~newbits) != 0 && t_new < 64 && rank + t_new < m;    // uniform: another round may follow
+        round_tables(tid, CP, WP, VT, TW, again);
+        __syncthreads();
+        if (!again) {
+            // the last round: only its pivot rows are settled here (coefficients final, marked -2); every other row takes its
+            // coefficients from the probe-row table in panel_coeff_kernel, on the whole chip instead of in this one workgroup
+            if (tid < nwin && win_piv[tid]) {
+                const int row = win_row[tid];
+                cco[row] = fin_c[tid];
+                used[row] = 1;
+                slot_of[row] = -2;
+            }
+            for (int idx = tid; idx < 2048; idx += RB_THREADS) tabs_base[mat * 4096 + idx] = VT[idx];
+            pending = 1;
+            unresolved &= ~newbits;
+            t = t_new;
+            __syncthreads();
+            break;
+        }
         for (int64_t row = tid; row < m; row += RB_THREADS) {
             const int sl = slot_of[row];
-            if (sl >= 0) {
-                wpan[row] = win_w[sl];
-                cco[row] = win_c[sl];
-                if (win_piv[sl]) used[row] = 1;
-                slot_of[row] = -1;
-            } else {
-                u64 w = wpan[row], c = cco[row];
-#pragma unroll 4
-                for (int p = t; p < t_new; ++p) {
-                    const u64 hit = 0ull - ((w >> pbit[p]) & 1ull);
-                    w ^= pword[p] & hit;
-                    c |= (1ull << p) & hit;
-                }
-                wpan[row] = w;
-                cco[row] = c;
+            if (sl >= 0) slot_of[row] = -1;
+            if (sl >= 0 && win_piv[sl]) {                             // a new pivot row: as the wavefront left it
+                wpan[row] = fin_w[sl];
+                cco[row] = fin_c[sl];
+                used[row] = 1;
+            } else {                                                  // every other row: linear in its word
+                const u64 w0 = wpan[row];
+                cco[row] |= byte_lookup(VT, w0);
+                wpan[row] = byte_lookup(TW, w0);
             }
         }
         unresolved &= ~newbits;
@@ -654,6 +669,7 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
         const int64_t fc = pw * 64 + (__ffsll((long long)unresolved) - 1);
         if (fc < first_free) first_free = fc;
     }
+    if (tid == 0) st->pending = pending;
     if (tid == 0) {
         st->t = t;
         st->rank = rank + t;
@@ -668,12 +684,7 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
         pivrow[rank + pos] = prow_l[lane];
         if (pivots) pivots[rank + pos] = pw * 64 + pbit[lane];
     }
-    u64* snap = snap_base + mat * 64 * ld;
-    for (int64_t idx = tid; idx < (int64_t)t * ld; idx += RB_THREADS) {
-        const int p = (int)(idx / ld);
-        const int64_t wd = idx - (int64_t)p * ld;
-        snap[idx] = a[(int64_t)prow_l[p] * ld + wd];
-    }
+    if (tid < t) prow_base[mat * 64 + tid] = prow_l[tid];               // for panel_snapshot_kernel, which follows
     if (wave == 0) {
         u64 v = lane < t ? 1ull << lane : 0ull;
         const u64 cs = lane < t ? csel[lane] : 0ull;
@@ -692,13 +703,7 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
         VT[idx] = x;
     }
     __syncthreads();
-    for (int64_t row = tid; row < m; row += RB_THREADS) {
-        const u64 c = cco[row];
-        u64 d = 0;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) d ^= VT[g * 256 + (int)((c >> (8 * g)) & 255ull)];
-        dout[row] = d;
-    }
+    for (int idx = tid; idx < 2048; idx += RB_THREADS) tabs_base[mat * 4096 + 2048 + idx] = VT[idx];      // d_i = c_i . V: panel_coeff_kernel
 }
 
 // grid (row blocks, column chunks of 64 words, matrices), block 1024, 128 KiB dynamic LDS.
@@ -1140,7 +1145,7 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
     const size_t sbytes = al((size_t)batch * sizeof(RrefState)), ubytes = al((size_t)batch * m);
     const size_t dbytes = al((size_t)batch * m * 8), nbytes = al((size_t)batch * 64 * ld * 8);
     const bool stream = rpt > 8;
-    const size_t xbytes = stream ? 2 * dbytes + al((size_t)batch * m * 4) : 0;
+    const size_t xbytes = stream ? 2 * dbytes + al((size_t)batch * m * 4) + al((size_t)batch * 64 * 4) + (size_t)batch * 4096 * 8 : 0;
     GF2_TRY(gf2_ws_reserve(ctx, 1, abytes + pbytes + sbytes + ubytes + dbytes + nbytes + xbytes));
     char* q = (char*)ctx->ws[1];
     u64* tmp = (u64*)q; q += abytes;
@@ -1152,6 +1157,8 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
     u64* wpan = (u64*)q;
     u64* cco = (u64*)(q + dbytes);
     int32_t* slot_of = (int32_t*)(q + 2 * dbytes);
+    int32_t* panel_rows = (int32_t*)(q + 2 * dbytes + al((size_t)batch * m * 4));
+    u64* tabs = (u64*)(q + 2 * dbytes + al((size_t)batch * m * 4) + al((size_t)batch * 64 * 4));
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
     GF2_HIP(hipMemsetAsync(states, 0, sbytes + ubytes, ctx->stream));          // rank = 0, used = 0 ...
     {
@@ -1172,10 +1179,16 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
 #define GF2_RP_LAUNCH(RPT)                                                                                              \
     hipLaunchKernelGGL((rref_panel_kernel<RPT>), dim3((unsigned)batch), dim3(RB_THREADS), 0, ctx->stream, a_dev, m, n, ld, \
                        pw, pivots_dev, cap, pivrow, states, used, dco, snap)
-        if (stream)
+        if (stream) {
+            hipLaunchKernelGGL(panel_column_kernel, dim3((unsigned)gf2_cdiv(m, 256), (unsigned)batch), dim3(256), 0, ctx->stream,
+                               (const u64*)a_dev, m, ld, pw, wpan, cco, slot_of);
             hipLaunchKernelGGL(rref_panel_stream_kernel, dim3((unsigned)batch), dim3(RB_THREADS), 0, ctx->stream, a_dev, m, n,
-                               ld, pw, pivots_dev, cap, pivrow, states, used, dco, snap, wpan, cco, slot_of);
-        else if (rpt <= 1)
+                               ld, pw, pivots_dev, cap, pivrow, states, used, dco, panel_rows, wpan, cco, slot_of, tabs);
+            hipLaunchKernelGGL(panel_coeff_kernel, dim3((unsigned)gf2_cdiv(m, 1024), (unsigned)batch), dim3(1024), 0, ctx->stream, m,
+                               (const RrefState*)states, (const u64*)wpan, (const u64*)cco, (const int32_t*)slot_of, (const u64*)tabs, dco);
+            hipLaunchKernelGGL(panel_snapshot_kernel, dim3(64, (unsigned)batch), dim3(256), 0, ctx->stream, (const u64*)a_dev, m, ld,
+                               (const RrefState*)states, (const int32_t*)panel_rows, snap);
+        } else if (rpt <= 1)
             GF2_RP_LAUNCH(1);
         else if (rpt <= 2)
             GF2_RP_LAUNCH(2);
@@ -1186,6 +1199,17 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
 #undef GF2_RP_LAUNCH
         hipLaunchKernelGGL(rref_update_kernel, ugrid, dim3(RB_THREADS), 128 * 1024, ctx->stream, a_dev, m, ld, rows_per_wg, states, dco,
                            snap);
+        // Every row may have its pivot once m columns have been seen, and a random matrix is done right there: from then on the
+        // ranks are read back now and then (a stream synchronisation, but it saves the launches of the panels that would find
+        // nothing left to do -- half of them for a 2048 x 4096 matrix).
+        if ((pw + 1) * 64 >= m && pw + 1 < panels && ((pw + 1) * 64 - m) % 512 < 64) {
+            std::vector<RrefState> now((size_t)batch);
+            GF2_HIP(hipMemcpyAsync(now.data(), states, (size_t)batch * sizeof(RrefState), hipMemcpyDeviceToHost, ctx->stream));
+            GF2_TRY(gf2_stream_wait(ctx->stream));
+            bool done = true;
+            for (const auto& st : now) done = done && st.rank >= m;
+            if (done) break;
+        }
     }
     GF2_HIP(hipGetLastError());
     hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)m, (unsigned)batch), dim3(64), 0, ctx->stream, (const u64*)a_dev,
