@@ -29,5 +29,4 @@ for _ in range(2 if m > 8192 else 4):
     best = ms if best is None else min(best, ms)
 ranks = rk.download((batch,), np.int64)
 print("rank", int(ranks[0]))
-print("rref %dx%d batch %d: %.3f ms  %.2f GB/s (2*m*ld*8 bytes per matrix)  dbg=%s"
-      % (m, n, batch, best, batch * 2 * a.nbytes / best / 1e6, os.environ.get("GF2_RB_DBG")))
+print("rref %dx%d batch %d: %.3f ms  %.2f GB/s (2*m*ld*8 bytes per matrix)" % (m, n, batch, best, batch * 2 * a.nbytes / best / 1e6))

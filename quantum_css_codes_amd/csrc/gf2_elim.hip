@@ -39,6 +39,7 @@ struct RrefState {                                  // per matrix, in global scr
     int32_t t;                                      // pivots of the current panel
     int32_t stalled;                                // normalisation: the panel stopped early, a single step must follow
     int32_t pending;                                // streamed RREF panel: the last round's table waits in tabs (panel_coeff_kernel)
+    int32_t tg[2];                                  // RREF: pivots of the two panels of the current pair (one trailing update per pair)
 };
 
 template <int MODE>
@@ -181,12 +182,15 @@ __global__ __launch_bounds__(ELIM_THREADS) void eliminate_kernel(u64* __restrict
 //        With P_p the pivot row's value when chosen, P = V . OLDPIV (V from the coefficients-when-chosen) and
 //        new_i = old_i ^ (c_i . V) . OLDPIV, where OLDPIV are the chosen rows as they stand at the start of the panel.
 //     2. d_i = c_i . V through byte tables of V (LDS); d_i and a snapshot of the OLDPIV rows go to global scratch.
-//   rref_update_kernel (grid: row blocks x 64-word column chunks x matrices -- the whole GPU)
-//     3. A[i] ^= d_i . OLDPIV, Method of Four Russians at full chunk width: for each group of 4 pivots the 16 XOR
-//        combinations of their rows sit in LDS (128 KiB); a wavefront owns a row, lane = word, d_i is scalar, so each
-//        of the 16 lookups is one v_add + one ds_read_b64 in which every lane reads the same entry (conflict-free),
-//        and the row is loaded and stored as 512 contiguous bytes.  Chunks left of the panel are skipped while no
-//        pivot-free column has been seen there (they cannot change).
+//   rref_update_pair_kernel (grid: row blocks x 32-word column chunks x matrices -- the whole GPU), once per PAIR of panels
+//     3. A[i] ^= dA_i . OLDPIV_A ^ dB_i . OLDPIV_B', Method of Four Russians: for each group of 4 pivots of either panel the 16
+//        XOR combinations of their rows sit in LDS (2 x 64 KiB); a wavefront moves two rows at a time (32 lanes = 256
+//        contiguous bytes each), a lookup is one SDWA instruction that drops a nibble of d into the address + one
+//        ds_read_b64.  The second panel of a pair runs BEFORE the first panel's update has been applied: it brings its own
+//        column up to date on the way in (one byte-table lookup per row) and the table build of this kernel does the same
+//        for its pivot rows (OLDPIV_B' = OLDPIV_B ^ fix . OLDPIV_A), so the matrix makes one trip through HBM per 128
+//        columns.  Chunks left of the pair are skipped while no pivot-free column has been seen there (they cannot change).
+//        (rref_update_kernel, one panel per pass at 64-word chunks with scalar d, still serves the normalisation.)
 //   gather_rows_kernel: after the last panel the pivot rows are gathered into rows 0..rank-1, the rest zeroed.
 #define RB_THREADS 1024
 #define RB_WIN 128
@@ -355,7 +359,12 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
                                                                int64_t pw, int64_t* __restrict__ pivots_base, int64_t cap,
                                                                int32_t* __restrict__ pivrow_base, RrefState* __restrict__ states,
                                                                unsigned char* __restrict__ used_base, u64* __restrict__ d_base,
-                                                               u64* __restrict__ snap_base) {
+                                                               u64* __restrict__ snap_base, int member,
+                                                               const u64* __restrict__ dprev_base, const u64* __restrict__ snapprev_base,
+                                                               u64* __restrict__ fix_base) {
+    // member: 0 = first panel of a pair (the matrix is up to date), 1 = second panel: the first panel's update has not been
+    // applied yet (one trailing pass serves both), so this panel's column is brought up to date on the way in:
+    // word ^= d_prev[row] . (column pw of the first panel's pivot-row snapshot), through a byte table
     __shared__ u64 VT[2048];                                            // byte tables: of the probe rows' coefficients per round, of V at the end
     __shared__ u64 TW[2048];                                            // byte tables of the probe rows' words (rounds that are followed by another)
     __shared__ u64 V[64], csel[64], pword[64], win_w[RB_WIN], win_c[RB_WIN], fin_w[RB_WIN], fin_c[RB_WIN], CP[64], WP[64];
@@ -370,11 +379,17 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
     const int64_t rank = st->rank;
     int64_t first_free = st->first_free;
     if (rank >= m || pw * 64 >= n) {                                   // nothing left to do for this matrix
-        if (tid == 0) st->t = 0;
+        if (tid == 0) {
+            st->t = 0;
+            st->tg[member] = 0;
+            if (member == 0) st->tg[1] = 0;
+        }
         return;
     }
     int64_t* pivots = pivots_base ? pivots_base + mat * cap : nullptr;
     int32_t* pivrow = pivrow_base + mat * cap;
+    const int t_prev = member ? st->tg[0] : 0;
+    const u64* dprev = dprev_base + mat * m;
 
     // ---- 1. panel factorisation ------------------------------------------------------------------------------------------
     u64 w[RPT], c[RPT];
@@ -386,6 +401,24 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
         w[k] = row < m ? a[row * ld + pw] : 0ull;
         c[k] = 0;
         if (row < m && used[row]) usedmask |= 1u << k;
+    }
+    if (t_prev > 0) {                                                  // uniform: the pair's first panel left an update behind
+        if (tid < 64) CP[tid] = tid < t_prev ? snapprev_base[(mat * 64 + tid) * ld + pw] : 0ull;
+        __syncthreads();
+        for (int idx = tid; idx < 2048; idx += RB_THREADS) {
+            const int g = idx >> 8, vv = idx & 255;
+            u64 x = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x ^= CP[8 * g + k] & (0ull - (u64)((vv >> k) & 1));
+            TW[idx] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int64_t row = tid + (int64_t)RB_THREADS * k;
+            if (row < m) w[k] ^= byte_lookup(TW, dprev[row]);
+        }
+        __syncthreads();
     }
     usedmask0 = usedmask;
     const int64_t cols_here = n - pw * 64;
@@ -462,15 +495,21 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
     }
     if (tid == 0) {
         st->t = t;
+        st->tg[member] = t;
         st->rank = rank + t;
-        st->skip_lo = 0;
-        st->skip_hi = st->first_free < pw * 64 ? st->first_free : pw * 64;     // first_free as it was BEFORE this panel
+        if (member == 0) {                                            // the pair's update skips what its FIRST panel allows
+            st->tg[1] = 0;
+            st->skip_lo = 0;
+            st->skip_hi = st->first_free < pw * 64 ? st->first_free : pw * 64;     // first_free as it was BEFORE this panel
+        }
         st->first_free = first_free;
     }
     if (t == 0) return;
 #pragma unroll
     for (int k = 0; k < RPT; ++k)
         if (((usedmask ^ usedmask0) >> k) & 1u) used[tid + RB_THREADS * k] = 1;
+    // the update kernel brings this panel's pivot rows up to date before it uses them: what the first panel adds to them
+    if (member && tid < t) fix_base[mat * 64 + tid] = t_prev > 0 ? dprev[prow_l[tid]] : 0ull;
     if (wave == 0 && lane < t) {
         // global pivot lists in ascending column order (a later round may have resolved an earlier column): the
         // position of a pivot is the number of resolved panel columns below its own
@@ -524,10 +563,29 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
 // panel, the snapshot of its pivot rows (64 rows of ld words).
 __global__ __launch_bounds__(256) void panel_column_kernel(const u64* __restrict__ base, int64_t m, int64_t ld, int64_t pw,
                                                            u64* __restrict__ wpan_base, u64* __restrict__ cco_base,
-                                                           int32_t* __restrict__ slot_base) {
+                                                           int32_t* __restrict__ slot_base, int member,
+                                                           const RrefState* __restrict__ states, const u64* __restrict__ dprev_base,
+                                                           const u64* __restrict__ snapprev_base) {
+    __shared__ u64 colp[64], TP[2048];
     const int64_t mat = blockIdx.y, row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int t_prev = member ? states[mat].tg[0] : 0;
+    if (t_prev > 0) {                                                  // second panel of a pair: see rref_panel_kernel
+        const int tid = threadIdx.x;
+        if (tid < 64) colp[tid] = tid < t_prev ? snapprev_base[(mat * 64 + tid) * ld + pw] : 0ull;
+        __syncthreads();
+        for (int idx = tid; idx < 2048; idx += 256) {
+            const int g = idx >> 8, vv = idx & 255;
+            u64 x = 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x ^= colp[8 * g + k] & (0ull - (u64)((vv >> k) & 1));
+            TP[idx] = x;
+        }
+        __syncthreads();
+    }
     if (row >= m) return;
-    wpan_base[mat * m + row] = base[(mat * m + row) * ld + pw];
+    u64 w = base[(mat * m + row) * ld + pw];
+    if (t_prev > 0) w ^= byte_lookup(TP, dprev_base[mat * m + row]);
+    wpan_base[mat * m + row] = w;
     cco_base[mat * m + row] = 0;
     slot_base[mat * m + row] = -1;
 }
@@ -574,7 +632,8 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
                                                                       unsigned char* __restrict__ used_base, u64* __restrict__ d_base,
                                                                       int32_t* __restrict__ prow_base, u64* __restrict__ wpan_base,
                                                                       u64* __restrict__ cco_base, int32_t* __restrict__ slot_base,
-                                                                      u64* __restrict__ tabs_base) {
+                                                                      u64* __restrict__ tabs_base, int member,
+                                                                      const u64* __restrict__ dprev_base, u64* __restrict__ fix_base) {
     __shared__ u64 VT[2048], TW[2048];
     __shared__ u64 V[64], csel[64], pword[64], win_w[RB_WIN], win_c[RB_WIN], fin_w[RB_WIN], fin_c[RB_WIN], CP[64], WP[64];
     __shared__ int win_row[RB_WIN], win_piv[RB_WIN], pbit[64], prow_l[64], misc[4];
@@ -593,9 +652,14 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
     const int64_t rank = st->rank;
     int64_t first_free = st->first_free;
     if (rank >= m || pw * 64 >= n) {
-        if (tid == 0) st->t = 0;
+        if (tid == 0) {
+            st->t = 0;
+            st->tg[member] = 0;
+            if (member == 0) st->tg[1] = 0;
+        }
         return;
     }
+    const int t_prev = member ? st->tg[0] : 0;
     int64_t* pivots = pivots_base ? pivots_base + mat * cap : nullptr;
     int32_t* pivrow = pivrow_base + mat * cap;
     const int64_t cols_here = n - pw * 64;
@@ -672,12 +736,17 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
     if (tid == 0) st->pending = pending;
     if (tid == 0) {
         st->t = t;
+        st->tg[member] = t;
         st->rank = rank + t;
-        st->skip_lo = 0;
-        st->skip_hi = st->first_free < pw * 64 ? st->first_free : pw * 64;
+        if (member == 0) {
+            st->tg[1] = 0;
+            st->skip_lo = 0;
+            st->skip_hi = st->first_free < pw * 64 ? st->first_free : pw * 64;
+        }
         st->first_free = first_free;
     }
     if (t == 0) return;
+    if (member && tid < t) fix_base[mat * 64 + tid] = t_prev > 0 ? dprev_base[mat * m + prow_l[tid]] : 0ull;
     if (wave == 0 && lane < t) {
         const u64 resolved = panel_cols & ~unresolved;
         const int pos = __popcll(resolved & ((1ull << pbit[lane]) - 1ull));
@@ -784,6 +853,180 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_kernel(u64* __restrict
         for (int u = 0; u < 8; ++u) {
             const int64_t row = r0 + (int64_t)u * NW;
             if (d[u] && word_live) a[row * ld + cw0 + lane] = x[u];
+        }
+    }
+}
+
+// addr.byte1 = low / high nibble of byte B of d, the other bytes of addr kept (SDWA): one instruction turns the table's base
+// address into the address of entry (nibble) -- entries are 256 bytes apart, byte 0 holds the lane's word offset.
+template <int B>
+__device__ __forceinline__ void nibble_lo_to_byte1(unsigned int& addr, unsigned int d, unsigned int c0f) {
+    if constexpr (B == 0) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:DWORD" : "+v"(addr) : "v"(d), "v"(c0f));
+    if constexpr (B == 1) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1 src1_sel:DWORD" : "+v"(addr) : "v"(d), "v"(c0f));
+    if constexpr (B == 2) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2 src1_sel:DWORD" : "+v"(addr) : "v"(d), "v"(c0f));
+    if constexpr (B == 3) asm("v_and_b32_sdwa %0, %1, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3 src1_sel:DWORD" : "+v"(addr) : "v"(d), "v"(c0f));
+}
+template <int B>
+__device__ __forceinline__ void nibble_hi_to_byte1(unsigned int& addr, unsigned int d) {
+    if constexpr (B == 0) asm("v_lshrrev_b32_sdwa %0, 4, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_0" : "+v"(addr) : "v"(d));
+    if constexpr (B == 1) asm("v_lshrrev_b32_sdwa %0, 4, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_1" : "+v"(addr) : "v"(d));
+    if constexpr (B == 2) asm("v_lshrrev_b32_sdwa %0, 4, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_2" : "+v"(addr) : "v"(d));
+    if constexpr (B == 3) asm("v_lshrrev_b32_sdwa %0, 4, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_3" : "+v"(addr) : "v"(d));
+}
+
+// One byte (two groups of 4 pivots) of both panels' coefficients for four rows: 16 table reads issued together, then the XORs.
+template <int BYTE>
+__device__ __forceinline__ void pair_lookups4(u64* x, const u64* dA, const u64* dB, unsigned int* pas, unsigned int* pbs, unsigned int c0f) {
+    typedef const __attribute__((address_space(3))) u64* lds_u64_ptr;
+    constexpr unsigned int off = (unsigned int)BYTE * 8192u;          // groups 2*BYTE and 2*BYTE + 1: 4096 bytes each
+    u64 t[16];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const unsigned int a = BYTE < 4 ? (unsigned int)dA[u] : (unsigned int)(dA[u] >> 32);
+        const unsigned int b = BYTE < 4 ? (unsigned int)dB[u] : (unsigned int)(dB[u] >> 32);
+        unsigned int pa = pas[u], pb = pbs[u];                         // byte 1 is rewritten by every lookup, the rest stays
+        nibble_lo_to_byte1<BYTE & 3>(pa, a, c0f);
+        t[4 * u] = *(lds_u64_ptr)(uintptr_t)(pa + off);
+        nibble_hi_to_byte1<BYTE & 3>(pa, a);
+        t[4 * u + 1] = *(lds_u64_ptr)(uintptr_t)(pa + off + 4096u);
+        nibble_lo_to_byte1<BYTE & 3>(pb, b, c0f);
+        t[4 * u + 2] = *(lds_u64_ptr)(uintptr_t)(pb + off);
+        nibble_hi_to_byte1<BYTE & 3>(pb, b);
+        t[4 * u + 3] = *(lds_u64_ptr)(uintptr_t)(pb + off + 4096u);
+        pas[u] = pa, pbs[u] = pb;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const unsigned int lo = __builtin_amdgcn_bitop3_b32((unsigned int)x[u], (unsigned int)t[4 * u], (unsigned int)t[4 * u + 1], 0x96);
+        const unsigned int hi = __builtin_amdgcn_bitop3_b32((unsigned int)(x[u] >> 32), (unsigned int)(t[4 * u] >> 32),
+                                                            (unsigned int)(t[4 * u + 1] >> 32), 0x96);
+        unsigned int lo2 = __builtin_amdgcn_bitop3_b32(lo, (unsigned int)t[4 * u + 2], (unsigned int)t[4 * u + 3], 0x96);
+        unsigned int hi2 = __builtin_amdgcn_bitop3_b32(hi, (unsigned int)(t[4 * u + 2] >> 32), (unsigned int)(t[4 * u + 3] >> 32), 0x96);
+        // pins the XORs here: they have no side effects, and instruction selection otherwise places all 256 of a row block after
+        // its last read, with every table word spilled in between
+        asm volatile("" : "+v"(lo2), "+v"(hi2));
+        x[u] = ((u64)hi2 << 32) | lo2;
+    }
+}
+
+// The RREF's trailing update, one pass of the matrix for a PAIR of panels (grid: row blocks, column chunks of 32 words,
+// matrices; block 1024; 128 KiB of dynamic LDS: two Four-Russians tables of 16 groups x 16 entries x 32 words).
+//   new_i = old_i ^ dA_i . SA ^ dB_i . SB',   SB'_q = SB_q ^ fix_q . SA
+// SA: the first panel's pivot rows as they stood before it; SB: the second panel's pivot rows as they stand in memory, that
+// is without the first panel's update, which the table build adds (fix_q = dA of that row).  A wavefront moves two rows
+// at a time, 32 lanes = 256 contiguous bytes each; a lookup is v_bfe + v_lshl_add + ds_read_b64 with an immediate offset.
+#define U2_CW 32
+__global__ __launch_bounds__(RB_THREADS) void rref_update_pair_kernel(u64* __restrict__ base, int64_t m, int64_t ld,
+                                                                     int64_t rows_per_wg, const RrefState* __restrict__ states,
+                                                                     const u64* __restrict__ da_base, const u64* __restrict__ db_base,
+                                                                     const u64* __restrict__ snapa_base, const u64* __restrict__ snapb_base,
+                                                                     const u64* __restrict__ fix_base) {
+    extern __shared__ __attribute__((aligned(16))) u64 T[];           // [2][16 groups][16 entries][32 words]
+    const int64_t mat = blockIdx.z;
+    const RrefState st = states[mat];
+    const int ta = st.tg[0], tb = st.tg[1];
+    const int64_t cw0 = (int64_t)blockIdx.y * U2_CW;
+    if ((ta | tb) == 0 || (cw0 * 64 >= st.skip_lo && (cw0 + U2_CW) * 64 <= st.skip_hi)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wc_n = ld - cw0 < U2_CW ? (int)(ld - cw0) : U2_CW;
+    typedef const __attribute__((address_space(3))) u64* lds_u64_ptr;
+    // 16 lookups of one table, entry (g, nibble g of d) at byte (g*16 + nibble)*256 + word*8 from `at`
+    auto lookup16 = [](unsigned int at, u64 d) -> u64 {
+        u64 x = 0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const unsigned int nib = (unsigned int)(d >> (4 * g)) & 15u;
+            x ^= *(lds_u64_ptr)(uintptr_t)(at + nib * 256u + (unsigned int)g * 4096u);
+        }
+        return x;
+    };
+    // the 16 XOR combinations of a group's four rows: a lane takes (group, word) and the entries with bit 3 clear or set, reads the
+    // four single rows and writes its eight entries (4 LDS reads and 8 writes per lane instead of 32 reads)
+    auto combos = [&](u64* tab) {
+        const int wd = tid & (U2_CW - 1), g = (tid / U2_CW) & 15, top = tid / (16 * U2_CW);
+        u64* e = tab + (g * 16) * U2_CW + wd;
+        const u64 r0 = e[1 * U2_CW], r1 = e[2 * U2_CW], r2 = e[4 * U2_CW], r3 = top ? e[8 * U2_CW] : 0ull;
+        const u64 c3 = r3, c13 = r0 ^ r3, c23 = r1 ^ r3, c123 = r0 ^ r1 ^ r3;
+        u64* o = e + (top ? 8 * U2_CW : 0);
+        if (!top) o[0] = 0ull;                                         // entry 8 is a single row and stays
+        if (top) o[1 * U2_CW] = c13, o[2 * U2_CW] = c23;               // entries 1, 2, 4 are single rows
+        o[3 * U2_CW] = c123;
+        if (top) o[4 * U2_CW] = r2 ^ c3;
+        o[5 * U2_CW] = r2 ^ c13;
+        o[6 * U2_CW] = r2 ^ c23;
+        o[7 * U2_CW] = r2 ^ c123;
+    };
+    u64* TA = T;
+    u64* TB = T + 16 * 16 * U2_CW;
+    u64 sb[2];
+    {
+        u64 sa[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {                               // 64 x 32 words / 1024 lanes
+            const int idx = tid + RB_THREADS * it, p = idx / U2_CW, wd = idx & (U2_CW - 1);
+            sa[it] = (p < ta && wd < wc_n) ? snapa_base[(mat * 64 + p) * ld + cw0 + wd] : 0ull;
+            sb[it] = (p < tb && wd < wc_n) ? snapb_base[(mat * 64 + p) * ld + cw0 + wd] : 0ull;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + RB_THREADS * it, p = idx / U2_CW, wd = idx & (U2_CW - 1);
+            TA[((p >> 2) * 16 + (1 << (p & 3))) * U2_CW + wd] = sa[it];
+        }
+    }
+    __syncthreads();
+    combos(TA);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + RB_THREADS * it, p = idx / U2_CW, wd = idx & (U2_CW - 1);
+        u64 x = sb[it];
+        if (ta > 0 && p < tb) x ^= lookup16((unsigned int)wd * 8u, fix_base[mat * 64 + p]);
+        TB[((p >> 2) * 16 + (1 << (p & 3))) * U2_CW + wd] = x;
+    }
+    __syncthreads();
+    combos(TB);
+    __syncthreads();
+    u64* a = base + mat * m * ld;
+    const u64* da = da_base + mat * m;
+    const u64* db = db_base + mat * m;
+    // the second half-wave takes its row's words rotated by 16: whichever 32 lanes the LDS serves together (0..31, or 0..15 with
+    // 32..47), their 256 bytes then fall on 64 different banks (without the rotation the pair kernel ran at half speed)
+    const int half = lane >> 5, hl = (lane & (U2_CW - 1)) ^ (half << 4);
+    const bool word_live = hl < wc_n && !((cw0 + hl) * 64 >= st.skip_lo && (cw0 + hl + 1) * 64 <= st.skip_hi);
+    const unsigned int at_a = (unsigned int)hl * 8u, at_b = at_a + 65536u, c0f = 0x0fu;
+    const int64_t row_end = ((int64_t)blockIdx.x + 1) * rows_per_wg < m ? ((int64_t)blockIdx.x + 1) * rows_per_wg : m;
+    constexpr int NW = RB_THREADS / 64;
+    // addresses = a wavefront-uniform base (scalar registers) + one 32-bit lane offset that serves all eight rows of a lane:
+    // per-lane 64-bit pointers for 8 rows x 3 arrays would take 48 registers
+    const int rl = 2 * wave + half;                                    // this lane's row among the 32 of a slot
+    const unsigned int lane_word = (unsigned int)rl * (unsigned int)ld + (unsigned int)hl;
+    for (int64_t rb = (int64_t)blockIdx.x * rows_per_wg; rb < row_end; rb += 2 * NW * 8) {
+        u64 x[8], dA[8], dB[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                                  // 16 rows' loads in flight per wavefront
+            const int64_t rs = rb + (int64_t)u * 2 * NW;               // uniform
+            const bool in = rs + rl < row_end;
+            const u64* dau = da + rs;
+            const u64* dbu = db + rs;
+            const u64* au = a + rs * ld + cw0;
+            dA[u] = (in && ta > 0) ? dau[(unsigned int)rl] : 0ull;
+            dB[u] = (in && tb > 0) ? dbu[(unsigned int)rl] : 0ull;
+            x[u] = (in && word_live) ? au[lane_word] : 0ull;             // (not made to wait for d: rows with d = 0 are rare)
+        }
+        unsigned int pas[8], pbs[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pas[u] = at_a, pbs[u] = at_b;
+        // (scheduling barriers: left alone, the scheduler hoists all 256 reads of a row block and spills)
+#define GF2_PAIR_BYTE(B)                                                                                                \
+    pair_lookups4<B>(x, dA, dB, pas, pbs, c0f); __builtin_amdgcn_sched_barrier(0);                                      \
+    pair_lookups4<B>(x + 4, dA + 4, dB + 4, pas + 4, pbs + 4, c0f); __builtin_amdgcn_sched_barrier(0)
+        GF2_PAIR_BYTE(0); GF2_PAIR_BYTE(1); GF2_PAIR_BYTE(2); GF2_PAIR_BYTE(3);
+        GF2_PAIR_BYTE(4); GF2_PAIR_BYTE(5); GF2_PAIR_BYTE(6); GF2_PAIR_BYTE(7);
+#undef GF2_PAIR_BYTE
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            u64* au = a + (rb + (int64_t)u * 2 * NW) * ld + cw0;
+            if ((dA[u] | dB[u]) && word_live) au[lane_word] = x[u];
         }
     }
 }
@@ -1145,15 +1388,21 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
     const size_t sbytes = al((size_t)batch * sizeof(RrefState)), ubytes = al((size_t)batch * m);
     const size_t dbytes = al((size_t)batch * m * 8), nbytes = al((size_t)batch * 64 * ld * 8);
     const bool stream = rpt > 8;
+    const size_t fbytes = al((size_t)batch * 64 * 8);
     const size_t xbytes = stream ? 2 * dbytes + al((size_t)batch * m * 4) + al((size_t)batch * 64 * 4) + (size_t)batch * 4096 * 8 : 0;
-    GF2_TRY(gf2_ws_reserve(ctx, 1, abytes + pbytes + sbytes + ubytes + dbytes + nbytes + xbytes));
+    GF2_TRY(gf2_ws_reserve(ctx, 1, abytes + pbytes + sbytes + ubytes + 2 * dbytes + 2 * nbytes + fbytes + xbytes));
     char* q = (char*)ctx->ws[1];
     u64* tmp = (u64*)q; q += abytes;
     int32_t* pivrow = (int32_t*)q; q += pbytes;
     RrefState* states = (RrefState*)q; q += sbytes;
     unsigned char* used = (unsigned char*)q; q += ubytes;
-    u64* dco = (u64*)q; q += dbytes;
-    u64* snap = (u64*)q; q += nbytes;
+    u64* dco2[2];                                                      // per panel of a pair: coefficients d, pivot-row snapshot
+    u64* snap2[2];
+    dco2[0] = (u64*)q; q += dbytes;
+    dco2[1] = (u64*)q; q += dbytes;
+    snap2[0] = (u64*)q; q += nbytes;
+    snap2[1] = (u64*)q; q += nbytes;
+    u64* fix = (u64*)q; q += fbytes;
     u64* wpan = (u64*)q;
     u64* cco = (u64*)(q + dbytes);
     int32_t* slot_of = (int32_t*)(q + 2 * dbytes);
@@ -1167,23 +1416,36 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
         GF2_HIP(hipMemcpyAsync(states, init.data(), (size_t)batch * sizeof(RrefState), hipMemcpyHostToDevice, ctx->stream));
         GF2_HIP(hipStreamSynchronize(ctx->stream));                              // init lives on the host stack
     }
-    if (!ctx->lds_optin[1]) {
-        GF2_HIP(hipFuncSetAttribute((const void*)rref_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        ctx->lds_optin[1] = true;
+    if (!ctx->lds_optin[4]) {
+        GF2_HIP(hipFuncSetAttribute((const void*)rref_update_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ctx->lds_optin[4] = true;
     }
     const int64_t panels = gf2_words(n) < ld ? gf2_words(n) : ld;
     // rows per update workgroup: a lone matrix wants many workgroups, a large batch wants the table build amortised
-    const int64_t rows_per_wg = batch * gf2_cdiv(ld, 64) >= 64 ? 512 : (batch * gf2_cdiv(ld, 64) >= 8 ? 256 : 128);
-    const dim3 ugrid((unsigned)gf2_cdiv(m, rows_per_wg), (unsigned)gf2_cdiv(ld, 64), (unsigned)batch);
+    const int64_t chunks = gf2_cdiv(ld, U2_CW);
+    // (a workgroup owns its CU -- 128 KiB of tables -- and building them takes as long as streaming 300 rows: two workgroups
+    // per CU over the whole launch, but no fewer than 128 rows each)
+    int64_t rows_per_wg = gf2_cdiv(gf2_cdiv(m * chunks * batch, 2 * (int64_t)ctx->num_cus), 256) * 256;
+    if (rows_per_wg > 256) rows_per_wg = gf2_cdiv(m, gf2_cdiv(m, rows_per_wg));
+    if (rows_per_wg < 128) rows_per_wg = 128;
+    if (m * chunks * batch < 256 * (int64_t)ctx->num_cus) rows_per_wg = 128;
+    const dim3 ugrid((unsigned)gf2_cdiv(m, rows_per_wg), (unsigned)chunks, (unsigned)batch);
+    // Panels go in PAIRS with one trailing pass of the matrix per pair (rref_update_pair_kernel): the second panel brings its
+    // own column up to date on the way in and leaves the correction of its pivot rows to the table build of that pass.
     for (int64_t pw = 0; pw < panels; ++pw) {
+        const int member = (int)(pw & 1);
+        u64* dco = dco2[member];
+        u64* snap = snap2[member];
 #define GF2_RP_LAUNCH(RPT)                                                                                              \
     hipLaunchKernelGGL((rref_panel_kernel<RPT>), dim3((unsigned)batch), dim3(RB_THREADS), 0, ctx->stream, a_dev, m, n, ld, \
-                       pw, pivots_dev, cap, pivrow, states, used, dco, snap)
+                       pw, pivots_dev, cap, pivrow, states, used, dco, snap, member, (const u64*)dco2[0], (const u64*)snap2[0], fix)
         if (stream) {
             hipLaunchKernelGGL(panel_column_kernel, dim3((unsigned)gf2_cdiv(m, 256), (unsigned)batch), dim3(256), 0, ctx->stream,
-                               (const u64*)a_dev, m, ld, pw, wpan, cco, slot_of);
+                               (const u64*)a_dev, m, ld, pw, wpan, cco, slot_of, member, (const RrefState*)states,
+                               (const u64*)dco2[0], (const u64*)snap2[0]);
             hipLaunchKernelGGL(rref_panel_stream_kernel, dim3((unsigned)batch), dim3(RB_THREADS), 0, ctx->stream, a_dev, m, n,
-                               ld, pw, pivots_dev, cap, pivrow, states, used, dco, panel_rows, wpan, cco, slot_of, tabs);
+                               ld, pw, pivots_dev, cap, pivrow, states, used, dco, panel_rows, wpan, cco, slot_of, tabs, member,
+                               (const u64*)dco2[0], fix);
             hipLaunchKernelGGL(panel_coeff_kernel, dim3((unsigned)gf2_cdiv(m, 1024), (unsigned)batch), dim3(1024), 0, ctx->stream, m,
                                (const RrefState*)states, (const u64*)wpan, (const u64*)cco, (const int32_t*)slot_of, (const u64*)tabs, dco);
             hipLaunchKernelGGL(panel_snapshot_kernel, dim3(64, (unsigned)batch), dim3(256), 0, ctx->stream, (const u64*)a_dev, m, ld,
@@ -1197,12 +1459,14 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
         else
             GF2_RP_LAUNCH(8);
 #undef GF2_RP_LAUNCH
-        hipLaunchKernelGGL(rref_update_kernel, ugrid, dim3(RB_THREADS), 128 * 1024, ctx->stream, a_dev, m, ld, rows_per_wg, states, dco,
-                           snap);
+        if (member == 0 && pw + 1 < panels) continue;                 // the pair's second panel first
+        hipLaunchKernelGGL(rref_update_pair_kernel, ugrid, dim3(RB_THREADS), 128 * 1024, ctx->stream, a_dev, m, ld, rows_per_wg,
+                           (const RrefState*)states, (const u64*)dco2[0], (const u64*)dco2[1], (const u64*)snap2[0],
+                           (const u64*)snap2[1], (const u64*)fix);
         // Every row may have its pivot once m columns have been seen, and a random matrix is done right there: from then on the
         // ranks are read back now and then (a stream synchronisation, but it saves the launches of the panels that would find
         // nothing left to do -- half of them for a 2048 x 4096 matrix).
-        if ((pw + 1) * 64 >= m && pw + 1 < panels && ((pw + 1) * 64 - m) % 512 < 64) {
+        if ((pw + 1) * 64 >= m && pw + 1 < panels && ((pw + 1) * 64 - m) % 512 < 128) {
             std::vector<RrefState> now((size_t)batch);
             GF2_HIP(hipMemcpyAsync(now.data(), states, (size_t)batch * sizeof(RrefState), hipMemcpyDeviceToHost, ctx->stream));
             GF2_TRY(gf2_stream_wait(ctx->stream));
