@@ -83,6 +83,7 @@ int gf2_ctx_sync(gf2_ctx* ctx);
 #define GF2_F_SAMPLER_GENERIC      (1u << 11)  /* gf2_sample_errors_dev: lane-per-word kernel                           */
 #define GF2_F_DIAG_CLOCKS          (1u << 12)  /* slab pipeline: print wall-clock stamps of its kernels to stderr       */
 #define GF2_F_DIAG_MC_TIMES        (1u << 13)  /* gf2_mc_run: print the host's phases to stderr                         */
+#define GF2_F_MC_ROWS              (1u << 14)  /* gf2_mc_run: packed rows from the sampler, records by the compact kernel */
 int gf2_ctx_set_flags(gf2_ctx* ctx, uint32_t flags);
 int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
 /* Tunables of a context (value < 0 restores the default). */
@@ -90,7 +91,8 @@ int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
 #define GF2_OPT_COMBINE_BLOCKS  1   /* slab pipeline: workgroups of the combine kernel (default 128)                      */
 #define GF2_OPT_GATHER_REVERSE   2   /* slab pipeline: 1 (default) = the gather kernel walks the records last tile first  */
 #define GF2_OPT_REDO_BLOCKS_PER_CU 3 /* slab pipeline: workgroups per CU of the redo kernel (default 8)                       */
-#define GF2_OPT_COUNT           4
+#define GF2_OPT_MC_CHUNK_LOG2   4   /* gf2_mc_run, three-stream pipeline: 2^k samples per chunk, 16 <= k <= 22 (default 21)       */
+#define GF2_OPT_COUNT           5
 int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value);
 
 /* Device memory and stream-ordered copies on the context's stream (copies are synchronous). */

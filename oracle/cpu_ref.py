@@ -343,10 +343,11 @@ def pauli_thresholds(p_x, p_y, p_z):
     return t_any, t_1, t_2
 
 
-def binomial_cdf_table(t_any, nb):
-    """cdf[k] = 2^32 * P(Bin(nb, q) <= k) rounded to nearest and clamped to 2^32, q = t_any / 2^32, in IEEE doubles with the
-    operation order of DESIGN.md "Sampler".  The number of errors of a word is K = #{k < nb : u >= cdf[k]}."""
-    cdf = [1 << 32] * 65
+SEGMENT = 512                # qubits per segment of the sampler
+
+
+def _binomial_cdf_direct(t_any, nb):
+    cdf = [1 << 32] * (max(nb, 64) + 1)
     if nb <= 0:
         return cdf
     if t_any >= (1 << 32):
@@ -369,21 +370,44 @@ def binomial_cdf_table(t_any, nb):
     return cdf
 
 
+_cdf_cache = {}
+
+
+def binomial_cdf_table(t_any, nb):
+    """cdf[k] = 2^32 * P(Bin(nb, q) <= k) rounded to nearest and clamped to 2^32, q = t_any / 2^32, in IEEE doubles with the
+    operation order of DESIGN.md "Sampler".  The number of errors of a segment is K = #{k < nb : u >= cdf[k]}.  Segments of more
+    than 64 qubits at q > 1/2 take the table from the complementary count nb - K ~ Bin(nb, 1 - q) ((1 - q)^nb underflows)."""
+    key = (t_any, nb)
+    if key not in _cdf_cache:
+        if nb <= 64 or t_any <= (1 << 31) or t_any >= (1 << 32):
+            cdf = _binomial_cdf_direct(t_any, nb)
+        else:
+            other = _binomial_cdf_direct((1 << 32) - t_any, nb)
+            cdf = [1 << 32] * (nb + 1)
+            for k in range(nb):
+                cdf[k] = (1 << 32) - other[nb - k - 1]
+        _cdf_cache[key] = cdf
+    return _cdf_cache[key]
+
+
 def sample_pauli_error(seed, sample, n, p_x, p_y, p_z):
     """[build-defined, x3]  Error of global sample index `sample`: a pure function of (seed, sample).  Returns
-    (e_x, e_z) as length-n int arrays.  Per 64-qubit word one draw d: its high half gives the number of erroneous
+    (e_x, e_z) as length-n int arrays.  Per segment of 512 qubits one draw d: its high half gives the number of erroneous
     qubits by inverse binomial CDF; each erroneous qubit takes one further draw mix64(d + G (k + 1)), whose high half
-    picks its position (Floyd's algorithm) and whose low half its kind (DESIGN.md "Sampler")."""
+    picks its position inside the segment (Floyd's algorithm) and whose low half its kind (DESIGN.md "Sampler")."""
     t_any, t_1, t_2 = pauli_thresholds(p_x, p_y, p_z)
     ks = mix64(seed + GOLDEN * (sample + 1))
     e_x = np.zeros(n, dtype='int')
     e_z = np.zeros(n, dtype='int')
-    words = (n + 63) // 64
-    for w in range(words):
-        nb = 64 if w < words - 1 else n - 64 * (words - 1)
+    segments = (n + SEGMENT - 1) // SEGMENT
+    for s in range(segments):
+        nb = SEGMENT if s < segments - 1 else n - SEGMENT * (segments - 1)
         cdf = binomial_cdf_table(t_any, nb)
-        d = mix64(ks + STREAM_MULT * (w + 1))
-        k_err = sum(1 for k in range(nb) if (d >> 32) >= cdf[k])
+        d = mix64(ks + STREAM_MULT * (s + 1))
+        u = d >> 32
+        k_err = 0
+        while k_err < nb and u >= cdf[k_err]:
+            k_err += 1
         chosen = set()
         for k in range(k_err):                                 # Floyd: k_err distinct positions in range(nb)
             v = mix64(d + GOLDEN * (k + 1))
@@ -392,8 +416,8 @@ def sample_pauli_error(seed, sample, n, p_x, p_y, p_z):
             pos = j if t in chosen else t
             chosen.add(pos)
             kind = v & 0xFFFFFFFF
-            e_x[64 * w + pos] = 1 if kind < t_2 else 0
-            e_z[64 * w + pos] = 1 if kind >= t_1 else 0
+            e_x[SEGMENT * s + pos] = 1 if kind < t_2 else 0
+            e_z[SEGMENT * s + pos] = 1 if kind >= t_1 else 0
     return e_x, e_z
 
 

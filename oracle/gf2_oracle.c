@@ -169,8 +169,9 @@ static u64 quantise(double x) {
 
 /* Inverse binomial CDF table: cdf[k] = round-to-nearest(2^32 * P(Bin(nb, q) <= k)) clamped to 2^32, q = t_any / 2^32, IEEE
  * doubles in exactly this operation order (DESIGN.md "Sampler").  K = number of k < nb with u >= cdf[k]. */
-static void binomial_cdf(u64 t_any, int nb, u64* cdf) {
-    for (int k = 0; k < 65; ++k) cdf[k] = 4294967296ull;
+#define SEGMENT 512
+static void binomial_cdf_direct(u64 t_any, int nb, u64* cdf) {
+    for (int k = 0; k <= SEGMENT; ++k) cdf[k] = 4294967296ull;
     if (nb <= 0) return;
     if (t_any >= 4294967296ull) {
         for (int k = 0; k < nb; ++k) cdf[k] = 0;
@@ -188,43 +189,56 @@ static void binomial_cdf(u64 t_any, int nb, u64* cdf) {
         pmf = pmf * (double)(nb - k) / (double)(k + 1) * q / om;
     }
 }
+/* Segments of more than 64 qubits at q > 1/2: from the complementary count nb - K ~ Bin(nb, 1 - q), whose (1 - q')^nb does
+ * not underflow. */
+static void binomial_cdf(u64 t_any, int nb, u64* cdf) {
+    if (nb <= 64 || t_any <= 2147483648ull || t_any >= 4294967296ull) {
+        binomial_cdf_direct(t_any, nb, cdf);
+        return;
+    }
+    u64 other[SEGMENT + 1];
+    binomial_cdf_direct(4294967296ull - t_any, nb, other);
+    for (int k = 0; k <= SEGMENT; ++k) cdf[k] = 4294967296ull;
+    for (int k = 0; k < nb; ++k) cdf[k] = 4294967296ull - other[nb - k - 1];
+}
 
+/* Sample-major rows of lde words; per SEGMENT of 512 qubits one draw for the number of errors, one per erroneous qubit. */
 int orc_sample_errors(int64_t n, u64 seed, int64_t first, int64_t count, double p_x, double p_y, double p_z,
                       u64* ex, u64* ez, int64_t lde) {
     const double p_t = p_x + p_y + p_z, p_xy = p_x + p_y;
     const u64 t_any = quantise(p_t);
     const u64 t_1 = p_t > 0.0 ? quantise(p_x / p_t) : 0;          /* X only below t_1, Y below t_2, else Z */
     const u64 t_2 = p_t > 0.0 ? quantise(p_xy / p_t) : 0;
-    const int64_t words = (n + 63) >> 6;
-    const int nb_last = n > 0 ? (int)(n - (words - 1) * 64) : 0;
-    u64 cdf_full[65], cdf_last[65];
-    binomial_cdf(t_any, 64, cdf_full);
-    binomial_cdf(t_any, nb_last, cdf_last);
+    const int64_t segments = (n + SEGMENT - 1) / SEGMENT;
+    const int nb_last = n > 0 ? (int)(n - (segments - 1) * SEGMENT) : 0;
+    static u64 cdf_full[SEGMENT + 1], cdf_last[SEGMENT + 1], made_t = ~0ull;   /* (kept between calls: the decode tally asks per sample) */
+    static int made_nb = -1;
+    if (made_t != t_any || made_nb != nb_last) {
+        binomial_cdf(t_any, SEGMENT, cdf_full);
+        binomial_cdf(t_any, nb_last, cdf_last);
+        made_t = t_any, made_nb = nb_last;
+    }
     for (int64_t i = 0; i < count; ++i) {
         const u64 ks = mix64(seed + GOLDEN * ((u64)(first + i) + 1));
-        for (int64_t w = 0; w < lde; ++w) {
-            u64 x = 0, z = 0;
-            if (w < words) {
-                const int nb = w == words - 1 ? nb_last : 64;
-                const u64* cdf = w == words - 1 ? cdf_last : cdf_full;
-                const u64 d = mix64(ks + STREAM_MULT * ((u64)w + 1));      /* the word's draw */
-                int k_err = 0;
-                for (int k = 0; k < nb; ++k)
-                    if ((d >> 32) >= cdf[k]) k_err += 1;                   /* the table is non-decreasing */
-                u64 chosen = 0;
-                for (int k = 0; k < k_err; ++k) {                         /* Floyd: k_err distinct positions, one draw each */
-                    const u64 v = mix64(d + GOLDEN * ((u64)k + 1));
-                    const int j = nb - k_err + k;
-                    const int t = (int)(((v >> 32) * (u64)(j + 1)) >> 32);
-                    const int pos = ((chosen >> t) & 1ull) ? j : t;
-                    const u64 kind = v & 0xFFFFFFFFull;
-                    chosen |= 1ull << pos;
-                    if (kind < t_2) x |= 1ull << pos;                      /* X or Y */
-                    if (kind >= t_1) z |= 1ull << pos;                     /* Y or Z */
-                }
+        for (int64_t w = 0; w < lde; ++w) ex[i * lde + w] = 0, ez[i * lde + w] = 0;
+        for (int64_t s = 0; s < segments; ++s) {
+            const int nb = s == segments - 1 ? nb_last : SEGMENT;
+            const u64* cdf = s == segments - 1 ? cdf_last : cdf_full;
+            const u64 d = mix64(ks + STREAM_MULT * ((u64)s + 1));          /* the segment's draw */
+            int k_err = 0;
+            while (k_err < nb && (d >> 32) >= cdf[k_err]) k_err += 1;      /* the table is non-decreasing */
+            u64 chosen[SEGMENT / 64] = {0};
+            for (int k = 0; k < k_err; ++k) {                             /* Floyd: k_err distinct positions, one draw each */
+                const u64 v = mix64(d + GOLDEN * ((u64)k + 1));
+                const int j = nb - k_err + k;
+                const int t = (int)(((v >> 32) * (u64)(j + 1)) >> 32);
+                const int pos = ((chosen[t >> 6] >> (t & 63)) & 1ull) ? j : t;
+                const u64 kind = v & 0xFFFFFFFFull;
+                const int64_t word = s * (SEGMENT / 64) + (pos >> 6);
+                chosen[pos >> 6] |= 1ull << (pos & 63);
+                if (kind < t_2) ex[i * lde + word] |= 1ull << (pos & 63);  /* X or Y */
+                if (kind >= t_1) ez[i * lde + word] |= 1ull << (pos & 63); /* Y or Z */
             }
-            ex[i * lde + w] = x;
-            ez[i * lde + w] = z;
         }
     }
     return 0;

@@ -18,8 +18,8 @@ hm2[:, 2048:4095] = np.eye(2047, dtype=np.uint8)
 c1 = ctx.check_create(_native.pack_rows(hm1), 2048, 4096)
 c2 = ctx.check_create(_native.pack_rows(hm2), 2047, 4096)
 p = 0.01 / 3
-ctx.mc_run(c1, c2, 1, 0, 1 << 20, p, p, p, _native.HIST_WEIGHT)
 count = 1 << 24
+ctx.mc_run(c1, c2, 1, 0, count, p, p, p, _native.HIST_WEIGHT)          # (workspaces are sized by the first call)
 t0 = time.perf_counter()
 hz, hx = ctx.mc_run(c1, c2, 1, 0, count, p, p, p, _native.HIST_WEIGHT)
 dt = time.perf_counter() - t0

@@ -157,6 +157,8 @@ int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value) {
     if (value >= 0) {
         if (option == GF2_OPT_SLAB_PASS_LOG2 && (value < 12 || value > 22))
             GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_SLAB_PASS_LOG2 must be in 12..22");
+        if (option == GF2_OPT_MC_CHUNK_LOG2 && (value < 16 || value > 22))
+            GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_MC_CHUNK_LOG2 must be in 16..22");
         if (option == GF2_OPT_COMBINE_BLOCKS && (value < 1 || value > 65535))
             GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_COMBINE_BLOCKS must be in 1..65535");
     }
@@ -171,6 +173,7 @@ int gf2_ctx_destroy(gf2_ctx* ctx) {
     for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(ctx->side[k]);
     for (int k = 0; k < 4; ++k)
         if (ctx->ws[k]) (void)hipFree(ctx->ws[k]);
+    if (ctx->seg_cdf_dev) (void)hipFree(ctx->seg_cdf_dev);
     destroy_streams_and_events(ctx);
     free(ctx);
     return GF2_OK;

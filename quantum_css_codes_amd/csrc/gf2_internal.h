@@ -62,6 +62,10 @@ struct gf2_ctx {
     // routing flags (GF2_F_*) and tunables (GF2_OPT_*, -1 = default): gf2_ctx_set_flags / gf2_ctx_set_option
     uint32_t flags;
     int64_t opt[GF2_OPT_COUNT];
+    // the sampler's two inverse-CDF tables (whole segments, last segment) in device memory, and what they were made for
+    uint64_t* seg_cdf_dev;
+    uint64_t seg_key_t;
+    int seg_key_nb;
 };
 static inline bool gf2_flag(const gf2_ctx* ctx, uint32_t f) { return (ctx->flags & f) != 0; }
 
@@ -116,6 +120,14 @@ bool gf2_slabs_ok(const gf2_check* ck);
 int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde,
                        uint64_t* hist_dev, hipStream_t stream, int ws_slot);
 int gf2_slabs_reserve(gf2_ctx* ctx, const gf2_check* ck, int64_t batch, int ws_slot);
+// gf2_mc_run's path without packed rows: the sampler writes the records and the identity words itself (gf2_slabs.hip)
+struct SegTables;
+bool gf2_mc_records_ok(const gf2_check* c1, const gf2_check* c2);
+size_t gf2_mc_records_bytes(int64_t n, int64_t pass);
+int gf2_mc_records_sample(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t seed, int64_t first_sample, int64_t count,
+                          int64_t pass, const SegTables& th, void* buf, hipStream_t stream);
+int gf2_mc_records_weigh(gf2_ctx* ctx, const gf2_check* ck, int comp, uint64_t seed, int64_t first_sample, int64_t count, int64_t pass,
+                         const SegTables& th, void* buf, uint64_t* hist_dev, hipStream_t stream, int ws_slot);
 bool gf2_mc_sparse_fused_ok(const gf2_check* c1, const gf2_check* c2);
 int gf2_mc_sparse_fused(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t seed, int64_t first_sample,
                         int64_t count, double p_x, double p_y, double p_z, uint64_t* hz_dev, uint64_t* hx_dev);

@@ -14,120 +14,244 @@
 
 #include "gf2_sampler.h"
 
-// One lane per output word.  Sample-major: idx = i * lde + w.  Tiled: idx is the tiled word offset
-// (i>>6)*64*ldt + (w>>1)*128 + (i&63)*2 + (w&1).  Either way consecutive lanes write consecutive words.
+// Generic sampler, any n and either layout: one lane per (sample, segment).  The lane runs its segment start to end into 32 dwords
+// of LDS of its own and writes the segment's (up to) eight words of e_x and e_z.  Sample-major: word w of sample i at i * lde + w.
+// Tiled: at (i>>6)*64*ldt + (w>>1)*128 + (i&63)*2 + (w&1).  Words of the row pitch beyond the last segment are zeroed.
+#define GEN_THREADS 256
+#define GEN_STRIDE 33                          // dwords per lane: odd, so the lanes' dwords fall on different banks
 template <bool TILED>
-__global__ __launch_bounds__(256) void sampler_kernel(u64 seed, int64_t first_sample, int64_t count, int64_t n,
-                                                      int64_t words, int64_t lde, int64_t total, SamplerTables th,
-                                                      uint64_t* __restrict__ ex, uint64_t* __restrict__ ez) {
-    __shared__ u64 cdf_lds[130];
-    stage_cdf(th, cdf_lds);
+__global__ __launch_bounds__(GEN_THREADS) void sampler_kernel(u64 seed, int64_t first_sample, int64_t count, int64_t n,
+                                                              int64_t words, int64_t lde, SegTables th,
+                                                              uint64_t* __restrict__ ex, uint64_t* __restrict__ ez) {
+    __shared__ u64 cdf_lds[2 * GF2_SEG_CDF];
+    __shared__ unsigned int xz_all[GEN_THREADS * GEN_STRIDE];
+    stage_seg_cdf(th, cdf_lds);
+    unsigned int* const xz = xz_all + threadIdx.x * GEN_STRIDE;
+    const int64_t segs_row = TILED ? th.nseg : (lde + GF2_SEG_WORDS - 1) / GF2_SEG_WORDS;   // sample-major: the pitch is zero-filled
+    const int64_t rows = TILED ? ((count + 63) / 64) * 64 : count;
+    const int64_t total = rows * segs_row;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
-        int64_t i, w;
-        if (TILED) {
-            const int64_t tile = idx / (64 * lde), rem = idx - tile * 64 * lde;
-            i = tile * 64 + ((rem & 127) >> 1);
-            w = (rem >> 7) * 2 + (rem & 1);
+        const int64_t i = idx / segs_row;
+        const int s = (int)(idx - i * segs_row);
+        if (i < count && s < th.nseg) {
+            const bool last = s == th.nseg - 1;
+            sample_segment(sample_key(seed, (u64)(first_sample + i)), s, last ? th.nb_last : GF2_SEG_BITS,
+                           cdf_lds + (last ? GF2_SEG_CDF : 0), th.t_1, th.t_2, xz);
         } else {
-            i = idx / lde;
-            w = idx - i * lde;
+#pragma unroll
+            for (int q = 0; q < 32; ++q) xz[q] = 0;
         }
-        u64 x = 0, z = 0;
-        if (i < count && w < words) {
-            const bool last = w == words - 1;
-            sample_word(seed, (u64)(first_sample + i), (u64)w, last ? th.nb_last : 64, cdf_lds + (last ? 65 : 0), th.t_1,
-                        th.t_2, &x, &z);
+#pragma unroll
+        for (int q = 0; q < GF2_SEG_WORDS; ++q) {
+            const int64_t w = (int64_t)s * GF2_SEG_WORDS + q;
+            const u64 x = ((u64)xz[2 * q + 1] << 32) | xz[2 * q], z = ((u64)xz[16 + 2 * q + 1] << 32) | xz[16 + 2 * q];
+            if (TILED) {
+                if (w < lde) {                                    // the tiled pitch: the words rounded up to an even number
+                    const int64_t at = (i >> 6) * 64 * lde + (w >> 1) * 128 + (i & 63) * 2 + (w & 1);
+                    ex[at] = x;
+                    ez[at] = z;
+                }
+            } else if (w < lde) {
+                ex[i * lde + w] = x;
+                ez[i * lde + w] = z;
+            }
         }
-        ex[idx] = x;
-        ez[idx] = z;
     }
 }
 
-// Sample-major errors of up to 64 words per sample: one wavefront per block of 8 samples, lane = word.  Every word takes its
-// one draw and writes zeros into an LDS image of the block; the words with errors (a third of them at p = 0.01) queue up in a
-// ring and are worked off 64 at a time, so that the draws per erroneous qubit run on full wavefronts instead of on the
-// few lanes of each sample that need them; the image then leaves as whole rows.
-#define SMP_BLOCK 8
+// ---- a block of 64 segments per wavefront ---------------------------------------------------------------------------------
+// Shared by the row sampler below and by the record sampler of the LDS-slab pipeline: lane = (sample, segment), NSP = segments
+// per sample rounded up to a power of two, 64 / NSP samples per block.
+//   1. every lane takes its segment's draw d and error count K (the table's first 16 entries sit in scalar registers: a count
+//      is 16 compares, not a chain of dependent table reads);
+//   2. the (segment, k) pairs of the block are laid out flat (prefix sum of K), so that everything per erroneous qubit -- its
+//      draw (a mix64 and a multiply) and later its output -- runs on full wavefronts, 64 qubits per pass, whatever the
+//      spread of K over the segments;
+//   3. Floyd's rule (a candidate position that is taken already gives way to j = nb - K + k) is the one sequential thing: a lane
+//      sends its K candidates through returning LDS atomics on a 512-bit map of its own, eight in flight, and notes which
+//      came back taken.  A taken candidate is a duplicate of an earlier candidate; what the atomics cannot see is a later
+//      candidate equal to the j an earlier duplicate moved to -- the (rare) lanes with duplicates check for that.
+// Afterwards flat item f < E is qubit (src[f] & 63 = lane, src[f] >> 6 = k) with cand[f] = position | kind << 9.
+// A block with more than SMP_FLAT erroneous qubits, or a segment with more than 64 (rates far beyond the sparse regime), is
+// resolved lane by lane (seg_block_sequential).
 #define SMP_WAVES 4
-#define SMP_RING 128
+#define SMP_FLAT 768
+#define SMP_TAKEN 17                            // dwords per lane of the position map: 16 + 1 (odd: the lanes' dwords spread over the banks)
+struct alignas(16) SegBlockLds {
+    u64 draw[64];                               // d of lane's segment
+    unsigned short kn[64];                      // its K
+    unsigned int taken[64 * SMP_TAKEN];
+    unsigned short src[SMP_FLAT];
+    unsigned short cand[SMP_FLAT];
+};
+
+// Steps 1 and 2 up to the flat layout: returns K, first (the lane's first flat item) and E (uniform).
+__device__ __forceinline__ void seg_block_counts(const SegTables& th, u64 seed, u64 sample, int s, bool live, bool last, int lane,
+                                                 u64* d_out, int* K_out, int* first_out, int* E_out) {
+    u64 d = 0;
+    int K = 0;
+    if (live) {
+        d = segment_draw(sample_key(seed, sample), (u64)s);
+        const u64 u = d >> 32;
+        const u64* const tab = th.cdf + (last ? GF2_SEG_CDF : 0);
+        int nb = last ? th.nb_last : GF2_SEG_BITS;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) K += u >= (last ? th.cdf[GF2_SEG_CDF + k] : th.cdf[k]) ? 1 : 0;    // uniform addresses: scalar loads
+        if (K == 16)
+            while (K < nb && u >= tab[K]) K += 1;
+    }
+    // inclusive prefix sum over the lanes with DPP moves (a shuffle goes through the LDS crossbar: six dependent round trips)
+    int incl = K;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);     // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);     // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);     // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);     // row_shr:8: scans of the four rows of 16
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);    // row_bcast:15 into rows 1 and 3
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);    // row_bcast:31 into rows 2 and 3
+    (void)lane;
+    *d_out = d;
+    *K_out = K;
+    *first_out = incl - K;
+    *E_out = __builtin_amdgcn_readlane(incl, 63);
+}
+
+// Steps 2 and 3 for a block with E <= SMP_FLAT and K <= 64 everywhere (uniform: the caller checks).
+__device__ __forceinline__ void seg_block_positions(SegBlockLds& L, const SegTables& th, int lane, int nsp, u64 d, int K, int nb,
+                                                    int first, int E) {
+    L.draw[lane] = d;
+    L.kn[lane] = (unsigned short)K;
+#pragma unroll
+    for (int q = 0; q < SMP_TAKEN; ++q) L.taken[q * 64 + lane] = 0;
+    for (int k = 0; k < K; ++k) L.src[first + k] = (unsigned short)(lane | (k << 6));
+    __builtin_amdgcn_wave_barrier();
+    for (int f0 = lane; f0 < E; f0 += 3 * 64) {                        // three passes' LDS reads in flight together
+        unsigned int m[3], t[3], kind[3];
+        u64 dd[3];
+        unsigned int kk[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) m[u] = f0 + 64 * u < E ? (unsigned int)L.src[f0 + 64 * u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) dd[u] = L.draw[m[u] & 63u], kk[u] = L.kn[m[u] & 63u];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const bool from_last = (int)(m[u] & (unsigned int)(nsp - 1)) == th.nseg - 1;
+            error_draw(dd[u], (int)(m[u] >> 6), (int)kk[u], from_last ? th.nb_last : GF2_SEG_BITS, th.t_1, th.t_2, &t[u], &kind[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (f0 + 64 * u < E) L.cand[f0 + 64 * u] = (unsigned short)(t[u] | (kind[u] << 9));
+    }
+    __builtin_amdgcn_wave_barrier();
+    unsigned int* const mine = L.taken + lane * SMP_TAKEN;
+    u64 coll = 0, high = 0;                                            // high: candidates in [nb - K, nb), where the j live
+    const unsigned int j0 = (unsigned int)(nb - K);
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        unsigned int t[8], old[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = k0 + u < K ? (unsigned int)L.cand[first + k0 + u] & 511u : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) old[u] = atomicOr(&mine[t[u] >> 5], k0 + u < K ? 1u << (t[u] & 31u) : 0u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (k0 + u < K && ((old[u] >> (t[u] & 31u)) & 1u)) coll |= 1ull << (k0 + u);
+            if (k0 + u < K && t[u] >= j0) high |= 1ull << (k0 + u);
+        }
+    }
+    if (coll) {
+        // duplicates move to j_i = nb - K + i; a later candidate equal to such a j_i is taken too (and moves in its turn).
+        // Only candidates of `high` can equal a j, and there is hardly ever one.
+        u64 todo = coll;
+        while (todo) {
+            const int i = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            u64 later = high & ~coll & (i < 63 ? ~0ull << (i + 1) : 0ull);
+            while (later) {
+                const int k = __ffsll((long long)later) - 1;
+                later &= later - 1;
+                if (((unsigned int)L.cand[first + k] & 511u) == j0 + (unsigned int)i) coll |= 1ull << k, todo |= 1ull << k;
+            }
+        }
+        u64 moved = coll;
+        while (moved) {
+            const int k = __ffsll((long long)moved) - 1;
+            moved &= moved - 1;
+            L.cand[first + k] = (unsigned short)((L.cand[first + k] & 0x600u) | (j0 + (unsigned int)k));
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The same outcome, one lane per segment start to end, for blocks the flat layout does not hold: calls emit(position, kind).
+template <typename Emit>
+__device__ __forceinline__ void seg_block_sequential(SegBlockLds& L, const SegTables& th, int lane, u64 d, int K, int nb, Emit emit) {
+    unsigned int* const mine = L.taken + lane * SMP_TAKEN;
+    for (int q = 0; q < SMP_TAKEN; ++q) mine[q] = 0;
+    for (int k = 0; k < K; ++k) {
+        unsigned int t, kind;
+        error_draw(d, k, K, nb, th.t_1, th.t_2, &t, &kind);
+        const bool taken = (mine[t >> 5] >> (t & 31u)) & 1u;
+        const unsigned int pos = taken ? (unsigned int)(nb - K + k) : t;
+        mine[pos >> 5] |= 1u << (pos & 31u);
+        emit(pos, kind);
+    }
+}
+
+// Sample-major errors of 8 .. 64 words per sample (512 <= n <= 4096, or less with a wide pitch): the block's errors are set in an
+// LDS image of its rows by flat passes over the erroneous qubits (LDS atomics without return), and the image leaves as whole rows.
 struct alignas(16) SamplerWaveLds {
-    u64 ring_d[SMP_RING];                       // the word's draw
-    unsigned short ring_m[SMP_RING];            // sample in block << 6 | word, error count << 9
-    u64 img[2][SMP_BLOCK][64];                  // e_x, e_z of the block
+    SegBlockLds b;
+    u64 img[2][64 * GF2_SEG_WORDS];             // e_x, e_z of the block: lane (sample, segment) owns words 8 lane .. 8 lane + 7
 };
 
 __global__ __launch_bounds__(64 * SMP_WAVES) void sampler_rows_kernel(u64 seed, int64_t first_sample, int64_t count, int words,
-                                                                    int64_t lde, SamplerTables th, uint64_t* __restrict__ ex,
-                                                                    uint64_t* __restrict__ ez) {
-    __shared__ u64 cdf_lds[130];
+                                                                    int64_t lde, int nsp_log2, SegTables th,
+                                                                    uint64_t* __restrict__ ex, uint64_t* __restrict__ ez) {
     __shared__ SamplerWaveLds lds_all[SMP_WAVES];
-    stage_cdf(th, cdf_lds);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     SamplerWaveLds& L = lds_all[wave];
-    const bool live = lane < words;
-    const bool last = lane == words - 1;
-    const int nb = last ? th.nb_last : 64;
-    const u64* const cdf = cdf_lds + (last ? 65 : 0);
-    const u64 cdf0 = cdf[0];
-    const int64_t nblocks = (count + SMP_BLOCK - 1) / SMP_BLOCK;
+    const int nsp = 1 << nsp_log2, per_block = 64 >> nsp_log2;        // segments per sample (padded), samples per block
+    const int j = lane >> nsp_log2, s = lane & (nsp - 1);
+    const bool seg_live = s < th.nseg;
+    const bool last = s == th.nseg - 1;
+    const int nb = last ? th.nb_last : GF2_SEG_BITS;
+    unsigned int* const img_x = reinterpret_cast<unsigned int*>(&L.img[0][0]);
+    unsigned int* const img_z = reinterpret_cast<unsigned int*>(&L.img[1][0]);
+    const int64_t nblocks = (count + per_block - 1) / per_block;
     const int64_t total_waves = (int64_t)gridDim.x * SMP_WAVES;
-    unsigned int head = 0, tail = 0;
-    auto process = [&](unsigned int first, unsigned int n_items) {
-        if ((unsigned int)lane < n_items) {
-            const unsigned int at = (first + lane) & (SMP_RING - 1);
-            const u64 d = L.ring_d[at];
-            const unsigned int m = L.ring_m[at];
-            const unsigned int sw = m & 511u, w = m & 63u;
-            u64 x, z;
-            place_errors(d, (int)(m >> 9), (int)w == words - 1 ? th.nb_last : 64, th.t_1, th.t_2, &x, &z);
-            (&L.img[0][0][0])[sw] = x;
-            (&L.img[1][0][0])[sw] = z;
-        }
-    };
 #pragma unroll 1
     for (int64_t blk = (int64_t)blockIdx.x * SMP_WAVES + wave; blk < nblocks; blk += total_waves) {
-        const int64_t i0 = blk * SMP_BLOCK;
-#pragma unroll 1
-        for (int s = 0; s < SMP_BLOCK; ++s) {
-            // the sample's key is the same in every lane: made scalar by hand, the compiler keeps it in vector registers
-            const u64 si = (u64)(first_sample + i0 + s);
-            const u64 si_s = ((u64)(unsigned int)__builtin_amdgcn_readfirstlane((int)(si >> 32)) << 32) |
-                             (unsigned int)__builtin_amdgcn_readfirstlane((int)si);
-            const u64 ks = sample_key(seed, si_s);
-            L.img[0][s][lane] = 0;
-            L.img[1][s][lane] = 0;
-            int k_err = 0;
-            u64 d = 0;
-            if (live && i0 + s < count) {
-                d = word_draw(ks, (u64)lane);
-                if ((d >> 32) >= cdf0) k_err = error_count(d, nb, cdf);
+        const int64_t i0 = blk * per_block;
+        const bool live = seg_live && i0 + j < count;
+#pragma unroll
+        for (int q = 0; q < GF2_SEG_WORDS; ++q) L.img[0][q * 64 + lane] = 0, L.img[1][q * 64 + lane] = 0;
+        u64 d;
+        int K, first, E;
+        seg_block_counts(th, seed, (u64)(first_sample + i0 + j), s, live, last, lane, &d, &K, &first, &E);
+        const bool flat = E <= SMP_FLAT && __ballot(K > 64) == 0;      // uniform
+        if (flat) {
+            seg_block_positions(L.b, th, lane, nsp, d, K, nb, first, E);
+            for (int f = lane; f < E; f += 64) {
+                const unsigned int from = L.b.src[f] & 63u, c = L.b.cand[f], pos = c & 511u;
+                if (c & 0x200u) atomicOr(&img_x[from * 16 + (pos >> 5)], 1u << (pos & 31u));
+                if (c & 0x400u) atomicOr(&img_z[from * 16 + (pos >> 5)], 1u << (pos & 31u));
             }
-            const u64 act = __ballot(k_err > 0);
-            if (k_err > 0) {
-                const unsigned int pos = (tail + __builtin_amdgcn_mbcnt_hi((unsigned int)(act >> 32),
-                                                                             __builtin_amdgcn_mbcnt_lo((unsigned int)act, 0u))) &
-                                         (SMP_RING - 1);
-                L.ring_d[pos] = d;
-                L.ring_m[pos] = (unsigned short)((unsigned int)(s << 6) | (unsigned int)lane | ((unsigned int)k_err << 9));
-            }
-            tail += (unsigned int)__popcll(act);
-            if (tail - head >= 64) {                                // uniform
-                __builtin_amdgcn_wave_barrier();
-                process(head, 64);
-                head += 64;
-            }
+        } else {
+            __builtin_amdgcn_wave_barrier();
+            if (live)
+                seg_block_sequential(L.b, th, lane, d, K, nb, [&](unsigned int pos, unsigned int kind) {
+                    if (kind & 1u) img_x[lane * 16 + (pos >> 5)] |= 1u << (pos & 31u);
+                    if (kind & 2u) img_z[lane * 16 + (pos >> 5)] |= 1u << (pos & 31u);
+                });
         }
         __builtin_amdgcn_wave_barrier();
-        if (tail != head) process(head, tail - head);
-        head = tail;
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int s = 0; s < SMP_BLOCK; ++s) {
-            if (i0 + s < count && lane < lde) {
-                ex[(i0 + s) * lde + lane] = L.img[0][s][lane];
-                ez[(i0 + s) * lde + lane] = L.img[1][s][lane];
+        // rows out: sample jj of the block is words jj * nsp * 8 .. of the image, `words` of them valid, lde stored
+        for (int jj = 0; jj < per_block; ++jj) {
+            if (i0 + jj < count && lane < lde) {
+                const bool in_row = lane < nsp * GF2_SEG_WORDS;
+                ex[(i0 + jj) * lde + lane] = in_row ? L.img[0][jj * nsp * GF2_SEG_WORDS + lane] : 0ull;
+                ez[(i0 + jj) * lde + lane] = in_row ? L.img[1][jj * nsp * GF2_SEG_WORDS + lane] : 0ull;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -217,6 +341,33 @@ __global__ __launch_bounds__(256) void mc_small_kernel(DecodeRows rows, int r1, 
     }
 }
 
+// The sampler's tables for (rates, n) in the context's device buffer; uploaded only when they change (a Monte-Carlo run asks
+// once per chunk).  The upload waits for the context's stream: a kernel in flight may still read the old tables.
+int gf2_seg_tables(gf2_ctx* ctx, double p_x, double p_y, double p_z, int64_t n, SegTables* out) {
+    GF2_TRY(check_probabilities(p_x, p_y, p_z));
+    const double p_t = p_x + p_y + p_z, p_xy = p_x + p_y;
+    const uint64_t t_any = gf2_quantise(p_t);
+    out->t_1 = p_t > 0.0 ? gf2_quantise(p_x / p_t) : 0;
+    out->t_2 = p_t > 0.0 ? gf2_quantise(p_xy / p_t) : 0;
+    out->nseg = (int)gf2_cdiv(n, GF2_SEG_BITS);
+    out->nb_last = n > 0 ? (int)(n - (int64_t)(out->nseg - 1) * GF2_SEG_BITS) : 0;
+    if (!ctx->seg_cdf_dev) {
+        GF2_HIP(hipMalloc((void**)&ctx->seg_cdf_dev, 2 * GF2_SEG_CDF * sizeof(uint64_t)));
+        ctx->seg_key_nb = -1;
+    }
+    if (ctx->seg_key_nb != out->nb_last || ctx->seg_key_t != t_any) {
+        std::vector<u64> host(2 * GF2_SEG_CDF);
+        binomial_cdf_table(t_any, GF2_SEG_BITS, host.data(), GF2_SEG_CDF);
+        binomial_cdf_table(t_any, out->nb_last, host.data() + GF2_SEG_CDF, GF2_SEG_CDF);
+        GF2_TRY(gf2_stream_wait(ctx->stream));
+        GF2_HIP(hipMemcpy(ctx->seg_cdf_dev, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice));
+        ctx->seg_key_nb = out->nb_last;
+        ctx->seg_key_t = t_any;
+    }
+    out->cdf = (const u64*)ctx->seg_cdf_dev;
+    return GF2_OK;
+}
+
 extern "C" {
 
 int gf2_sample_errors_dev(gf2_ctx* ctx, int64_t n, uint64_t seed, int64_t first_sample, int64_t count, double p_x,
@@ -227,26 +378,37 @@ int gf2_sample_errors_dev(gf2_ctx* ctx, int64_t n, uint64_t seed, int64_t first_
     if (layout == GF2_LAYOUT_TILED) lde = gf2_tiled_ld(n);
     if (n < 0 || count < 0 || first_sample < 0 || lde < gf2_words(n) || lde < 1)
         GF2_FAIL(GF2_E_ARG, "gf2_sample_errors_dev: bad shape");
-    SamplerTables th;
-    GF2_TRY(make_thresholds(p_x, p_y, p_z, n, &th));
+    GF2_TRY(check_probabilities(p_x, p_y, p_z));
     if (count == 0) return GF2_OK;
     if (!ex_dev || !ez_dev) GF2_FAIL(GF2_E_ARG, "gf2_sample_errors_dev: null buffer");
     GF2_TRY(gf2_ctx_activate(ctx));
-    const int64_t total = layout == GF2_LAYOUT_TILED ? gf2_tiled_words(n, count) : count * lde;
-    int64_t blocks = gf2_cdiv(total, 256);
+    if (n == 0) {
+        if (layout == GF2_LAYOUT_SAMPLE_MAJOR) {
+            GF2_TRY(gf2_dev_zero(ctx, ex_dev, (size_t)count * lde * 8));
+            GF2_TRY(gf2_dev_zero(ctx, ez_dev, (size_t)count * lde * 8));
+        }
+        return GF2_OK;
+    }
+    SegTables th;
+    GF2_TRY(gf2_seg_tables(ctx, p_x, p_y, p_z, n, &th));
+    const int64_t segs_row = layout == GF2_LAYOUT_TILED ? th.nseg : gf2_cdiv(lde, GF2_SEG_WORDS);
+    int64_t blocks = gf2_cdiv((layout == GF2_LAYOUT_TILED ? gf2_cdiv(count, 64) * 64 : count) * segs_row, GEN_THREADS);
     if (blocks > 16384) blocks = 16384;
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_SAMPLER));
     if (layout == GF2_LAYOUT_TILED)
-        hipLaunchKernelGGL(sampler_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (u64)seed, first_sample,
-                           count, n, gf2_words(n), lde, total, th, ex_dev, ez_dev);
+        hipLaunchKernelGGL(sampler_kernel<true>, dim3((unsigned)blocks), dim3(GEN_THREADS), 0, ctx->stream, (u64)seed, first_sample,
+                           count, n, gf2_words(n), lde, th, ex_dev, ez_dev);
     else if (lde <= 64 && gf2_words(n) >= 8 && !gf2_flag(ctx, GF2_F_SAMPLER_GENERIC)) {
-        int64_t rblocks = gf2_cdiv(gf2_cdiv(count, SMP_BLOCK), SMP_WAVES);
+        int nsp_log2 = 0;
+        while ((1 << nsp_log2) < th.nseg) nsp_log2 += 1;
+        const int per_block = 64 >> nsp_log2;
+        int64_t rblocks = gf2_cdiv(gf2_cdiv(count, per_block), SMP_WAVES);
         if (rblocks > (int64_t)ctx->num_cus * 8) rblocks = (int64_t)ctx->num_cus * 8;
         hipLaunchKernelGGL(sampler_rows_kernel, dim3((unsigned)rblocks), dim3(64 * SMP_WAVES), 0, ctx->stream, (u64)seed, first_sample,
-                           count, (int)gf2_words(n), lde, th, ex_dev, ez_dev);
+                           count, (int)gf2_words(n), lde, nsp_log2, th, ex_dev, ez_dev);
     } else
-        hipLaunchKernelGGL(sampler_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (u64)seed, first_sample,
-                           count, n, gf2_words(n), lde, total, th, ex_dev, ez_dev);
+        hipLaunchKernelGGL(sampler_kernel<false>, dim3((unsigned)blocks), dim3(GEN_THREADS), 0, ctx->stream, (u64)seed, first_sample,
+                           count, n, gf2_words(n), lde, th, ex_dev, ez_dev);
     GF2_TRY(gf2_prof_end(ctx));
     GF2_HIP(hipGetLastError());
     return GF2_OK;
@@ -303,12 +465,71 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
     // path below) -- 3.0e10 / 1.7e10 / 4.0e9 samples/s at n = 127 / 255 / 511 against 8.0e9 / 6.5e9 / 2.8e9 through the slab
     // pipelines and 2.8e9 / 2.3e9 / 2.0e9 with the sampler fused into the column-gather kernel
     const bool lanes = gf2_lane_ok(c1) && gf2_lane_ok(c2);
+    if (mode == GF2_HIST_WEIGHT && dens <= 36.0 && gf2_mc_records_ok(c1, c2) && !gf2_flag(ctx, GF2_F_MC_DENSE) &&
+        !gf2_flag(ctx, GF2_F_MC_UNFUSED) && !gf2_flag(ctx, GF2_F_MC_FUSED) && !gf2_flag(ctx, GF2_F_MC_ROWS) && count >= 65536 && !lanes) {
+        // No packed rows at all: the record sampler (gf2_slabs.hip) writes what the gather kernels read -- the records of the
+        // non-identity columns and the words under the identity block -- for chunk k + 1 on the context's stream while the
+        // gather, combine and misfit kernels of the two components work on chunk k on the two side streams (two buffer sets).
+        int64_t chunk_s = 1ll << (ctx->opt[GF2_OPT_MC_CHUNK_LOG2] >= 0 ? ctx->opt[GF2_OPT_MC_CHUNK_LOG2] : 21);
+        if (chunk_s > count) chunk_s = gf2_cdiv(count, 64) * 64;
+        SegTables th;
+        GF2_TRY(gf2_seg_tables(ctx, p_x, p_y, p_z, n, &th));
+        auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        const size_t set_bytes = al(gf2_mc_records_bytes(n, chunk_s)), hzb = (size_t)nbins_z * 8, hxb = (size_t)nbins_x * 8;
+        GF2_TRY(gf2_ws_reserve(ctx, 0, 2 * set_bytes + al(hzb) + al(hxb)));
+        GF2_TRY(gf2_slabs_reserve(ctx, c1, chunk_s, 2));
+        GF2_TRY(gf2_slabs_reserve(ctx, c2, chunk_s, 3));
+        char* q = (char*)ctx->ws[0];
+        void* set[2] = {q, q + set_bytes};
+        uint64_t* dz = (uint64_t*)(q + 2 * set_bytes);
+        uint64_t* dx = (uint64_t*)(q + 2 * set_bytes + al(hzb));
+        hipEvent_t* sampled = ctx->side_ev;            // [2]
+        hipEvent_t* done_z = ctx->side_ev + 2;         // [2]
+        hipEvent_t* done_x = ctx->side_ev + 4;         // [2]
+        GF2_TRY(gf2_dev_zero(ctx, dz, hzb));
+        GF2_TRY(gf2_dev_zero(ctx, dx, hxb));
+        int64_t k = 0;
+        auto enqueue_chunk = [&](int64_t done, int64_t now, int b) -> int {
+            if (k >= 2) {
+                GF2_HIP(hipStreamWaitEvent(ctx->stream, done_z[b], 0));
+                GF2_HIP(hipStreamWaitEvent(ctx->stream, done_x[b], 0));
+            }
+            GF2_TRY(gf2_prof_begin(ctx, GF2_K_SAMPLER));
+            GF2_TRY(gf2_mc_records_sample(ctx, c1, c2, seed, first_sample + done, now, chunk_s, th, set[b], ctx->stream));
+            GF2_TRY(gf2_prof_end(ctx));
+            GF2_HIP(hipEventRecord(sampled[b], ctx->stream));
+            GF2_HIP(hipStreamWaitEvent(ctx->side[0], sampled[b], 0));
+            GF2_HIP(hipStreamWaitEvent(ctx->side[1], sampled[b], 0));
+            GF2_TRY(gf2_mc_records_weigh(ctx, c1, 1, seed, first_sample + done, now, chunk_s, th, set[b], dz, ctx->side[0], 2));
+            GF2_TRY(gf2_mc_records_weigh(ctx, c2, 0, seed, first_sample + done, now, chunk_s, th, set[b], dx, ctx->side[1], 3));
+            GF2_HIP(hipEventRecord(done_z[b], ctx->side[0]));
+            GF2_HIP(hipEventRecord(done_x[b], ctx->side[1]));
+            return GF2_OK;
+        };
+        for (int64_t done = 0; done < count; done += chunk_s, ++k) {
+            const int64_t now = count - done < chunk_s ? count - done : chunk_s;
+            const int rc = enqueue_chunk(done, now, (int)(k & 1));
+            if (rc != GF2_OK) {
+                (void)hipStreamSynchronize(ctx->side[0]);
+                (void)hipStreamSynchronize(ctx->side[1]);
+                (void)hipStreamSynchronize(ctx->stream);
+                return rc;
+            }
+        }
+        for (int b = 0; b < 2 && b < k; ++b) {                     // join: the histograms are read on the context's stream
+            GF2_HIP(hipStreamWaitEvent(ctx->stream, done_z[b], 0));
+            GF2_HIP(hipStreamWaitEvent(ctx->stream, done_x[b], 0));
+        }
+        GF2_TRY(gf2_d2h(ctx, hist_z, dz, hzb));
+        GF2_TRY(gf2_d2h(ctx, hist_x, dx, hxb));
+        return GF2_OK;
+    }
     if (mode == GF2_HIST_WEIGHT && dens <= 160.0 && gf2_slabs_ok(c1) && gf2_slabs_ok(c2) && !gf2_flag(ctx, GF2_F_MC_DENSE) &&
         !gf2_flag(ctx, GF2_F_MC_UNFUSED) && !gf2_flag(ctx, GF2_F_MC_FUSED) && count >= 65536 && !lanes) {
         // Three streams: the sampler draws chunk k + 1 on the context's stream while the LDS-slab pipelines of the two
         // components work on chunk k on the two side streams (double-buffered errors; events carry the hand-overs).
         const int64_t lde_s = gf2_words(n);
-        const int64_t chunk_s = 1ll << 21;
+        const int64_t chunk_s = 1ll << (ctx->opt[GF2_OPT_MC_CHUNK_LOG2] >= 0 ? ctx->opt[GF2_OPT_MC_CHUNK_LOG2] : 21);
         auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t eb = (size_t)chunk_s * lde_s * 8, hzb = (size_t)nbins_z * 8, hxb = (size_t)nbins_x * 8;
         GF2_TRY(gf2_ws_reserve(ctx, 0, 4 * al(eb) + al(hzb) + al(hxb)));

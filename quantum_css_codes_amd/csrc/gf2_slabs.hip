@@ -26,6 +26,7 @@
 // columns.
 #include "gf2_internal.h"
 #include "gf2_sparse_dev.h"
+#include "gf2_sampler.h"
 
 #define CMP_WAVES 4
 #define CMP_THREADS (64 * CMP_WAVES)
@@ -377,6 +378,218 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void sl
         wave_lds_sync();
     }
     if (a.clk && lane == 0) atomicMax(&a.clk[1], (u64)wall_clock64());
+}
+
+// ---- records straight from the sampler (gf2_mc_run) ---------------------------------------------------------------------------
+//
+// The Monte-Carlo run draws its errors itself, and what the gather kernel wants of a sample is not its packed row but (1) the
+// record of its non-identity columns and (2) the words under the identity block.  This kernel makes exactly those from the
+// sampler's definition (gf2_sampler.h): no row is written to be read back and taken apart by the compact kernel (1 KiB written
+// and 0.5 KiB read per sample and two compact launches per pass less).
+// Wavefront = tile of 64 samples, lane = SAMPLE, for all its segments in turn: a lane takes the segment's draw and count, then
+// its erroneous qubits one after the other -- a mix64, Floyd's rule through one returning LDS atomic on a 512-bit map of its
+// own, and per component either a bit in the lane's image of the identity words or a 16-bit slot appended to its record (the
+// slot count is a register: nobody else writes this record).  The lanes of a wavefront do nearly the same amount of work (41 +- 6
+// erroneous qubits at n = 4096, p = 0.01), so there is no flat re-layout to pay for.  After each segment the identity words
+// leave as 64-byte pieces; after the last, the tile's records are sorted by count and stored as the compact kernel stores them.
+// A sample whose record overflows (or that misses the short half of its tile) goes on a list: slab_misfit_kernel draws it
+// again, as a packed row, and computes its weight with the wavefront-per-sample routine.
+struct RecSide {
+    u32x4* rec;                  // the tile records (TILE_REC_BYTES per tile)
+    u64* eident;                 // error rows of lde words of which only the words under the identity block are written
+    unsigned int* misfit_count;
+    unsigned int* misfit_list;   // sample index inside the pass
+    int ident_off, r, null_ord;
+    int seg_lo, seg_hi;          // segments whose words the gather kernel may read
+};
+struct RecSamplerArgs {
+    u64 seed;
+    int64_t first_sample, count, lde;
+    SegTables th;
+    RecSide side[2];             // [0]: X component (e_x, against H2), [1]: Z component (e_z, against H1)
+    int n;
+};
+#define RS_STRIDE 17             // dwords per lane of a 512-bit map: 16 + 1 (odd: the lanes' dwords spread over the banks)
+struct alignas(16) RecWaveLds {
+    unsigned char rec[2][4096 + 16];
+    unsigned int taken[64 * RS_STRIDE];
+    unsigned int img[64 * RS_STRIDE];     // identity words of the one component that has any in the current segment (gf2_mc_records_ok)
+    unsigned int bins[64];
+    unsigned short sink[64];              // where a lane's record store goes when there is nothing to store
+};
+
+__global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs a) {
+    __shared__ RecWaveLds L;
+    const int lane = threadIdx.x;
+    const int64_t ntiles = (a.count + 63) >> 6;
+    unsigned int* const my_taken = L.taken + lane * RS_STRIDE;
+#pragma unroll 1
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t i = tile * 64 + lane;
+        const bool live = i < a.count;
+        const u64 ks = sample_key(a.seed, (u64)(a.first_sample + i));
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const unsigned int null_ent = (unsigned int)a.side[c].null_ord << 4;
+            const unsigned int n2 = null_ent | (null_ent << 16);
+            const u32x4 null4 = {n2, n2, n2, n2};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) reinterpret_cast<u32x4*>(L.rec[c])[lane * 4 + q] = null4;
+        }
+        unsigned int cnt[2] = {0, 0};
+#pragma unroll 1
+        for (int s = 0; s < a.th.nseg; ++s) {
+            const bool last = s == a.th.nseg - 1;
+            const int nb = last ? a.th.nb_last : GF2_SEG_BITS;
+            const int base = s * GF2_SEG_BITS;
+            const bool flush0 = s >= a.side[0].seg_lo && s < a.side[0].seg_hi, flush1 = s >= a.side[1].seg_lo && s < a.side[1].seg_hi;
+#pragma unroll
+            for (int q = 0; q < RS_STRIDE; ++q) {
+                L.taken[q * 64 + lane] = 0;
+                if (flush0 || flush1) L.img[q * 64 + lane] = 0;               // uniform
+            }
+            u64 d = 0;
+            int K = 0;
+            if (live) {
+                d = segment_draw(ks, (u64)s);
+                const u64 u = d >> 32;
+                const u64* const tab = a.th.cdf + (last ? GF2_SEG_CDF : 0);
+#pragma unroll
+                for (int k = 0; k < 16; ++k) K += u >= tab[k] ? 1 : 0;         // uniform addresses: scalar loads
+                if (K == 16)
+                    while (K < nb && u >= tab[K]) K += 1;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // One erroneous qubit into the outputs, without a branch: an identity column is a bit in the image (an LDS OR of zero
+            // otherwise), any other column a 16-bit slot at the end of the lane's record (stored to the lane's sink otherwise).
+            auto emit = [&](bool on, unsigned int pos, unsigned int kind) {
+                const int col = base + (int)pos;
+                unsigned int id_bit = 0;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const RecSide& sd = a.side[c];
+                    const bool mine = on && ((kind >> c) & 1u);
+                    const bool is_id = (unsigned int)(col - sd.ident_off) < (unsigned int)sd.r;
+                    if (mine && is_id) id_bit = 1u << (pos & 31u);
+                    const bool is_rec = mine && !is_id;
+                    cnt[c] += is_rec ? 1u : 0u;
+                    const unsigned int ord = (unsigned int)(col < sd.ident_off ? col : col - sd.r) << 4;
+                    unsigned short* const at = (is_rec && cnt[c] < REC_SLOTS) ? reinterpret_cast<unsigned short*>(L.rec[c] + lane * 64 + cnt[c] * 2)
+                                                                              : &L.sink[lane];
+                    *at = (unsigned short)ord;
+                }
+                atomicOr(&L.img[lane * RS_STRIDE + (pos >> 5)], id_bit);
+            };
+            // two erroneous qubits per trip: their draws are independent chains of multiplies, and the second one's atomic is
+            // issued behind the first one's without waiting for it (the LDS serves a wavefront's operations in order)
+            for (int k = 0; __ballot(k < K) != 0; k += 2) {
+                const bool on0 = k < K, on1 = k + 1 < K;
+                unsigned int t0, kind0, t1, kind1;
+                error_draw(d, k, K, nb, a.th.t_1, a.th.t_2, &t0, &kind0);
+                error_draw(d, k + 1, K, nb, a.th.t_1, a.th.t_2, &t1, &kind1);
+                if (!on0) t0 = 0;
+                if (!on1) t1 = 0;
+                const unsigned int old0 = atomicOr(&my_taken[t0 >> 5], on0 ? 1u << (t0 & 31u) : 0u);
+                const unsigned int old1 = atomicOr(&my_taken[t1 >> 5], on1 ? 1u << (t1 & 31u) : 0u);
+                const unsigned int j0 = (unsigned int)(nb - K + k) & 511u, j1 = (j0 + 1u) & 511u;
+                // Floyd: a position taken already gives way to j (never taken before); the second qubit's candidate may be the
+                // j the first one has just moved to
+                const bool hit0 = on0 && ((old0 >> (t0 & 31u)) & 1u);
+                const bool hit1 = on1 && (((old1 >> (t1 & 31u)) & 1u) || (hit0 && t1 == j0));
+                const unsigned int pos0 = hit0 ? j0 : t0, pos1 = hit1 ? j1 : t1;
+                atomicOr(&my_taken[j0 >> 5], hit0 ? 1u << (j0 & 31u) : 0u);
+                atomicOr(&my_taken[j1 >> 5], hit1 ? 1u << (j1 & 31u) : 0u);
+                emit(on0, pos0, kind0);
+                emit(on1, pos1, kind1);
+            }
+            __builtin_amdgcn_wave_barrier();
+            // the segment's identity words out: four lanes per sample, 16 bytes each, sixteen samples per store instruction
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const RecSide& sd = a.side[c];
+                if (s < sd.seg_lo || s >= sd.seg_hi) continue;             // uniform
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int smp = it * 16 + (lane >> 2), dq = (lane & 3) * 4;
+                    const unsigned int* src = L.img + smp * RS_STRIDE + dq;
+                    const u32x4 v = {src[0], src[1], src[2], src[3]};
+                    const int64_t word = (int64_t)s * GF2_SEG_WORDS + (dq >> 1);
+                    if (tile * 64 + smp < a.count && word + 2 <= a.lde)
+                        *reinterpret_cast<u32x4*>(sd.eident + (tile * 64 + smp) * a.lde + word) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        // records out, per component, as the compact kernel leaves them: sorted by count, the 32 shortest as 32-byte records
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const RecSide& sd = a.side[c];
+            const unsigned int cc = cnt[c];
+            const bool over = cc >= REC_SLOTS;
+            const unsigned int key = over ? 0u : cc;
+            if (lane < 32) L.bins[lane] = 0;
+            wave_lds_sync();
+            const unsigned int in_bucket = atomicAdd(&L.bins[key], 1u);
+            wave_lds_sync();
+            {
+                unsigned int run = lane < 32 ? L.bins[lane] : 0u;
+#pragma unroll
+                for (int dd = 1; dd < 32; dd <<= 1) {
+                    const unsigned int up = __shfl_up(run, dd);
+                    if (lane >= dd) run += up;
+                }
+                if (lane < 32) L.bins[32 + lane] = run - L.bins[lane];
+            }
+            wave_lds_sync();
+            const unsigned int rank = L.bins[32 + key] + in_bucket;
+            wave_lds_sync();
+            const bool misfit = over || (rank < 32 && cc >= SHORT_SLOTS);
+            if (misfit && live) sd.misfit_list[atomicAdd(sd.misfit_count, 1u)] = (unsigned int)(tile * 64 + lane);
+            u32x4 R[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) R[q] = reinterpret_cast<const u32x4*>(L.rec[c])[lane * 4 + q];
+            R[0].x = (R[0].x & 0xFFFF0000u) | (over ? REC_OVER : (misfit ? REC_DONE | (SHORT_SLOTS - 1) : cc)) | ((unsigned int)lane << 8);
+            char* const tile_out = reinterpret_cast<char*>(sd.rec) + tile * TILE_REC_BYTES;
+            u32x4* const out = reinterpret_cast<u32x4*>(tile_out + (rank < 32 ? rank * 32u : 1024u + (rank - 32u) * 64u));
+            out[0] = R[0];
+            out[1] = R[1];
+            if (rank >= 32) {
+                out[2] = R[2];
+                out[3] = R[3];
+            }
+            wave_lds_sync();
+        }
+    }
+}
+
+// The listed samples once more, as packed rows of one component, and their weights by the wavefront-per-sample routine.
+#define MISFIT_WAVES 4
+__global__ __launch_bounds__(64 * MISFIT_WAVES) void slab_misfit_kernel(const unsigned int* __restrict__ count_ptr,
+                                                                       const unsigned int* __restrict__ list, u64 seed,
+                                                                       int64_t first_sample, SegTables th, SparseSide side, int comp,
+                                                                       int64_t n) {
+    __shared__ unsigned int img[MISFIT_WAVES][8 * 33];
+    __shared__ unsigned int cols[MISFIT_WAVES][SPARSE_LIST_CAP + 8];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned int total = *count_ptr;
+    const int words = (int)((n + 63) >> 6);
+    const bool last = lane == th.nseg - 1;
+    for (unsigned int e = blockIdx.x * MISFIT_WAVES + wave; e < total; e += gridDim.x * MISFIT_WAVES) {
+        const u64 sample = (u64)(first_sample + (int64_t)list[e]);
+        if (lane < th.nseg)
+            sample_segment(sample_key(seed, sample), lane, last ? th.nb_last : GF2_SEG_BITS, th.cdf + (last ? GF2_SEG_CDF : 0), th.t_1,
+                           th.t_2, img[wave] + lane * 33);
+        __builtin_amdgcn_wave_barrier();
+        u64 w = 0;
+        if (lane < words) {
+            const unsigned int* seg = img[wave] + (lane >> 3) * 33 + (comp ? 16 : 0) + (lane & 7) * 2;
+            w = ((u64)seg[1] << 32) | seg[0];
+        }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned int wt = sparse_component_weight(w, side, n, lane, cols[wave]);
+        if (lane == 0) atomicAdd(&side.hist[wt], 1ull);
+    }
 }
 
 // ---- gather ----------------------------------------------------------------------------------------------------------
@@ -1014,11 +1227,7 @@ static int64_t slab_pass(const gf2_ctx* ctx, int64_t batch) {
     return batch < cap ? batch : cap;
 }
 
-// Weight histogram of batch resident sample-major errors (hist: r + 1 bins, accumulated into).
-int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde,
-                       uint64_t* hist_dev, hipStream_t stream, int ws_slot) {
-    const int nbins = (int)ck->r + 1;
-    const size_t lds_bytes = (size_t)ck->slab_cols * 64;
+static int slab_lds_optin(gf2_ctx* ctx) {
     if (!ctx->lds_optin[2]) {
         GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
@@ -1028,6 +1237,66 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
         ctx->lds_optin[2] = true;
     }
+    return GF2_OK;
+}
+
+// gather -> combine (-> redo) of one pass: records, identity words (rows of lde words at e) and the workspace are in place.
+static int launch_gather_combine(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u32x4* rec, unsigned short* pw,
+                                 unsigned int* redo_count, unsigned int* redo_list, int64_t count, int64_t pad, int64_t lde,
+                                 bool fast, const StrayPlan& stray, uint64_t* hist_dev, hipStream_t stream, u64* clk_dev) {
+    const int nbins = (int)ck->r + 1;
+    const size_t lds_bytes = (size_t)ck->slab_cols * 64;
+    GatherArgs ga;
+    ga.tab = (const u32x4*)ck->slab_tab_dev;
+    ga.e = (const u64*)e;
+    ga.rec = rec;
+    ga.pw = pw;
+    ga.batch = count;
+    ga.batch_pad = pad;
+    ga.lde = lde;
+    ga.tab_stride = ck->slab_cols;
+    ga.nslabs = ck->nslabs512;
+    ga.r = (int)ck->r;
+    ga.ident_off = (int)ck->ident_off;
+    ga.null_ord = ck->slab_null;
+    ga.stray_n = stray.n_cols;
+    ga.stray_col[0] = stray.col[0];
+    ga.stray_col[1] = stray.col[1];
+    ga.clk = clk_dev;
+    ga.reverse = ctx->opt[GF2_OPT_GATHER_REVERSE] == 0 ? 0 : 1;
+    int64_t shares = ctx->num_cus / ck->nslabs512;
+    const int64_t max_shares = gf2_cdiv(gf2_cdiv(count, 16), GAT_WAVES);
+    if (shares > max_shares) shares = max_shares;
+    if (shares < 1) shares = 1;
+    const dim3 ggrid((unsigned)(shares * ck->nslabs512));
+    if (fast && (ck->ident_off & 31) != 0)
+        hipLaunchKernelGGL(slab_gather_fast_kernel<true>, ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+    else if (fast)
+        hipLaunchKernelGGL(slab_gather_fast_kernel<false>, ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+    else
+        hipLaunchKernelGGL(slab_gather_kernel, ggrid, dim3(GAT_THREADS), lds_bytes, stream, ga);
+    GF2_HIP(hipGetLastError());
+
+    // few large workgroups: every workgroup ends with one global atomic per non-empty bin
+    int64_t mblocks = gf2_cdiv(count, 4096);
+    const int64_t mb_cap = ctx->opt[GF2_OPT_COMBINE_BLOCKS] > 0 ? ctx->opt[GF2_OPT_COMBINE_BLOCKS] : 128;
+    if (mblocks > mb_cap) mblocks = mb_cap;
+    hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3(1024), 0, stream, pw, gf2_cdiv(count, 64) * 64, pad,
+                       ck->nslabs512, (u64*)hist_dev, nbins, redo_count, redo_list, clk_dev ? clk_dev + 4 : nullptr);
+    GF2_HIP(hipGetLastError());
+    if (stray.n_cols) {
+        hipLaunchKernelGGL(slab_redo_kernel, dim3((unsigned)(ctx->num_cus * (ctx->opt[GF2_OPT_REDO_BLOCKS_PER_CU] > 0 ? ctx->opt[GF2_OPT_REDO_BLOCKS_PER_CU] : 8))), dim3(256), 0, stream, (const u64*)e, count, lde,
+                           (const unsigned int*)redo_count, (const unsigned int*)redo_list, ck->ht_dev,
+                           (int)ck->r, (int)ck->n, (int)ck->ident_off, (u64*)hist_dev);
+        GF2_HIP(hipGetLastError());
+    }
+    return GF2_OK;
+}
+
+// Weight histogram of batch resident sample-major errors (hist: r + 1 bins, accumulated into).
+int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde,
+                       uint64_t* hist_dev, hipStream_t stream, int ws_slot) {
+    GF2_TRY(slab_lds_optin(ctx));
     const int64_t pass = slab_pass(ctx, batch);
     const int64_t pad = gf2_cdiv(pass, 64) * 64;
     const size_t rec_bytes = (size_t)pad * 64, pw_bytes = (size_t)ck->nslabs512 * pad * 2, redo_bytes = (size_t)pad * 4 + 256;
@@ -1085,50 +1354,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
         }
         GF2_HIP(hipGetLastError());
 
-        GatherArgs ga;
-        ga.tab = (const u32x4*)ck->slab_tab_dev;
-        ga.e = (const u64*)e;
-        ga.rec = rec;
-        ga.pw = pw;
-        ga.batch = count;
-        ga.batch_pad = pad;
-        ga.lde = lde;
-        ga.tab_stride = ck->slab_cols;
-        ga.nslabs = ck->nslabs512;
-        ga.r = (int)ck->r;
-        ga.ident_off = (int)ck->ident_off;
-        ga.null_ord = ck->slab_null;
-        ga.stray_n = stray.n_cols;
-        ga.stray_col[0] = stray.col[0];
-        ga.stray_col[1] = stray.col[1];
-        ga.clk = clk_dev;
-        ga.reverse = ctx->opt[GF2_OPT_GATHER_REVERSE] == 0 ? 0 : 1;
-        int64_t shares = ctx->num_cus / ck->nslabs512;
-        const int64_t max_shares = gf2_cdiv(gf2_cdiv(count, 16), GAT_WAVES);
-        if (shares > max_shares) shares = max_shares;
-        if (shares < 1) shares = 1;
-        const dim3 ggrid((unsigned)(shares * ck->nslabs512));
-        if (fast && (ck->ident_off & 31) != 0)
-            hipLaunchKernelGGL(slab_gather_fast_kernel<true>, ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
-        else if (fast)
-            hipLaunchKernelGGL(slab_gather_fast_kernel<false>, ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
-        else
-            hipLaunchKernelGGL(slab_gather_kernel, ggrid, dim3(GAT_THREADS), lds_bytes, stream, ga);
-        GF2_HIP(hipGetLastError());
-
-        // few large workgroups: every workgroup ends with one global atomic per non-empty bin
-        int64_t mblocks = gf2_cdiv(count, 4096);
-        const int64_t mb_cap = ctx->opt[GF2_OPT_COMBINE_BLOCKS] > 0 ? ctx->opt[GF2_OPT_COMBINE_BLOCKS] : 128;
-        if (mblocks > mb_cap) mblocks = mb_cap;
-        hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3(1024), 0, stream, pw, gf2_cdiv(count, 64) * 64, pad,
-                           ck->nslabs512, (u64*)hist_dev, nbins, redo_count, redo_list, clk_dev ? clk_dev + 4 : nullptr);
-        GF2_HIP(hipGetLastError());
-        if (stray.n_cols) {
-            hipLaunchKernelGGL(slab_redo_kernel, dim3((unsigned)(ctx->num_cus * (ctx->opt[GF2_OPT_REDO_BLOCKS_PER_CU] > 0 ? ctx->opt[GF2_OPT_REDO_BLOCKS_PER_CU] : 8))), dim3(256), 0, stream, (const u64*)e, count, lde,
-                               (const unsigned int*)redo_count, (const unsigned int*)redo_list, ck->ht_dev,
-                               (int)ck->r, (int)ck->n, (int)ck->ident_off, (u64*)hist_dev);
-            GF2_HIP(hipGetLastError());
-        }
+        GF2_TRY(launch_gather_combine(ctx, ck, e, rec, pw, redo_count, redo_list, count, pad, lde, fast, stray, hist_dev, stream, clk_dev));
         if (clk_dev) {
             u64 c[6];
             GF2_HIP(hipStreamSynchronize(stream));
@@ -1149,4 +1375,102 @@ int gf2_slabs_reserve(gf2_ctx* ctx, const gf2_check* ck, int64_t batch, int ws_s
     const int64_t pass = slab_pass(ctx, batch);
     const int64_t pad = gf2_cdiv(pass, 64) * 64;
     return gf2_ws_reserve(ctx, ws_slot, (size_t)pad * 64 + (size_t)ck->nslabs512 * pad * 2 + (size_t)pad * 4 + 256);
+}
+
+// ---- the Monte-Carlo run's own way in: records from the sampler ---------------------------------------------------------------
+
+// Both checks have row slabs, an identity block and at most 4096 columns; the caller looks at the error rate.
+static void identity_segments(const gf2_check* ck, int nseg, int* lo, int* hi) {
+    // the dwords the gather kernel loads: 16 per slab from the identity block's first, one more when the block is not dword-aligned
+    const int64_t first_dw = ck->ident_off >> 5;
+    const int64_t last_dw = first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) + ((ck->ident_off & 31) ? 4 : 0);
+    *lo = (int)(first_dw / 16);
+    *hi = (int)gf2_cdiv(last_dw, 16);
+    if (*hi > nseg) *hi = nseg;
+}
+
+// ... and no segment of 512 columns holds identity words of both (the record sampler keeps one image of identity words per
+// segment): true of a CSS code's standard forms H1 = [I | A], H2 = [A' | I | c] with r1 a multiple of 512.
+bool gf2_mc_records_ok(const gf2_check* c1, const gf2_check* c2) {
+    if (!(gf2_slabs_ok(c1) && gf2_slabs_ok(c2) && c1->ident_off >= 0 && c2->ident_off >= 0 && c1->n == c2->n && c1->n <= 4096 &&
+          c1->n >= 64))
+        return false;
+    const int nseg = (int)gf2_cdiv(c1->n, GF2_SEG_BITS);
+    int lo1, hi1, lo2, hi2;
+    identity_segments(c1, nseg, &lo1, &hi1);
+    identity_segments(c2, nseg, &lo2, &hi2);
+    return hi1 <= lo2 || hi2 <= lo1;
+}
+
+// Bytes of one buffer set for `pass` samples: per component the identity rows, the records and the misfit list.
+size_t gf2_mc_records_bytes(int64_t n, int64_t pass) {
+    const size_t pad = (size_t)gf2_cdiv(pass, 64) * 64;
+    const size_t row = (size_t)pad * gf2_words(n) * 8, rec = pad / 64 * TILE_REC_BYTES, mis = 256 + pad * 4;
+    return 2 * (row + ((rec + 255) & ~(size_t)255) + mis);
+}
+
+// Draws samples first_sample .. + count (count <= the pass the buffers were sized for) into `buf`: records, identity words and
+// misfit lists of both components, on `stream`.
+int gf2_mc_records_sample(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t seed, int64_t first_sample, int64_t count,
+                          int64_t pass, const SegTables& th, void* buf, hipStream_t stream) {
+    const int64_t n = c1->n, lde = gf2_words(n);
+    const size_t pad = (size_t)gf2_cdiv(pass, 64) * 64;
+    const size_t row = (size_t)pad * lde * 8, rec = ((pad / 64 * TILE_REC_BYTES) + 255) & ~(size_t)255, mis = 256 + pad * 4;
+    RecSamplerArgs a;
+    a.seed = seed;
+    a.first_sample = first_sample;
+    a.count = count;
+    a.lde = lde;
+    a.th = th;
+    a.n = (int)n;
+    char* q = (char*)buf;
+    for (int c = 0; c < 2; ++c) {
+        const gf2_check* ck = c == 0 ? c2 : c1;                      // X errors against H2, Z errors against H1 (css_code.py:457-470)
+        RecSide& sd = a.side[c];
+        sd.eident = (u64*)q; q += row;
+        sd.rec = (u32x4*)q; q += rec;
+        sd.misfit_count = (unsigned int*)q;
+        sd.misfit_list = (unsigned int*)q + 64;
+        q += mis;
+        sd.ident_off = (int)ck->ident_off;
+        sd.r = (int)ck->r;
+        sd.null_ord = ck->slab_null;
+        identity_segments(ck, th.nseg, &sd.seg_lo, &sd.seg_hi);
+        GF2_HIP(hipMemsetAsync(sd.misfit_count, 0, 256, stream));
+    }
+    int64_t blocks = gf2_cdiv(count, 64);
+    if (blocks > (int64_t)ctx->num_cus * 9) blocks = (int64_t)ctx->num_cus * 9;
+    hipLaunchKernelGGL(slab_record_sampler_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, a);
+    GF2_HIP(hipGetLastError());
+    return GF2_OK;
+}
+
+// gather -> combine -> misfits of component `comp` (0: X against c2 = ck, 1: Z against c1 = ck) of a buffer set, on `stream`;
+// partial weights in workspace `ws_slot`.
+int gf2_mc_records_weigh(gf2_ctx* ctx, const gf2_check* ck, int comp, uint64_t seed, int64_t first_sample, int64_t count, int64_t pass,
+                         const SegTables& th, void* buf, uint64_t* hist_dev, hipStream_t stream, int ws_slot) {
+    GF2_TRY(slab_lds_optin(ctx));
+    const int64_t n = ck->n, lde = gf2_words(n);
+    const size_t pad = (size_t)gf2_cdiv(pass, 64) * 64;
+    const size_t row = (size_t)pad * lde * 8, rec_b = ((pad / 64 * TILE_REC_BYTES) + 255) & ~(size_t)255, mis = 256 + pad * 4;
+    char* q = (char*)buf + (size_t)comp * (row + rec_b + mis);
+    const uint64_t* eident = (const uint64_t*)q;
+    u32x4* rec = (u32x4*)(q + row);
+    unsigned int* misfit_count = (unsigned int*)(q + row + rec_b);
+    const size_t pw_bytes = (size_t)ck->nslabs512 * pad * 2, redo_bytes = (size_t)pad * 4 + 256;
+    GF2_TRY(gf2_ws_reserve(ctx, ws_slot, (size_t)pad * 64 + pw_bytes + redo_bytes));
+    unsigned short* pw = (unsigned short*)((char*)ctx->ws[ws_slot] + (size_t)pad * 64);
+    unsigned int* redo_count = (unsigned int*)((char*)ctx->ws[ws_slot] + (size_t)pad * 64 + pw_bytes);
+    const int64_t first_dw = ck->ident_off >> 5;
+    const bool fast = (lde & 1) == 0 && (first_dw & 3) == 0 && first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) <= lde * 2 &&
+                      !gf2_flag(ctx, GF2_F_GATHER_GENERIC);
+    const StrayPlan none = {0, 0, {0, 0}};
+    GF2_HIP(hipMemsetAsync(redo_count, 0, 4, stream));              // (the combine kernel reads it; compact, which zeroes it, does not run)
+    GF2_TRY(launch_gather_combine(ctx, ck, eident, rec, pw, redo_count, redo_count + 64, count, (int64_t)pad, lde, fast, none, hist_dev,
+                                  stream, nullptr));
+    const SparseSide side = {ck->ht_dev, ck->r, ck->ident_off, (u64*)hist_dev, (int)(ck->r + 1)};
+    hipLaunchKernelGGL(slab_misfit_kernel, dim3(64), dim3(64 * MISFIT_WAVES), 0, stream, (const unsigned int*)misfit_count,
+                       (const unsigned int*)(misfit_count + 64), (u64)seed, first_sample, th, side, comp, n);
+    GF2_HIP(hipGetLastError());
+    return GF2_OK;
 }

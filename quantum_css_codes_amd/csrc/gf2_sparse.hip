@@ -206,31 +206,40 @@ __global__ __launch_bounds__(64 * SPARSE_WAVES) void syndrome_sparse_kernel(
 
 // ---- fused Monte-Carlo: sampler + both syndromes + both weight histograms, no error words in memory -------------------
 //
-// n <= 4096 and r_1, r_2 <= 2048: a wavefront owns a sample, lane = 64-qubit word = syndrome dword.  The lane draws
-// its own error words (e_x, e_z) with sample_word, then runs the sparse column accumulation once per component
+// n <= 4096 and r_1, r_2 <= 2048: a wavefront owns a sample, lane = 64-qubit word = syndrome dword.  The first lanes run
+// the sample's (at most 8) segments into an LDS image, every lane picks up its words (e_x, e_z) from there, then the sparse
+// column accumulation runs once per component
 // (e_z against H1, e_x against H2, css_code.py:457-470).  The identity-block bits, which the stand-alone kernel
 // re-reads from memory, come from the neighbouring lanes' registers here.
 __global__ __launch_bounds__(64 * SPARSE_WAVES) void mc_sparse_fused_kernel(SparseSide side_z, SparseSide side_x, int64_t n,
                                                                            u64 seed, int64_t first_sample, int64_t count,
-                                                                           SamplerTables th) {
+                                                                           SegTables th) {
     __shared__ unsigned int list[SPARSE_WAVES][SPARSE_LIST_CAP + 8];
     __shared__ unsigned int bins_z[2052], bins_x[2052];
-    __shared__ u64 cdf_lds[130];
+    __shared__ u64 cdf_lds[2 * GF2_SEG_CDF];
+    __shared__ unsigned int img[SPARSE_WAVES][8 * 33];                   // per segment 32 dwords (x: 0..15, z: 16..31) + 1 of padding
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int i = threadIdx.x; i < 2052; i += blockDim.x) {
         bins_z[i] = 0;
         bins_x[i] = 0;
     }
-    stage_cdf(th, cdf_lds);
+    stage_seg_cdf(th, cdf_lds);
     const int words = (int)((n + 63) >> 6);
-    const bool last = lane == words - 1;
+    const bool last = lane == th.nseg - 1;
     const int64_t total_waves = (int64_t)gridDim.x * SPARSE_WAVES;
     for (int64_t i = (int64_t)blockIdx.x * SPARSE_WAVES + wave; i < count; i += total_waves) {
         u64 ex = 0, ez = 0;
-        if (lane < words)
-            sample_word(seed, (u64)(first_sample + i), (u64)lane, last ? th.nb_last : 64, cdf_lds + (last ? 65 : 0), th.t_1,
-                        th.t_2, &ex, &ez);
+        if (lane < th.nseg)
+            sample_segment(sample_key(seed, (u64)(first_sample + i)), lane, last ? th.nb_last : GF2_SEG_BITS,
+                           cdf_lds + (last ? GF2_SEG_CDF : 0), th.t_1, th.t_2, img[wave] + lane * 33);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < words) {
+            const unsigned int* seg = img[wave] + (lane >> 3) * 33 + (lane & 7) * 2;
+            ex = ((u64)seg[1] << 32) | seg[0];
+            ez = ((u64)seg[17] << 32) | seg[16];
+        }
+        __builtin_amdgcn_wave_barrier();
         const unsigned int wz = sparse_component_weight(ez, side_z, n, lane, list[wave]);
         const unsigned int wx = sparse_component_weight(ex, side_x, n, lane, list[wave]);
         if (lane == 0) {
@@ -292,8 +301,8 @@ static void launch_sparse(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_d
 // Fused sparse Monte-Carlo (internal; gf2_mc_run uses it).  hist buffers must be zeroed by the caller.
 int gf2_mc_sparse_fused(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t seed, int64_t first_sample,
                         int64_t count, double p_x, double p_y, double p_z, uint64_t* hz_dev, uint64_t* hx_dev) {
-    SamplerTables th;
-    GF2_TRY(make_thresholds(p_x, p_y, p_z, c1->n, &th));
+    SegTables th;
+    GF2_TRY(gf2_seg_tables(ctx, p_x, p_y, p_z, c1->n, &th));
     if (count == 0) return GF2_OK;
     SparseSide sz = {c1->ht_dev, c1->r, c1->ident_off, (u64*)hz_dev, (int)(c1->r + 1)};
     SparseSide sx = {c2->ht_dev, c2->r, c2->ident_off, (u64*)hx_dev, (int)(c2->r + 1)};

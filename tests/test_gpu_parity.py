@@ -561,12 +561,22 @@ def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, route):
     want = c_oracle.mc(h1, 2048, h2, 2047, 4096, 0xABC, 5 * 10**6, 20000, 0.004, 0.003, 0.002, 1)
     for got in (fused, sparse, dense):
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
-    # large counts: the sampler of chunk k + 1 overlaps the two components' slab pipelines of chunk k on three streams
-    # (two and a bit chunks of 2^20, so the double buffers are reused); same histograms as the fused kernel and, on its
-    # own pace, the serial sampler -> pipeline -> pipeline path; twice, to see that nothing is left behind on a stream
+    # large counts: the record sampler of chunk k + 1 (records and identity words, no packed rows) overlaps the two
+    # components' gather / combine / misfit kernels of chunk k on three streams (a chunk and a bit, and with chunks of 2^19
+    # four and a bit, so the two buffer sets are reused); same histograms as the fused kernel, as the packed-row sampler
+    # with the compact kernels on three streams (GF2_MC_ROWS) and, on its own pace, the serial sampler -> pipeline -> pipeline
+    # path; twice, to see that nothing is left behind on a stream
     big = (0xABC, 123, (1 << 21) + 77777, 0.004, 0.003, 0.002, _native.HIST_WEIGHT)
     piped = ctx.mc_run(c1, c2, *big)
     piped_again = ctx.mc_run(c1, c2, *big)
+    ctx.set_option(_native.OPT_MC_CHUNK_LOG2, 19)
+    piped_small_chunks = ctx.mc_run(c1, c2, *big)
+    ctx.set_option(_native.OPT_MC_CHUNK_LOG2, None)
+    assert np.array_equal(piped_small_chunks[0], piped[0]) and np.array_equal(piped_small_chunks[1], piped[1])
+    route.force("GF2_MC_ROWS")
+    rows_big = ctx.mc_run(c1, c2, *big)
+    route.release("GF2_MC_ROWS")
+    assert np.array_equal(rows_big[0], piped[0]) and np.array_equal(rows_big[1], piped[1])
     route.force("GF2_MC_FUSED")
     fused_big = ctx.mc_run(c1, c2, *big)
     route.release("GF2_MC_FUSED")
@@ -576,6 +586,15 @@ def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, route):
     assert int(piped[0].sum()) == big[2] and int(piped[1].sum()) == big[2]
     for got in (piped_again, fused_big, serial_big):
         assert np.array_equal(got[0], piped[0]) and np.array_equal(got[1], piped[1])
+    # a rate at which most tiles have samples that do not fit their records (17 columns per sample on average): the misfit
+    # kernel draws those again; and a ragged last tile
+    hot = (0x5EED, 99, 70001, 0.005, 0.0035, 0.002, _native.HIST_WEIGHT)
+    hot_records = ctx.mc_run(c1, c2, *hot)
+    route.force("GF2_MC_FUSED")
+    hot_fused = ctx.mc_run(c1, c2, *hot)
+    route.release("GF2_MC_FUSED")
+    assert int(hot_records[0].sum()) == hot[2] and int(hot_records[1].sum()) == hot[2]
+    assert np.array_equal(hot_records[0], hot_fused[0]) and np.array_equal(hot_records[1], hot_fused[1])
 
 
 @pytest.mark.parametrize("case", [(127, 63, 64), (255, 127, 127), (511, 255, 250), (300, 100, 150)])

@@ -255,12 +255,12 @@ def test_c_oracle_nullspace(golden, steane_h):
         assert np.array_equal(c_oracle.unpack_rows(got, n), ref.nullspace(mat))
 
 
-@pytest.mark.parametrize("n", [7, 15, 64, 70, 130, 200])
+@pytest.mark.parametrize("n", [7, 15, 64, 70, 130, 200, 512, 513, 1030])
 def test_c_oracle_sampler(n):
-    # three statements of one definition (DESIGN.md "Sampler"); this pins the C one to the NumPy one, ragged last words included
+    # three statements of one definition (DESIGN.md "Sampler"); this pins the C one to the NumPy one, ragged last segments included
     from oracle import c_oracle
     for (p, seed, first, count) in (((0.05, 0.02, 0.1), 123, 1000, 40), ((0.004, 0.003, 0.003), 9, 0, 60),
-                                    ((0.3, 0.3, 0.4), 77, 5, 8), ((0.0, 0.0, 0.0), 1, 0, 3)):
+                                    ((0.3, 0.3, 0.4), 77, 5, 8), ((0.0, 0.0, 0.0), 1, 0, 3), ((0.5, 0.1, 0.2), 4, 9, 6)):
         ex, ez = c_oracle.sample_errors(n, seed, first, count, *p)
         for i in range(count):
             want_x, want_z = ref.sample_pauli_error(seed, first + i, n, *p)
@@ -345,7 +345,8 @@ def test_sampler_count_table_tail():
     # the inverse-CDF table is non-decreasing, ends at 2^32 and no draw (u <= 2^32 - 1) can yield more errors than the
     # binomial's own 2^-32 quantile: a sum that ends an ulp short of 1.0 must not leave 2^32 - 1 in the tail
     from math import comb
-    for p_t, nb in ((0.012, 64), (0.01, 33), (0.01, 64), (0.3, 64), (1e-6, 64), (0.5, 7), (0.999, 64)):
+    for p_t, nb in ((0.012, 64), (0.01, 33), (0.01, 64), (0.3, 64), (1e-6, 64), (0.5, 7), (0.999, 64), (0.01, 512), (0.3, 512),
+                    (0.5, 512), (0.7, 512), (0.999, 300), (1e-6, 512)):
         t_any = ref.quantise_probability(p_t)
         cdf = ref.binomial_cdf_table(t_any, nb)
         q = t_any / 2.0**32
@@ -362,6 +363,12 @@ def test_sampler_count_table_tail():
 
 def test_sampler_rates():
     n, count = 64 * 4, 300
+    # every qubit of every segment errs at rate 1, whatever the segment's length
+    ex, ez = ref.sample_pauli_error(3, 0, 1100, 0.25, 0.5, 0.25)
+    assert (ex | ez).all()
+    # segments of 512 at a rate beyond 1/2 (complementary table): the count still follows the rate
+    tot = sum(int(np.sum(ref.sample_pauli_error(5, i, 1024, 0.7, 0.0, 0.0)[0])) for i in range(40))
+    assert abs(tot / (40 * 1024) - 0.7) < 0.02
     tot = np.zeros(3)
     for i in range(count):
         ex, ez = ref.sample_pauli_error(99, i, n, 0.10, 0.05, 0.20)
