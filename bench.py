@@ -549,10 +549,14 @@ def main():
             # end to end: nothing resident, gf2_mc_run draws the errors itself (sampler || slab pipelines, three streams); its
             # histogram over this rank's batch must be the timed path's
             mc_count = max(batch, 1 << 24)
-            ctx.mc_run(chk1, chk2, SEED, 0, 1 << 20, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)
-            t_mc = time.perf_counter()
-            mc_z, _ = ctx.mc_run(chk1, chk2, SEED, first, mc_count, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)
-            t_mc = time.perf_counter() - t_mc
+            # (the first call of this size allocates the context's workspaces: untimed)
+            ctx.mc_run(chk1, chk2, SEED, 0, mc_count, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)
+            t_mc = None
+            for _ in range(2):
+                t0 = time.perf_counter()
+                mc_z, _ = ctx.mc_run(chk1, chk2, SEED, first, mc_count, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)
+                t1 = time.perf_counter() - t0
+                t_mc = t1 if t_mc is None else min(t_mc, t1)
             assert int(mc_z.sum()) == mc_count
             if mc_count == batch:
                 assert np.array_equal(mc_z, single_z), "end-to-end Monte-Carlo and the resident-error path disagree"
@@ -607,8 +611,9 @@ def main():
             assert np.array_equal(other_z, sec_z * np.uint64(10)), "the two syndrome kernels disagree"
             out["secondary"] = {
                 "monte_carlo_end_to_end": {"value": mc_count / t_mc, "unit": "syndromes/s",
-                                           "what": "gf2_mc_run: sampler of chunk k+1 overlapping the two slab pipelines of chunk k on three streams, no resident input, "
-                                                   "host wall time incl. histogram download, %d samples" % mc_count},
+                                           "what": "gf2_mc_run: the record sampler of chunk k+1 (records and identity words, no packed rows) beside the gather / "
+                                                   "combine / misfit kernels of chunk k on three streams, no resident input, host wall time incl. "
+                                                   "histogram download, %d samples, best of two calls after one untimed call" % mc_count},
                 other.algo + "_kernel": {"value": 10 * sec / (o_ms / 1e3), "unit": "syndromes/s", "ms_per_step": o_ms / 10,
                                          "roofline": roofline(other, o_launch, o_n), "histogram_ms_per_step": o_hist / 10},
                 "rref": rref_numbers(ctx)}

@@ -91,7 +91,7 @@ int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
 #define GF2_OPT_COMBINE_BLOCKS  1   /* slab pipeline: workgroups of the combine kernel (default 128)                      */
 #define GF2_OPT_GATHER_REVERSE   2   /* slab pipeline: 1 (default) = the gather kernel walks the records last tile first  */
 #define GF2_OPT_REDO_BLOCKS_PER_CU 3 /* slab pipeline: workgroups per CU of the redo kernel (default 8)                       */
-#define GF2_OPT_MC_CHUNK_LOG2   4   /* gf2_mc_run, three-stream pipeline: 2^k samples per chunk, 16 <= k <= 22 (default 21)       */
+#define GF2_OPT_MC_CHUNK_LOG2   4   /* gf2_mc_run at n <= 4096, sparse rates: 2^k samples per chunk, 16 <= k <= 22 (default 22; 21 with GF2_F_MC_ROWS) */
 #define GF2_OPT_COUNT           5
 int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value);
 

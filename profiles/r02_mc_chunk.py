@@ -21,7 +21,7 @@ ctx = _native.default_context()
 c1 = ctx.check_create(_native.pack_rows(hm1), 2048, 4096)
 c2 = ctx.check_create(_native.pack_rows(hm2), 2047, 4096)
 ref = None
-for k in (21, 20, 19, 18, 17, 16, 22):
+for k in (21, 20, 19, 18, 22):
     ctx.set_option(_native.OPT_MC_CHUNK_LOG2, k)
     ctx.mc_run(c1, c2, 1, 0, 1 << 22, p, p, p, _native.HIST_WEIGHT)
     best = None

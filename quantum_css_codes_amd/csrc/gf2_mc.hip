@@ -468,57 +468,31 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
     if (mode == GF2_HIST_WEIGHT && dens <= 36.0 && gf2_mc_records_ok(c1, c2) && !gf2_flag(ctx, GF2_F_MC_DENSE) &&
         !gf2_flag(ctx, GF2_F_MC_UNFUSED) && !gf2_flag(ctx, GF2_F_MC_FUSED) && !gf2_flag(ctx, GF2_F_MC_ROWS) && count >= 65536 && !lanes) {
         // No packed rows at all: the record sampler (gf2_slabs.hip) writes what the gather kernels read -- the records of the
-        // non-identity columns and the words under the identity block -- for chunk k + 1 on the context's stream while the
-        // gather, combine and misfit kernels of the two components work on chunk k on the two side streams (two buffer sets).
-        int64_t chunk_s = 1ll << (ctx->opt[GF2_OPT_MC_CHUNK_LOG2] >= 0 ? ctx->opt[GF2_OPT_MC_CHUNK_LOG2] : 21);
+        // non-identity columns and the words under the identity block -- and the gather, combine and misfit kernels of the two
+        // components follow, chunk by chunk on the context's stream.  (Measured with the sampler of chunk k + 1 on this stream and
+        // the two components of chunk k on the side streams, two buffer sets: 1.68e9 samples/s against 1.81e9 in line -- a gather
+        // workgroup needs a CU's LDS to itself and waits for the sampler's workgroups to drain wherever it lands, and all three
+        // kernels are bound by instruction issue, so there is nothing for them to share.)
+        // (chunks of 2^22 samples: 2.05e9 samples/s; 2^21: 1.97e9; 2^20: 1.83e9; 2^18: 1.57e9 -- profiles/r02_mc_chunk.log)
+        int64_t chunk_s = 1ll << (ctx->opt[GF2_OPT_MC_CHUNK_LOG2] >= 0 ? ctx->opt[GF2_OPT_MC_CHUNK_LOG2] : 22);
         if (chunk_s > count) chunk_s = gf2_cdiv(count, 64) * 64;
         SegTables th;
         GF2_TRY(gf2_seg_tables(ctx, p_x, p_y, p_z, n, &th));
         auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
         const size_t set_bytes = al(gf2_mc_records_bytes(n, chunk_s)), hzb = (size_t)nbins_z * 8, hxb = (size_t)nbins_x * 8;
-        GF2_TRY(gf2_ws_reserve(ctx, 0, 2 * set_bytes + al(hzb) + al(hxb)));
-        GF2_TRY(gf2_slabs_reserve(ctx, c1, chunk_s, 2));
-        GF2_TRY(gf2_slabs_reserve(ctx, c2, chunk_s, 3));
+        GF2_TRY(gf2_ws_reserve(ctx, 0, set_bytes + al(hzb) + al(hxb)));
         char* q = (char*)ctx->ws[0];
-        void* set[2] = {q, q + set_bytes};
-        uint64_t* dz = (uint64_t*)(q + 2 * set_bytes);
-        uint64_t* dx = (uint64_t*)(q + 2 * set_bytes + al(hzb));
-        hipEvent_t* sampled = ctx->side_ev;            // [2]
-        hipEvent_t* done_z = ctx->side_ev + 2;         // [2]
-        hipEvent_t* done_x = ctx->side_ev + 4;         // [2]
+        uint64_t* dz = (uint64_t*)(q + set_bytes);
+        uint64_t* dx = (uint64_t*)(q + set_bytes + al(hzb));
         GF2_TRY(gf2_dev_zero(ctx, dz, hzb));
         GF2_TRY(gf2_dev_zero(ctx, dx, hxb));
-        int64_t k = 0;
-        auto enqueue_chunk = [&](int64_t done, int64_t now, int b) -> int {
-            if (k >= 2) {
-                GF2_HIP(hipStreamWaitEvent(ctx->stream, done_z[b], 0));
-                GF2_HIP(hipStreamWaitEvent(ctx->stream, done_x[b], 0));
-            }
-            GF2_TRY(gf2_prof_begin(ctx, GF2_K_SAMPLER));
-            GF2_TRY(gf2_mc_records_sample(ctx, c1, c2, seed, first_sample + done, now, chunk_s, th, set[b], ctx->stream));
-            GF2_TRY(gf2_prof_end(ctx));
-            GF2_HIP(hipEventRecord(sampled[b], ctx->stream));
-            GF2_HIP(hipStreamWaitEvent(ctx->side[0], sampled[b], 0));
-            GF2_HIP(hipStreamWaitEvent(ctx->side[1], sampled[b], 0));
-            GF2_TRY(gf2_mc_records_weigh(ctx, c1, 1, seed, first_sample + done, now, chunk_s, th, set[b], dz, ctx->side[0], 2));
-            GF2_TRY(gf2_mc_records_weigh(ctx, c2, 0, seed, first_sample + done, now, chunk_s, th, set[b], dx, ctx->side[1], 3));
-            GF2_HIP(hipEventRecord(done_z[b], ctx->side[0]));
-            GF2_HIP(hipEventRecord(done_x[b], ctx->side[1]));
-            return GF2_OK;
-        };
-        for (int64_t done = 0; done < count; done += chunk_s, ++k) {
+        for (int64_t done = 0; done < count; done += chunk_s) {
             const int64_t now = count - done < chunk_s ? count - done : chunk_s;
-            const int rc = enqueue_chunk(done, now, (int)(k & 1));
-            if (rc != GF2_OK) {
-                (void)hipStreamSynchronize(ctx->side[0]);
-                (void)hipStreamSynchronize(ctx->side[1]);
-                (void)hipStreamSynchronize(ctx->stream);
-                return rc;
-            }
-        }
-        for (int b = 0; b < 2 && b < k; ++b) {                     // join: the histograms are read on the context's stream
-            GF2_HIP(hipStreamWaitEvent(ctx->stream, done_z[b], 0));
-            GF2_HIP(hipStreamWaitEvent(ctx->stream, done_x[b], 0));
+            GF2_TRY(gf2_prof_begin(ctx, GF2_K_SAMPLER));
+            GF2_TRY(gf2_mc_records_sample(ctx, c1, c2, seed, first_sample + done, now, chunk_s, th, q, ctx->stream));
+            GF2_TRY(gf2_prof_end(ctx));
+            GF2_TRY(gf2_mc_records_weigh(ctx, c1, 1, seed, first_sample + done, now, chunk_s, th, q, dz, ctx->stream, 2));
+            GF2_TRY(gf2_mc_records_weigh(ctx, c2, 0, seed, first_sample + done, now, chunk_s, th, q, dx, ctx->stream, 3));
         }
         GF2_TRY(gf2_d2h(ctx, hist_z, dz, hzb));
         GF2_TRY(gf2_d2h(ctx, hist_x, dx, hxb));

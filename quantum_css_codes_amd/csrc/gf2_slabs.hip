@@ -460,25 +460,41 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
                     while (K < nb && u >= tab[K]) K += 1;
             }
             __builtin_amdgcn_wave_barrier();
-            // One erroneous qubit into the outputs, without a branch: an identity column is a bit in the image (an LDS OR of zero
-            // otherwise), any other column a 16-bit slot at the end of the lane's record (stored to the lane's sink otherwise).
+            // What this segment holds of each component's check (uniform): columns under the identity block (lo <= position < lo + r,
+            // bits of the identity image) and / or other columns (slots of the record).  In a CSS code's standard forms a segment is
+            // one or the other, except the last one of H2 = [A' | I | c].
+            int lo[2];
+            bool has_id[2], has_rec[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                lo[c] = a.side[c].ident_off - base;
+                has_id[c] = lo[c] < nb && lo[c] + a.side[c].r > 0;
+                has_rec[c] = lo[c] > 0 || lo[c] + a.side[c].r < nb;
+            }
+            // One erroneous qubit into the outputs, without a divergent branch: an identity column is a bit in the image (an LDS
+            // OR of zero otherwise), any other column a 16-bit slot at the end of the lane's record (stored to the lane's sink
+            // otherwise).
             auto emit = [&](bool on, unsigned int pos, unsigned int kind) {
-                const int col = base + (int)pos;
                 unsigned int id_bit = 0;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const RecSide& sd = a.side[c];
                     const bool mine = on && ((kind >> c) & 1u);
-                    const bool is_id = (unsigned int)(col - sd.ident_off) < (unsigned int)sd.r;
-                    if (mine && is_id) id_bit = 1u << (pos & 31u);
-                    const bool is_rec = mine && !is_id;
-                    cnt[c] += is_rec ? 1u : 0u;
-                    const unsigned int ord = (unsigned int)(col < sd.ident_off ? col : col - sd.r) << 4;
-                    unsigned short* const at = (is_rec && cnt[c] < REC_SLOTS) ? reinterpret_cast<unsigned short*>(L.rec[c] + lane * 64 + cnt[c] * 2)
-                                                                              : &L.sink[lane];
-                    *at = (unsigned short)ord;
+                    const bool under = (unsigned int)((int)pos - lo[c]) < (unsigned int)sd.r;
+                    if (has_id[c]) {                                           // uniform
+                        if (mine && (!has_rec[c] || under)) id_bit = 1u << (pos & 31u);
+                    }
+                    if (has_rec[c]) {                                          // uniform
+                        const bool is_rec = mine && (!has_id[c] || !under);
+                        cnt[c] += is_rec ? 1u : 0u;
+                        const unsigned int ord = (unsigned int)((int)pos + ((int)pos < lo[c] ? base : base - sd.r)) << 4;
+                        unsigned short* const at = (is_rec && cnt[c] < REC_SLOTS)
+                                                       ? reinterpret_cast<unsigned short*>(L.rec[c] + lane * 64 + cnt[c] * 2)
+                                                       : &L.sink[lane];
+                        *at = (unsigned short)ord;
+                    }
                 }
-                atomicOr(&L.img[lane * RS_STRIDE + (pos >> 5)], id_bit);
+                if (has_id[0] || has_id[1]) atomicOr(&L.img[lane * RS_STRIDE + (pos >> 5)], id_bit);
             };
             // two erroneous qubits per trip: their draws are independent chains of multiplies, and the second one's atomic is
             // issued behind the first one's without waiting for it (the LDS serves a wavefront's operations in order)
