@@ -1455,6 +1455,8 @@ int gf2_mc_records_sample(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2
         GF2_HIP(hipMemsetAsync(sd.misfit_count, 0, 256, stream));
     }
     int64_t blocks = gf2_cdiv(count, 64);
+    // one wavefront per workgroup, 17 KiB of LDS each: 9 per CU (2, 4, 6 per CU: 0.31, 0.61, 0.78 of the rate at 9 -- the kernel
+    // is bound by what one wavefront issues, and more of them is what helps)
     if (blocks > (int64_t)ctx->num_cus * 9) blocks = (int64_t)ctx->num_cus * 9;
     hipLaunchKernelGGL(slab_record_sampler_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, a);
     GF2_HIP(hipGetLastError());
