@@ -159,6 +159,8 @@ int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value) {
             GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_SLAB_PASS_LOG2 must be in 12..22");
         if (option == GF2_OPT_MC_CHUNK_LOG2 && (value < 16 || value > 22))
             GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_MC_CHUNK_LOG2 must be in 16..22");
+        if (option == GF2_OPT_COMBINE_THREADS && value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)
+            GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_COMBINE_THREADS must be 64, 128, 256, 512 or 1024");
         if (option == GF2_OPT_COMBINE_BLOCKS && (value < 1 || value > 65535))
             GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_COMBINE_BLOCKS must be in 1..65535");
     }

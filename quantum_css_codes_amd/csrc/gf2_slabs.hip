@@ -1293,11 +1293,14 @@ static int launch_gather_combine(gf2_ctx* ctx, const gf2_check* ck, const uint64
         hipLaunchKernelGGL(slab_gather_kernel, ggrid, dim3(GAT_THREADS), lds_bytes, stream, ga);
     GF2_HIP(hipGetLastError());
 
-    // few large workgroups: every workgroup ends with one global atomic per non-empty bin
-    int64_t mblocks = gf2_cdiv(count, 4096);
-    const int64_t mb_cap = ctx->opt[GF2_OPT_COMBINE_BLOCKS] > 0 ? ctx->opt[GF2_OPT_COMBINE_BLOCKS] : 128;
+    // few large workgroups: every workgroup ends with one global atomic per non-empty bin.  (Workgroups of 256, 128 or 64 threads,
+    // which would fit a CU beside a gather workgroup of the other stream instead of waiting for one to drain, make the two-stream
+    // step 4, 6 and 7 % SLOWER: profiles/r02_sweep_combine.log.)
+    const int cthreads = ctx->opt[GF2_OPT_COMBINE_THREADS] > 0 ? (int)ctx->opt[GF2_OPT_COMBINE_THREADS] : 1024;
+    int64_t mblocks = gf2_cdiv(count, 4 * cthreads);
+    const int64_t mb_cap = ctx->opt[GF2_OPT_COMBINE_BLOCKS] > 0 ? ctx->opt[GF2_OPT_COMBINE_BLOCKS] : 128 * (1024 / cthreads);
     if (mblocks > mb_cap) mblocks = mb_cap;
-    hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3(1024), 0, stream, pw, gf2_cdiv(count, 64) * 64, pad,
+    hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3((unsigned)cthreads), 0, stream, pw, gf2_cdiv(count, 64) * 64, pad,
                        ck->nslabs512, (u64*)hist_dev, nbins, redo_count, redo_list, clk_dev ? clk_dev + 4 : nullptr);
     GF2_HIP(hipGetLastError());
     if (stray.n_cols) {
