@@ -87,8 +87,15 @@ struct CompactArgs {
     int64_t batch, lde;
     int r, n, ident_off, null_ord;
     u64 skip_words;            // words whose few non-identity columns are left to the redo pass (bit w = word w)
-    unsigned int* redo_count;  // zeroed here for the combine kernel of this call (null: no redo pass)
-    u64* clk;                  // debugging (GF2_GATHER_CLOCK): earliest entry / latest exit of the workgroups, else null
+    u64* clk;                  // debugging (GF2_F_DIAG_CLOCKS): earliest entry / latest exit of the workgroups, else null
+    // the PREVIOUS pass' partial weights, summed into the histogram on the way in (null: nothing to combine) -- the combine kernel's
+    // work without its launch between two passes of a call
+    const unsigned short* cmb_pw;
+    int64_t cmb_positions, cmb_pad;
+    unsigned int cmb_sample0;  // index of the previous pass' first sample in the call's batch (redo list entries are call-wide)
+    int cmb_nslabs, cmb_nbins;
+    unsigned int* redo_count;
+    unsigned int* redo_list;
 };
 
 // LDS per wavefront.  Non-zero (sample, word) pairs wait in a ring of 128 until 64 of them are there, so every pass over them
@@ -107,6 +114,70 @@ struct alignas(16) CompactWaveLds {
     unsigned int cnt[64];
 };
 static_assert(CMP_RING * 10 + CMP_LEFT * 12 >= (SPARSE_LIST_CAP + 8) * 4, "the slow routine's list reuses the ring and left regions");
+
+// The combine step for the positions this workgroup takes (every 4 * blockDim * gridDim): adds the (up to four) slabs' partial
+// weights of a record position and counts the total in `bins` (LDS, nbins counters, zeroed here), which it then adds to the
+// histogram -- one global atomic per non-empty bin and workgroup.  Positions a slab has flagged REC_STRAY go on the redo list
+// (as sample indices + sample0) through `staging` (1024 entries) instead.  Called by all threads of the workgroup.
+__device__ __forceinline__ void combine_positions(const unsigned short* __restrict__ pw, int64_t positions, int64_t batch_pad, int nslabs,
+                                                  u64* __restrict__ hist, int nbins, unsigned int* redo_count,
+                                                  unsigned int* __restrict__ redo_list, unsigned int sample0, unsigned int* bins,
+                                                  unsigned int* staging, unsigned int* shared2) {
+    unsigned int& redo_n = shared2[0];
+    unsigned int& redo_base = shared2[1];
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) bins[i] = 0;
+    if (threadIdx.x == 0) redo_n = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; s < positions; s += stride) {
+        u64 four[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) four[k] = *reinterpret_cast<const u64*>(pw + (int64_t)(k < nslabs ? k : 0) * batch_pad + s);
+        unsigned int w[4] = {0, 0, 0, 0};
+        bool skip[4], stray[4];
+        unsigned int local[4] = {0, 0, 0, 0};                      // tile-local sample index of a flagged position
+#pragma unroll
+        for (int t = 0; t < 4; ++t) skip[t] = stray[t] = false;   // finished and out-of-batch records carry REC_FLAG
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < nslabs) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const unsigned int v = (unsigned int)(four[k] >> (16 * t)) & 0xFFFFu;
+                    skip[t] |= v == REC_FLAG;
+                    if ((v & 0xFFC0u) == REC_STRAY) {
+                        stray[t] = true;
+                        local[t] = v & 63u;
+                    }
+                    w[t] += v;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (skip[t]) continue;
+            if (stray[t]) {
+                const unsigned int sample = sample0 + (unsigned int)((s + t) & ~(int64_t)63) + local[t];
+                const unsigned int at = atomicAdd(&redo_n, 1u);
+                if (at < 1024)
+                    staging[at] = sample;
+                else
+                    redo_list[atomicAdd(redo_count, 1u)] = sample;                       // more than the staging area holds
+            } else
+                atomicAdd(&bins[w[t]], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x)
+        if (bins[i]) atomicAdd(&hist[i], (u64)bins[i]);
+    const unsigned int mine = redo_n < 1024 ? redo_n : 1024;
+    if (mine) {                                                     // uniform
+        if (threadIdx.x == 0) redo_base = atomicAdd(redo_count, mine);
+        __syncthreads();
+        for (unsigned int i = threadIdx.x; i < mine; i += blockDim.x) redo_list[redo_base + i] = staging[i];
+    }
+    __syncthreads();
+}
 
 // A sub-pass scans 8 samples.  Only the words that hold non-identity columns matter (half of them in a standard form), so
 // the (sample, word) pairs of a sub-pass are dealt out densely: pair p = t * 64 + lane of round t is word
@@ -165,7 +236,13 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void sl
         if (lane == words - 1 && (a.n & 63)) amask &= ~(~0ull << (a.n & 63));
         if ((a.skip_words >> lane) & 1ull) amask = 0;
     }
-    if (a.redo_count && blockIdx.x == 0 && threadIdx.x == 0) *a.redo_count = 0;
+    if (a.cmb_pw) {
+        // the previous pass' combine step first (nothing of this pass is in flight yet); its counters use the waves' LDS
+        static_assert(sizeof(lds_all) >= (SLAB_MAX_BINS + 1024 + 2) * 4, "the combine step's counters and staging area fit the compact kernel's LDS");
+        unsigned int* const scratch = reinterpret_cast<unsigned int*>(lds_all);
+        combine_positions(a.cmb_pw, a.cmb_positions, a.cmb_pad, a.cmb_nslabs, a.hist, a.cmb_nbins, a.redo_count, a.redo_list,
+                          a.cmb_sample0, scratch, scratch + SLAB_MAX_BINS, scratch + SLAB_MAX_BINS + 1024);
+    }
     if (wave == 0) {
         const u64 act = __ballot(amask != 0);
         if (amask) wlist[__builtin_amdgcn_mbcnt_hi((unsigned int)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)act, 0u))] = lane;
@@ -1070,62 +1147,12 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
 // any is used.  Positions a slab has flagged REC_STRAY go on the redo list instead of into the histogram.
 __global__ __launch_bounds__(1024) void slab_combine_kernel(const unsigned short* __restrict__ pw, int64_t positions, int64_t batch_pad,
                                                            int nslabs, u64* __restrict__ hist, int nbins, unsigned int* redo_count,
-                                                           unsigned int* __restrict__ redo_list, u64* clk) {
+                                                           unsigned int* __restrict__ redo_list, unsigned int sample0, u64* clk) {
     __shared__ unsigned int bins[SLAB_MAX_BINS];
     __shared__ unsigned int redo_local[1024];                   // this workgroup's redo positions, handed over in one piece
-    __shared__ unsigned int redo_n, redo_base;
+    __shared__ unsigned int two[2];
     if (clk && threadIdx.x == 0) atomicMin(&clk[0], (u64)wall_clock64());
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x) bins[i] = 0;
-    if (threadIdx.x == 0) redo_n = 0;
-    __syncthreads();
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
-    for (int64_t s = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; s < positions; s += stride) {
-        u64 four[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) four[k] = *reinterpret_cast<const u64*>(pw + (int64_t)(k < nslabs ? k : 0) * batch_pad + s);
-        unsigned int w[4] = {0, 0, 0, 0};
-        bool skip[4], stray[4];
-        unsigned int local[4] = {0, 0, 0, 0};                      // tile-local sample index of a flagged position
-#pragma unroll
-        for (int t = 0; t < 4; ++t) skip[t] = stray[t] = false;   // finished and out-of-batch records carry REC_FLAG
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k < nslabs) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const unsigned int v = (unsigned int)(four[k] >> (16 * t)) & 0xFFFFu;
-                    skip[t] |= v == REC_FLAG;
-                    if ((v & 0xFFC0u) == REC_STRAY) {
-                        stray[t] = true;
-                        local[t] = v & 63u;
-                    }
-                    w[t] += v;
-                }
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (skip[t]) continue;
-            if (stray[t]) {
-                const unsigned int sample = (unsigned int)((s + t) & ~(int64_t)63) + local[t];
-                const unsigned int at = atomicAdd(&redo_n, 1u);
-                if (at < 1024)
-                    redo_local[at] = sample;
-                else
-                    redo_list[atomicAdd(redo_count, 1u)] = sample;                       // more than the staging area holds
-            } else
-                atomicAdd(&bins[w[t]], 1u);
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x)
-        if (bins[i]) atomicAdd(&hist[i], (u64)bins[i]);
-    const unsigned int mine = redo_n < 1024 ? redo_n : 1024;
-    if (mine) {                                                     // uniform
-        if (threadIdx.x == 0) redo_base = atomicAdd(redo_count, mine);
-        __syncthreads();
-        for (unsigned int i = threadIdx.x; i < mine; i += blockDim.x) redo_list[redo_base + i] = redo_local[i];
-    }
+    combine_positions(pw, positions, batch_pad, nslabs, hist, nbins, redo_count, redo_list, sample0, bins, redo_local, two);
     if (clk && threadIdx.x == 0) atomicMax(&clk[1], (u64)wall_clock64());
 }
 
@@ -1256,11 +1283,9 @@ static int slab_lds_optin(gf2_ctx* ctx) {
     return GF2_OK;
 }
 
-// gather -> combine (-> redo) of one pass: records, identity words (rows of lde words at e) and the workspace are in place.
-static int launch_gather_combine(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u32x4* rec, unsigned short* pw,
-                                 unsigned int* redo_count, unsigned int* redo_list, int64_t count, int64_t pad, int64_t lde,
-                                 bool fast, const StrayPlan& stray, uint64_t* hist_dev, hipStream_t stream, u64* clk_dev) {
-    const int nbins = (int)ck->r + 1;
+// The gather kernel of one pass: records, identity words (rows of lde words at e) and the workspace are in place.
+static int launch_gather(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u32x4* rec, unsigned short* pw, int64_t count, int64_t pad,
+                         int64_t lde, bool fast, const StrayPlan& stray, hipStream_t stream, u64* clk_dev) {
     const size_t lds_bytes = (size_t)ck->slab_cols * 64;
     GatherArgs ga;
     ga.tab = (const u32x4*)ck->slab_tab_dev;
@@ -1292,7 +1317,13 @@ static int launch_gather_combine(gf2_ctx* ctx, const gf2_check* ck, const uint64
     else
         hipLaunchKernelGGL(slab_gather_kernel, ggrid, dim3(GAT_THREADS), lds_bytes, stream, ga);
     GF2_HIP(hipGetLastError());
+    return GF2_OK;
+}
 
+// The combine kernel of one pass (sample0: the pass' first sample in the call's batch, for the redo list).
+static int launch_combine(gf2_ctx* ctx, const gf2_check* ck, const unsigned short* pw, unsigned int* redo_count, unsigned int* redo_list,
+                          int64_t count, int64_t pad, unsigned int sample0, uint64_t* hist_dev, hipStream_t stream, u64* clk_dev) {
+    const int nbins = (int)ck->r + 1;
     // few large workgroups: every workgroup ends with one global atomic per non-empty bin.  (Workgroups of 256, 128 or 64 threads,
     // which would fit a CU beside a gather workgroup of the other stream instead of waiting for one to drain, make the two-stream
     // step 4, 6 and 7 % SLOWER: profiles/r02_sweep_combine.log.)
@@ -1301,14 +1332,19 @@ static int launch_gather_combine(gf2_ctx* ctx, const gf2_check* ck, const uint64
     const int64_t mb_cap = ctx->opt[GF2_OPT_COMBINE_BLOCKS] > 0 ? ctx->opt[GF2_OPT_COMBINE_BLOCKS] : 128 * (1024 / cthreads);
     if (mblocks > mb_cap) mblocks = mb_cap;
     hipLaunchKernelGGL(slab_combine_kernel, dim3((unsigned)mblocks), dim3((unsigned)cthreads), 0, stream, pw, gf2_cdiv(count, 64) * 64, pad,
-                       ck->nslabs512, (u64*)hist_dev, nbins, redo_count, redo_list, clk_dev ? clk_dev + 4 : nullptr);
+                       ck->nslabs512, (u64*)hist_dev, nbins, redo_count, redo_list, sample0, clk_dev ? clk_dev + 4 : nullptr);
     GF2_HIP(hipGetLastError());
-    if (stray.n_cols) {
-        hipLaunchKernelGGL(slab_redo_kernel, dim3((unsigned)(ctx->num_cus * (ctx->opt[GF2_OPT_REDO_BLOCKS_PER_CU] > 0 ? ctx->opt[GF2_OPT_REDO_BLOCKS_PER_CU] : 8))), dim3(256), 0, stream, (const u64*)e, count, lde,
-                           (const unsigned int*)redo_count, (const unsigned int*)redo_list, ck->ht_dev,
-                           (int)ck->r, (int)ck->n, (int)ck->ident_off, (u64*)hist_dev);
-        GF2_HIP(hipGetLastError());
-    }
+    return GF2_OK;
+}
+
+// The redo kernel over the whole call's batch: the samples the combine steps have listed (they have a column compact left out).
+static int launch_redo(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde, unsigned int* redo_count,
+                       unsigned int* redo_list, uint64_t* hist_dev, hipStream_t stream) {
+    const int64_t per_cu = ctx->opt[GF2_OPT_REDO_BLOCKS_PER_CU] > 0 ? ctx->opt[GF2_OPT_REDO_BLOCKS_PER_CU] : 8;
+    hipLaunchKernelGGL(slab_redo_kernel, dim3((unsigned)(ctx->num_cus * per_cu)), dim3(256), 0, stream, (const u64*)e_dev, batch, lde,
+                       (const unsigned int*)redo_count, (const unsigned int*)redo_list, ck->ht_dev, (int)ck->r, (int)ck->n,
+                       (int)ck->ident_off, (u64*)hist_dev);
+    GF2_HIP(hipGetLastError());
     return GF2_OK;
 }
 
@@ -1318,12 +1354,28 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
     GF2_TRY(slab_lds_optin(ctx));
     const int64_t pass = slab_pass(ctx, batch);
     const int64_t pad = gf2_cdiv(pass, 64) * 64;
-    const size_t rec_bytes = (size_t)pad * 64, pw_bytes = (size_t)ck->nslabs512 * pad * 2, redo_bytes = (size_t)pad * 4 + 256;
+    // records and partial weights of one pass; the redo list is the call's (one redo launch at the end)
+    const size_t rec_bytes = (size_t)pad * 64, pw_bytes = (size_t)ck->nslabs512 * pad * 2;
+    const size_t redo_bytes = (size_t)(batch > pad ? gf2_cdiv(batch, 64) * 64 : pad) * 4 + 256;
     GF2_TRY(gf2_ws_reserve(ctx, ws_slot, rec_bytes + pw_bytes + redo_bytes));
     u32x4* rec = (u32x4*)ctx->ws[ws_slot];
     unsigned short* pw = (unsigned short*)((char*)ctx->ws[ws_slot] + rec_bytes);
     unsigned int* redo_count = (unsigned int*)((char*)ctx->ws[ws_slot] + rec_bytes + pw_bytes);
     unsigned int* redo_list = redo_count + 64;
+    // the hand-scheduled gather kernel needs every slab's identity words to be whole 16-byte pieces inside the row
+    const int64_t first_dw = ck->ident_off >= 0 ? ck->ident_off >> 5 : 0;
+    const bool fast = ck->ident_off >= 0 && (lde & 1) == 0 && (reinterpret_cast<uintptr_t>(e_dev) & 15) == 0 &&
+                      (first_dw & 3) == 0 && first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) <= lde * 2 &&
+                      !gf2_flag(ctx, GF2_F_GATHER_GENERIC);
+    StrayPlan stray = {0, 0, {0, 0}};
+    if (fast) stray = plan_stray(ctx, ck);
+    // GF2_F_COMBINE_FOLDED: between two passes of a call the combine step rides in the next pass' compact kernel (its first
+    // instructions, before any of its own loads) -- 14 launches fewer per call of 8 passes.  Built because the small kernels sit
+    // on the stream's critical path and are stretched by the other stream's big ones; measured: no change on two streams, 5 %
+    // slower on one (1280 workgroups' worth of histogram atomics instead of 128: profiles/r02_sweep_fold.log).  Off by default.
+    const bool fold = gf2_flag(ctx, GF2_F_COMBINE_FOLDED) && !gf2_flag(ctx, GF2_F_DIAG_CLOCKS);
+    GF2_HIP(hipMemsetAsync(redo_count, 0, 4, stream));
+    int64_t prev_first = 0, prev_count = 0;
     for (int64_t first = 0; first < batch; first += pass) {
         const int64_t count = batch - first < pass ? batch - first : pass;
         const uint64_t* e = e_dev + first * lde;
@@ -1333,14 +1385,6 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
             GF2_HIP(hipMalloc((void**)&clk_dev, 64));
             GF2_HIP(hipMemcpy(clk_dev, init, 48, hipMemcpyHostToDevice));
         }
-        // the hand-scheduled gather kernel needs every slab's identity words to be whole 16-byte pieces inside the row
-        const int64_t first_dw = ck->ident_off >= 0 ? ck->ident_off >> 5 : 0;
-        const bool fast = ck->ident_off >= 0 && (lde & 1) == 0 && (reinterpret_cast<uintptr_t>(e) & 15) == 0 &&
-                          (first_dw & 3) == 0 && first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) <= lde * 2 &&
-                          !gf2_flag(ctx, GF2_F_GATHER_GENERIC);
-        StrayPlan stray = {0, 0, {0, 0}};
-        if (fast) stray = plan_stray(ctx, ck);
-
         CompactArgs ca;
         ca.clk = clk_dev;
         ca.e = (const u64*)e;
@@ -1354,7 +1398,14 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
         ca.ident_off = (int)ck->ident_off;
         ca.null_ord = ck->slab_null;
         ca.skip_words = stray.skip_words;
+        ca.cmb_pw = fold && first > 0 ? pw : nullptr;
+        ca.cmb_positions = gf2_cdiv(prev_count, 64) * 64;
+        ca.cmb_pad = pad;
+        ca.cmb_sample0 = (unsigned int)prev_first;
+        ca.cmb_nslabs = ck->nslabs512;
+        ca.cmb_nbins = (int)ck->r + 1;
         ca.redo_count = redo_count;
+        ca.redo_list = redo_list;
         int64_t cblocks = gf2_cdiv(gf2_cdiv(count, 64), CMP_WAVES);
         // rounds per sub-pass: ceil(8 * words with non-identity columns / 64); workgroups per CU as the variant's registers allow
         {
@@ -1372,8 +1423,11 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
                 hipLaunchKernelGGL(slab_compact_kernel<8>, cgrid, cblock, 0, stream, ca);
         }
         GF2_HIP(hipGetLastError());
-
-        GF2_TRY(launch_gather_combine(ctx, ck, e, rec, pw, redo_count, redo_list, count, pad, lde, fast, stray, hist_dev, stream, clk_dev));
+        GF2_TRY(launch_gather(ctx, ck, e, rec, pw, count, pad, lde, fast, stray, stream, clk_dev));
+        if (!fold || first + pass >= batch)
+            GF2_TRY(launch_combine(ctx, ck, pw, redo_count, redo_list, count, pad, (unsigned int)first, hist_dev, stream, clk_dev));
+        prev_first = first;
+        prev_count = count;
         if (clk_dev) {
             u64 c[6];
             GF2_HIP(hipStreamSynchronize(stream));
@@ -1385,6 +1439,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
             GF2_HIP(hipFree(clk_dev));
         }
     }
+    if (stray.n_cols) GF2_TRY(launch_redo(ctx, ck, e_dev, batch, lde, redo_count, redo_list, hist_dev, stream));
     return GF2_OK;
 }
 
@@ -1486,9 +1541,8 @@ int gf2_mc_records_weigh(gf2_ctx* ctx, const gf2_check* ck, int comp, uint64_t s
     const bool fast = (lde & 1) == 0 && (first_dw & 3) == 0 && first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) <= lde * 2 &&
                       !gf2_flag(ctx, GF2_F_GATHER_GENERIC);
     const StrayPlan none = {0, 0, {0, 0}};
-    GF2_HIP(hipMemsetAsync(redo_count, 0, 4, stream));              // (the combine kernel reads it; compact, which zeroes it, does not run)
-    GF2_TRY(launch_gather_combine(ctx, ck, eident, rec, pw, redo_count, redo_count + 64, count, (int64_t)pad, lde, fast, none, hist_dev,
-                                  stream, nullptr));
+    GF2_TRY(launch_gather(ctx, ck, eident, rec, pw, count, (int64_t)pad, lde, fast, none, stream, nullptr));
+    GF2_TRY(launch_combine(ctx, ck, pw, redo_count, redo_count + 64, count, (int64_t)pad, 0u, hist_dev, stream, nullptr));
     const SparseSide side = {ck->ht_dev, ck->r, ck->ident_off, (u64*)hist_dev, (int)(ck->r + 1)};
     hipLaunchKernelGGL(slab_misfit_kernel, dim3(64), dim3(64 * MISFIT_WAVES), 0, stream, (const unsigned int*)misfit_count,
                        (const unsigned int*)(misfit_count + 64), (u64)seed, first_sample, th, side, comp, n);

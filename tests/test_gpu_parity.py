@@ -915,6 +915,54 @@ def test_syndrome_slab_pipeline_default_route_large_batch(ctx, route):
     assert np.array_equal(first.download((r + 1,), np.uint64), want)
 
 
+@pytest.mark.parametrize("shape", [(2047, 4096, 2048), (2048, 4096, 0), (1000, 3000, 1024)])
+def test_slab_pipeline_many_passes_and_the_folded_combine_step(shape, ctx, route):
+    # a call of many passes (2^12 samples each here; 2^21 by default): a combine kernel after every pass, and the redo list
+    # (H2-shaped check: a column next to the identity block) is the call's, worked off once at the end.  With
+    # GF2_F_COMBINE_FOLDED the combine step between two passes is done by the next pass' compact kernel instead.  Same
+    # histogram either way, as the column-gather kernel and, on a prefix, as the oracle; ragged last pass and ragged last tile.
+    r, n, ioff = shape
+    batch = 9 * 4096 + 1234
+    rng = np.random.default_rng(r + n)
+    hm = rng.integers(0, 2, (r, n), dtype=np.uint8)
+    hm[:, ioff:ioff + r] = np.identity(r, dtype=np.uint8)
+    h = _native.pack_rows(hm)
+    chk = ctx.check_create(h, r, n)
+    lde = _native.words_for(n)
+    ex, ez = ctx.alloc(batch * lde * 8), ctx.alloc(batch * lde * 8)
+    ctx.sample_errors_dev(n, 17, 3, batch, 0.004, 0.003, 0.003, ex, ez, lde)
+    got = {}
+    ctx.set_option(_native.OPT_SLAB_PASS_LOG2, 12)
+    try:
+        for name in ("default", "GF2_COMBINE_FOLDED", "GF2_NO_REDO"):
+            if name != "default":
+                route.force(name)
+            route.force("GF2_SPARSE_SLABS")
+            hist = ctx.alloc((r + 1) * 8).zero()
+            ctx.syndrome_sparse_dev(chk, ex, batch, lde, None, 0, hist, r + 1)
+            ctx.syndrome_sparse_dev(chk, ex, batch, lde, None, 0, hist, r + 1)          # twice: the redo list starts empty each call
+            got[name] = hist.download((r + 1,), np.uint64)
+            route.release("GF2_SPARSE_SLABS")
+            if name != "default":
+                route.release(name)
+    finally:
+        ctx.set_option(_native.OPT_SLAB_PASS_LOG2, None)
+    route.force("GF2_SPARSE_GATHER")
+    hist = ctx.alloc((r + 1) * 8).zero()
+    ctx.syndrome_sparse_dev(chk, ex, batch, lde, None, 0, hist, r + 1)
+    gather = hist.download((r + 1,), np.uint64)
+    for name, hist_n in got.items():
+        assert np.array_equal(hist_n, gather * np.uint64(2)), name
+    assert int(gather.sum()) == batch
+    e = ex.download((batch, lde), "<u8")
+    want = c_oracle.histogram(c_oracle.syndrome_batch(h, r, n, e[:2000].copy(), 2000), 2000, r, 1, r + 1)
+    route.release("GF2_SPARSE_GATHER")
+    route.force("GF2_SPARSE_SLABS")
+    first = ctx.alloc((r + 1) * 8).zero()
+    ctx.syndrome_sparse_dev(chk, ex, 2000, lde, None, 0, first, r + 1)
+    assert np.array_equal(first.download((r + 1,), np.uint64), want)
+
+
 @pytest.mark.parametrize("case", ["steane", "rm15_c2", "identity", "r0", "repetition", "random_31_16", "random_64_24",
                                   "duplicate_columns", "zero_column"])
 def test_syndrome_table_device_search(case, ctx, steane_h, rm15):
