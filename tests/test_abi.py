@@ -38,6 +38,20 @@ def test_ctypes_table_matches_header():
         assert len(args) == len(_native.SIGNATURES[name]), name
 
 
+def test_flag_and_option_numbers_match_the_header():
+    text = open(os.path.join(ROOT, "include", "gf2hip.h")).read()
+    flags = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define GF2_F_(\w+)\s+\(1u << (\d+)\)", text)}
+    assert len(flags) >= 16
+    for name, bit in flags.items():
+        assert getattr(_native, "F_" + name) == 1 << bit, name
+    assert len({v for v in flags.values()}) == len(flags)                     # no bit used twice
+    opts = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define GF2_OPT_(\w+)\s+(\d+)", text)}
+    count = opts.pop("COUNT")
+    assert sorted(opts.values()) == list(range(count))
+    for name, number in opts.items():
+        assert getattr(_native, "OPT_" + name) == number, name
+
+
 def test_host_packing_roundtrip():
     handle = _native.lib()
     rng = np.random.default_rng(1)

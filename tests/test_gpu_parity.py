@@ -1257,6 +1257,22 @@ def test_bench_under_torchrun_two_ranks_share_the_gpu(tmp_path):
     assert out["checks"]["histogram_total"] == 2 * (2 << 17)   # both shards' samples arrived in the all-reduced histogram
 
 
+def test_context_options_are_validated(ctx):
+    for option, bad in ((_native.OPT_SLAB_PASS_LOG2, 11), (_native.OPT_SLAB_PASS_LOG2, 23), (_native.OPT_COMBINE_BLOCKS, 0),
+                        (_native.OPT_MC_CHUNK_LOG2, 15), (_native.OPT_MC_CHUNK_LOG2, 23), (_native.OPT_COMBINE_THREADS, 96),
+                        (99, 1)):
+        with pytest.raises(_native.GF2Error):
+            ctx.set_option(option, bad)
+    for option, good in ((_native.OPT_SLAB_PASS_LOG2, 20), (_native.OPT_MC_CHUNK_LOG2, 20), (_native.OPT_COMBINE_THREADS, 256),
+                         (_native.OPT_COMBINE_BLOCKS, 64)):
+        ctx.set_option(option, good)
+        ctx.set_option(option, None)                                        # back to the default
+    before = ctx.get_flags()
+    with ctx.flags(_native.F_MC_ROWS | _native.F_COMBINE_FOLDED):
+        assert ctx.get_flags() == before | _native.F_MC_ROWS | _native.F_COMBINE_FOLDED
+    assert ctx.get_flags() == before
+
+
 def test_two_contexts_share_checks_and_run_concurrently(ctx):
     # bench.py issues the two components of a step on two contexts (two HIP streams, two workspaces) that share the prepared
     # checks and the resident errors; 30 overlapping steps must accumulate exactly 30 times the one-stream histograms
