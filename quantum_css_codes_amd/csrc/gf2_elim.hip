@@ -217,121 +217,130 @@ __device__ __forceinline__ u64 transpose64(u64 x, int lane) {
     return x;
 }
 
-// One round of the panel factorisation on the window (wavefront 0 of the panel kernels).  In: win_w / win_c / win_row (nwin <= 128
-// rows), the unresolved panel columns, t pivots so far.  Out: for every new pivot p its word and coefficients when chosen, its
-// column and its row (pword, csel, pbit, prow_l); fin_w / fin_c / win_piv for the window rows that became pivots; CP / WP, the
-// probe rows; misc = {pivots now, new columns lo, hi}.
+// One round of the panel factorisation on the window (wavefront 0 of the panel kernels), Gauss-Jordan inside one wavefront.
+// In: win_w / win_d / win_row (nwin <= 128 rows: panel word, coefficients so far, row), the unresolved panel columns, t pivots so
+// far.  Out: for every new pivot p its column and its row (pbit, prow_l); fin_w / fin_d / win_piv for the window rows that
+// became pivots; DP / WP, the probe rows; misc = {pivots now, new columns lo, hi}.
+//
+// Coefficients are kept in their FINAL form: new_i = old_i ^ d_i . OLDPIV, OLDPIV_p = pivot p's row as it stands at the start of
+// the panel.  The pivot row of p, when chosen, is P_p = OLDPIV_p ^ d_r . OLDPIV, so a row that takes P_p takes e_p ^ d_r into its
+// coefficients -- there is no separate matrix V to invert afterwards.  64 PROBE rows e_0 .. e_63 are eliminated along: row e_j
+// ends with the word and the coefficients any row gets for having bit j, and elimination is linear in the row, so every row
+// outside the window is finished with two table lookups instead of replaying the pivots.
+//
+// Lane l holds window rows l and l + 64 and probe row e_l (word and coefficients in registers).  The columns go in strips of
+// RB_STRIP:
+//   1. the strip's columns become bit vectors over the 192 rows (three ballots each) in SCALAR registers, and the strip is
+//      eliminated there: a pivot step is a find-first, and for each later column of the strip in which the pivot row has a bit,
+//      three 64-bit XORs -- no trip between the vector and the scalar unit per pivot (the column-sliced round before this one
+//      spent its 280 ns per pivot on six of them).  What is left of column j afterwards is its TAKE MASK: the rows that take
+//      pivot j.
+//   2. the strip's pivots are applied to the words and coefficients in order: the pivot row (up to date when its turn comes,
+//      because the earlier pivots of the strip have been applied) is broadcast by readlane and XORed into the rows of its take
+//      mask, which serves as the lane mask of the select as it stands.
+#define RB_STRIP 4                                  // columns per strip (8: the 24 column vectors and the kernel's own scalars spill)
 __device__ __forceinline__ void window_round(int lane, int nwin, int t, int64_t rank, int64_t m, u64 unresolved, const u64* win_w,
-                                             const u64* win_c, const int* win_row, int* win_piv, u64* fin_w, u64* fin_c, u64* pword,
-                                             u64* csel, int* pbit, int* prow_l, u64* CP, u64* WP, int* misc) {
-        // Gauss-Jordan on the window inside one wavefront, COLUMN-sliced: lane = panel column, bit i of (colw0, colw1) = window
-        // row i's bit in that column.  A step is a handful of scalar operations -- the column of bit b comes by readlane, its
-        // first row that is not a pivot yet becomes the pivot, every lane whose column has the pivot row's bit toggles the
-        // other rows of column b -- instead of two ballots over the rows and five readlanes of the pivot row's data.
-        // Coefficients are kept the same way (lane p: bit i = window row i took pivot p).  64 PROBE rows e_0 .. e_63 (third
-        // word) are eliminated along: row e_j ends with the coefficients and the word any row gets for having bit j, and
-        // elimination is linear in the row, so every row outside the pivots is finished with two table lookups instead of
-        // replaying the pivots one by one.
-        const u64 ew0 = lane < nwin ? win_w[lane] : 0ull, ew1 = lane + 64 < nwin ? win_w[lane + 64] : 0ull;
-        u64 colw0 = transpose64(ew0, lane), colw1 = transpose64(ew1, lane), colw2 = 1ull << lane;
-        u64 ccol0 = 0, ccol1 = 0, ccol2 = 0;
-        if (t > 0) {                                              // uniform: coefficients of earlier rounds
-            ccol0 = transpose64(lane < nwin ? win_c[lane] : 0ull, lane);
-            ccol1 = transpose64(lane + 64 < nwin ? win_c[lane + 64] : 0ull, lane);
+                                             const u64* win_d, const int* win_row, int* win_piv, u64* fin_w, u64* fin_d,
+                                             int* pbit, int* prow_l, u64* DP, u64* WP, int* misc) {
+    u64 w[3], d[3];
+    w[0] = lane < nwin ? win_w[lane] : 0ull;
+    w[1] = lane + 64 < nwin ? win_w[lane + 64] : 0ull;
+    w[2] = 1ull << lane;
+    d[0] = (t > 0 && lane < nwin) ? win_d[lane] : 0ull;               // uniform: coefficients of earlier rounds
+    d[1] = (t > 0 && lane + 64 < nwin) ? win_d[lane + 64] : 0ull;
+    d[2] = 0ull;
+    u64 piv0 = 0, piv1 = 0, newbits = 0;                               // (uniform) window rows that are pivots; columns resolved here
+    unsigned int my_pbit = 0, my_prow = 0;                             // lane p: pivot p's column and window row
+    int tt = t;
+    auto rl = [](unsigned int v, int src) { return (unsigned int)__builtin_amdgcn_readlane((int)v, src); };
+#pragma unroll 1
+    for (int s = 0; s < 64 / RB_STRIP; ++s) {
+        const unsigned int sm = (unsigned int)(unresolved >> (RB_STRIP * s)) & ((1u << RB_STRIP) - 1u);
+        if (!sm || tt >= 64 || rank + tt >= m) continue;              // uniform
+        const unsigned int y0 = (unsigned int)(w[0] >> (RB_STRIP * s)), y1 = (unsigned int)(w[1] >> (RB_STRIP * s)), y2 = (unsigned int)(w[2] >> (RB_STRIP * s));
+        u64 c0[RB_STRIP], c1[RB_STRIP], c2[RB_STRIP];                                       // column j of the strip: window rows 0..63, 64..127, probe rows
+#pragma unroll
+        for (int j = 0; j < RB_STRIP; ++j) {
+            c0[j] = __ballot((y0 >> j) & 1u);
+            c1[j] = __ballot((y1 >> j) & 1u);
+            c2[j] = __ballot((y2 >> j) & 1u);
         }
-        u64 piv0 = 0, piv1 = 0, newbits = 0, todo = unresolved;
-        // what lane p keeps about pivot p: the pivot row's word and coefficients when chosen, its column, its window index.
-        // Lane tt's slots (and its coefficient words: no pivot tt before this round) are zero until step tt sets them: one
-        // v_writelane_b32 per dword with the lane in M0 (a select costs two instructions each: an SGPR value and an SGPR mask
-        // do not fit one VOP3; the compiler has no builtin for writelane and does not use M0 in this kernel).
-        unsigned int pw_lo = 0, pw_hi = 0, cs_lo = 0, cs_hi = 0, my_pbit = 0, my_prow = 0;
-        unsigned int x0l = (unsigned int)colw0, x0h = (unsigned int)(colw0 >> 32), x1l = (unsigned int)colw1, x1h = (unsigned int)(colw1 >> 32);
-        unsigned int x2l = (unsigned int)colw2, x2h = (unsigned int)(colw2 >> 32);
-        unsigned int c0l = (unsigned int)ccol0, c0h = (unsigned int)(ccol0 >> 32), c1l = (unsigned int)ccol1, c1h = (unsigned int)(ccol1 >> 32);
-        unsigned int c2l = 0, c2h = 0;
-        int tt = t;
-        // a ^ (b & c) in one instruction (v_bitop3_b32, truth table 0x78)
-        auto xor_and = [](unsigned int a, unsigned int bb, unsigned int cc) { return __builtin_amdgcn_bitop3_b32(a, bb, cc, 0x78); };
-        auto rl = [](unsigned int v, int src) { return (unsigned int)__builtin_amdgcn_readlane((int)v, src); };
-        while (todo && tt < 64 && rank + tt < m) {
-            const int b = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const unsigned int b0l = rl(x0l, b), b0h = rl(x0h, b), b1l = rl(x1l, b), b1h = rl(x1h, b);     // column b, rows 0..127
-            const u64 cb0 = ((u64)b0h << 32) | b0l, cb1 = ((u64)b1h << 32) | b1l;
-            const u64 cand0 = cb0 & ~piv0, cand1 = cb1 & ~piv1;
-            if (!(cand0 | cand1)) continue;                       // no pivot for this column inside the window
-            const unsigned int b2l = rl(x2l, b), b2h = rl(x2h, b);                                          // ... and the probe rows
-            unsigned int m0l = b0l, m0h = b0h, m1l = b1l, m1h = b1h;     // rows that take the pivot row: all with the bit but itself
-            unsigned int hit, pcs_src_l, pcs_src_h;                      // hit: all ones in the lanes whose column the pivot row has
+        int prow_s[RB_STRIP];
+        unsigned int vm = 0;                                           // columns of the strip that found a pivot
+#pragma unroll
+        for (int j = 0; j < RB_STRIP; ++j) {
+            prow_s[j] = 0;
+            if (!((sm >> j) & 1u) || tt >= 64 || rank + tt >= m) continue;
+            const u64 cand0 = c0[j] & ~piv0, cand1 = c1[j] & ~piv1;
+            if (!(cand0 | cand1)) continue;                           // no pivot for this column inside the window
             int r;
-            if (cand0) {                                          // uniform; the usual case: a pivot among the first 64 window rows
+            if (cand0) {
                 r = __ffsll((long long)cand0) - 1;
-                const u64 keep = ~(1ull << r);
-                m0l &= (unsigned int)keep;
-                m0h &= (unsigned int)(keep >> 32);
-                hit = (unsigned int)__builtin_amdgcn_sbfe((int)(r < 32 ? x0l : x0h), (unsigned int)(r & 31), 1u);
-                pcs_src_l = c0l, pcs_src_h = c0h;
                 piv0 |= 1ull << r;
+                c0[j] &= ~(1ull << r);                                // the pivot row does not take itself
             } else {
-                const int r1 = __ffsll((long long)cand1) - 1;
-                r = 64 + r1;
-                const u64 keep = ~(1ull << r1);
-                m1l &= (unsigned int)keep;
-                m1h &= (unsigned int)(keep >> 32);
-                hit = (unsigned int)__builtin_amdgcn_sbfe((int)(r1 < 32 ? x1l : x1h), (unsigned int)(r1 & 31), 1u);
-                pcs_src_l = c1l, pcs_src_h = c1h;
-                piv1 |= 1ull << r1;
+                r = 64 + __ffsll((long long)cand1) - 1;
+                piv1 |= 1ull << (r - 64);
+                c1[j] &= ~(1ull << (r - 64));
             }
-            const u64 pwd = __ballot(hit != 0);                                                            // = the pivot row's word
-            const u64 pcs = __ballot((((r & 32) ? pcs_src_h : pcs_src_l) >> (r & 31)) & 1u);                // = its coefficients so far
-            x0l = xor_and(x0l, m0l, hit), x0h = xor_and(x0h, m0h, hit);
-            x1l = xor_and(x1l, m1l, hit), x1h = xor_and(x1h, m1h, hit);
-            x2l = xor_and(x2l, b2l, hit), x2h = xor_and(x2h, b2h, hit);
-            asm volatile(
-                "s_mov_b32 m0, %12\n\t"
-                "v_writelane_b32 %0, %13, m0\n\tv_writelane_b32 %1, %14, m0\n\tv_writelane_b32 %2, %15, m0\n\t"
-                "v_writelane_b32 %3, %16, m0\n\tv_writelane_b32 %4, %17, m0\n\tv_writelane_b32 %5, %18, m0\n\t"
-                "v_writelane_b32 %6, %19, m0\n\tv_writelane_b32 %7, %20, m0\n\tv_writelane_b32 %8, %21, m0\n\t"
-                "v_writelane_b32 %9, %22, m0\n\tv_writelane_b32 %10, %23, m0\n\tv_writelane_b32 %11, %24, m0"
-                : "+v"(c0l), "+v"(c0h), "+v"(c1l), "+v"(c1h), "+v"(c2l), "+v"(c2h), "+v"(pw_lo), "+v"(pw_hi), "+v"(cs_lo),
-                  "+v"(cs_hi), "+v"(my_pbit), "+v"(my_prow)
-                : "s"(tt), "s"(m0l), "s"(m0h), "s"(m1l), "s"(m1h), "s"(b2l), "s"(b2h), "s"((unsigned int)pwd),
-                  "s"((unsigned int)(pwd >> 32)), "s"((unsigned int)pcs), "s"((unsigned int)(pcs >> 32)), "s"((unsigned int)b),
-                  "s"((unsigned int)r)
-                : "m0");
-            newbits |= 1ull << b;
+#pragma unroll
+            for (int j2 = j + 1; j2 < RB_STRIP; ++j2) {                       // the columns before j are done with: zero in the pivot row
+                const u64 src = r < 64 ? c0[j2] : c1[j2];
+                if ((src >> (r & 63)) & 1ull) {
+                    c0[j2] ^= c0[j];
+                    c1[j2] ^= c1[j];
+                    c2[j2] ^= c2[j];
+                }
+            }
+            prow_s[j] = r;
+            vm |= 1u << j;
+            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0"
+                         : "+v"(my_pbit), "+v"(my_prow)
+                         : "s"(tt), "s"((unsigned int)(RB_STRIP * s + j)), "s"((unsigned int)r)
+                         : "m0");
+            newbits |= 1ull << (RB_STRIP * s + j);
             tt += 1;
         }
-        colw0 = ((u64)x0h << 32) | x0l, colw1 = ((u64)x1h << 32) | x1l, colw2 = ((u64)x2h << 32) | x2l;
-        ccol0 = ((u64)c0h << 32) | c0l, ccol1 = ((u64)c1h << 32) | c1l, ccol2 = ((u64)c2h << 32) | c2l;
-        const u64 my_pword = ((u64)pw_hi << 32) | pw_lo, my_csel = ((u64)cs_hi << 32) | cs_lo;
-        // the new pivot rows as they stand at the end of the round: word and coefficients (bit r across the lanes)
-        for (int p = t; p < tt; ++p) {
-            const int r = __builtin_amdgcn_readlane((int)my_prow, p);
-            const u64 wf = __ballot(r < 64 ? (colw0 >> r) & 1ull : (colw1 >> (r - 64)) & 1ull);
-            const u64 cf = __ballot(r < 64 ? (ccol0 >> r) & 1ull : (ccol1 >> (r - 64)) & 1ull);
-            if (lane == 0) {
-                fin_w[r] = wf;
-                fin_c[r] = cf;
-                win_piv[r] = 1;
-            }
+        if (!vm) continue;
+        int p = tt - __builtin_popcount(vm);
+#pragma unroll
+        for (int j = 0; j < RB_STRIP; ++j) {
+            if (!((vm >> j) & 1u)) continue;                          // uniform
+            const int r = prow_s[j], rlane = r & 63;
+            const u64 wsrc = r < 64 ? w[0] : w[1], dsrc = r < 64 ? d[0] : d[1];
+            const u64 P = ((u64)rl((unsigned int)(wsrc >> 32), rlane) << 32) | rl((unsigned int)wsrc, rlane);
+            const u64 Vp = (((u64)rl((unsigned int)(dsrc >> 32), rlane) << 32) | rl((unsigned int)dsrc, rlane)) ^ (1ull << p);
+            p += 1;
+            if (__builtin_amdgcn_inverse_ballot_w64(c0[j])) w[0] ^= P, d[0] ^= Vp;
+            if (__builtin_amdgcn_inverse_ballot_w64(c1[j])) w[1] ^= P, d[1] ^= Vp;
+            if (__builtin_amdgcn_inverse_ballot_w64(c2[j])) w[2] ^= P, d[2] ^= Vp;
         }
-        if (lane >= t && lane < tt) {
-            pword[lane] = my_pword;
-            csel[lane] = my_csel;
-            pbit[lane] = (int)my_pbit;
-            prow_l[lane] = win_row[my_prow];
-        }
-        CP[lane] = transpose64(ccol2, lane);                     // row j: the coefficients a row takes for having bit j
-        WP[lane] = transpose64(colw2, lane);                     // row j: what becomes of bit j
-        if (lane == 0) {
-            misc[0] = tt;
-            misc[1] = (int)(unsigned int)newbits;
-            misc[2] = (int)(unsigned int)(newbits >> 32);
-        }
+    }
+    // the new pivot rows as they stand at the end of the round
+    if ((piv0 >> lane) & 1ull) {
+        fin_w[lane] = w[0];
+        fin_d[lane] = d[0];
+        win_piv[lane] = 1;
+    }
+    if ((piv1 >> lane) & 1ull) {
+        fin_w[lane + 64] = w[1];
+        fin_d[lane + 64] = d[1];
+        win_piv[lane + 64] = 1;
+    }
+    if (lane >= t && lane < tt) {
+        pbit[lane] = (int)my_pbit;
+        prow_l[lane] = win_row[my_prow];
+    }
+    DP[lane] = d[2];                                                   // row j: the coefficients a row takes for having bit j
+    WP[lane] = w[2];                                                   // row j: what becomes of bit j
+    if (lane == 0) {
+        misc[0] = tt;
+        misc[1] = (int)(unsigned int)newbits;
+        misc[2] = (int)(unsigned int)(newbits >> 32);
+    }
 }
 
-// Byte tables of the probe rows: VT of their coefficients, TW of their words (only when another round follows).
+// Byte tables of the probe rows: VT of their coefficients (DP), TW of their words (only when another round follows).
 __device__ __forceinline__ void round_tables(int tid, const u64* CP, const u64* WP, u64* VT, u64* TW, bool again) {
     for (int idx = tid; idx < 2048; idx += RB_THREADS) {
         const int g = idx >> 8, vv = idx & 255;
@@ -365,9 +374,9 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
     // member: 0 = first panel of a pair (the matrix is up to date), 1 = second panel: the first panel's update has not been
     // applied yet (one trailing pass serves both), so this panel's column is brought up to date on the way in:
     // word ^= d_prev[row] . (column pw of the first panel's pivot-row snapshot), through a byte table
-    __shared__ u64 VT[2048];                                            // byte tables: of the probe rows' coefficients per round, of V at the end
+    __shared__ u64 VT[2048];                                            // byte tables of the probe rows' coefficients (per round)
     __shared__ u64 TW[2048];                                            // byte tables of the probe rows' words (rounds that are followed by another)
-    __shared__ u64 V[64], csel[64], pword[64], win_w[RB_WIN], win_c[RB_WIN], fin_w[RB_WIN], fin_c[RB_WIN], CP[64], WP[64];
+    __shared__ u64 win_w[RB_WIN], win_d[RB_WIN], fin_w[RB_WIN], fin_d[RB_WIN], DP[64], WP[64];
     __shared__ int win_row[RB_WIN], win_piv[RB_WIN], pbit[64], prow_l[64], wave_tot[RB_THREADS / 64], misc[4];
 
     const int64_t mat = blockIdx.x;
@@ -392,24 +401,24 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
     const u64* dprev = dprev_base + mat * m;
 
     // ---- 1. panel factorisation ------------------------------------------------------------------------------------------
-    u64 w[RPT], c[RPT];
+    u64 w[RPT], d[RPT];                                                 // panel word and coefficients (new = old ^ d . OLDPIV) of this lane's rows
     int slot[RPT];
     unsigned int usedmask = 0, usedmask0;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int64_t row = tid + (int64_t)RB_THREADS * k;
         w[k] = row < m ? a[row * ld + pw] : 0ull;
-        c[k] = 0;
+        d[k] = 0;
         if (row < m && used[row]) usedmask |= 1u << k;
     }
     if (t_prev > 0) {                                                  // uniform: the pair's first panel left an update behind
-        if (tid < 64) CP[tid] = tid < t_prev ? snapprev_base[(mat * 64 + tid) * ld + pw] : 0ull;
+        if (tid < 64) DP[tid] = tid < t_prev ? snapprev_base[(mat * 64 + tid) * ld + pw] : 0ull;
         __syncthreads();
         for (int idx = tid; idx < 2048; idx += RB_THREADS) {
             const int g = idx >> 8, vv = idx & 255;
             u64 x = 0;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) x ^= CP[8 * g + k] & (0ull - (u64)((vv >> k) & 1));
+            for (int k = 0; k < 8; ++k) x ^= DP[8 * g + k] & (0ull - (u64)((vv >> k) & 1));
             TW[idx] = x;
         }
         __syncthreads();
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
                     slot[k] = pos;
                     win_row[pos] = tid + RB_THREADS * k;
                     win_w[pos] = w[k];
-                    win_c[pos] = c[k];
+                    win_d[pos] = d[k];
                     win_piv[pos] = 0;
                 }
                 pos += 1;
@@ -465,23 +474,23 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
         __syncthreads();
         const int nwin = total < RB_WIN ? total : RB_WIN;
         if (wave == 0)
-            window_round(lane, nwin, t, rank, m, unresolved, win_w, win_c, win_row, win_piv, fin_w, fin_c, pword, csel, pbit, prow_l, CP, WP, misc);
+            window_round(lane, nwin, t, rank, m, unresolved, win_w, win_d, win_row, win_piv, fin_w, fin_d, pbit, prow_l, DP, WP, misc);
         __syncthreads();
         const int t_new = misc[0];
         const u64 newbits = ((u64)(unsigned int)misc[2] << 32) | (unsigned int)misc[1];
         // another round may follow (uniform): only then are the rows' words needed again
         const bool again = (unresolved & ~newbits) != 0 && t_new < 64 && rank + t_new < m;
-        round_tables(tid, CP, WP, VT, TW, again);
+        round_tables(tid, DP, WP, VT, TW, again);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
             if (slot[k] >= 0 && win_piv[slot[k]]) {                   // a new pivot row: as the wavefront left it
                 w[k] = fin_w[slot[k]];
-                c[k] = fin_c[slot[k]];
+                d[k] = fin_d[slot[k]];
                 usedmask |= 1u << k;
             } else {                                                  // every other row: linear in its word
                 const u64 w0 = w[k];
-                c[k] |= byte_lookup(VT, w0);
+                d[k] ^= byte_lookup(VT, w0);
                 if (again) w[k] = byte_lookup(TW, w0);
             }
         }
@@ -526,34 +535,11 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
         snap[idx] = a[(int64_t)prow_l[p] * ld + wd];
     }
 
-    // ---- 2. V (forward substitution in one wavefront), its byte tables, d_i = c_i . V ---------------------------------------
-    if (wave == 0) {
-        u64 v = lane < t ? 1ull << lane : 0ull;
-        const u64 cs = lane < t ? csel[lane] : 0ull;
-        for (int q = 0; q < t; ++q) {
-            const u64 vq = readlane64(v, q);
-            if ((cs >> q) & 1ull) v ^= vq;
-        }
-        V[lane] = v;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 2048; idx += RB_THREADS) {
-        const int g = idx >> 8, vv = idx & 255;
-        u64 x = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x ^= V[8 * g + k] & (0ull - (u64)((vv >> k) & 1));
-        VT[idx] = x;
-    }
-    __syncthreads();
+    // ---- 2. the coefficients are final as they are (window_round keeps them in terms of the pivot rows' snapshot)
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int64_t row = tid + (int64_t)RB_THREADS * k;
-        if (row < m) {
-            u64 d = 0;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) d ^= VT[g * 256 + (int)((c[k] >> (8 * g)) & 255ull)];
-            dout[row] = d;
-        }
+        if (row < m) dout[row] = d[k];
     }
 }
 
@@ -601,26 +587,23 @@ __global__ __launch_bounds__(256) void panel_snapshot_kernel(const u64* __restri
     for (int64_t wd = threadIdx.x; wd < ld; wd += blockDim.x) dst[wd] = src[wd];
 }
 
-// After the streamed panel kernel: the coefficients of every row (the last round's table applied to the row's word, unless the
-// panel kernel has settled the row: slot -2) and d_i = c_i . V, one row per lane on as many workgroups as there are rows for.
+// After the streamed panel kernel: the coefficients of every row the panel kernel has not settled itself (slot -2) take the last
+// round's probe-row table applied to the row's word, one row per lane on as many workgroups as there are rows for.
 __global__ __launch_bounds__(1024) void panel_coeff_kernel(int64_t m, const RrefState* __restrict__ states,
                                                            const u64* __restrict__ wpan_base, const u64* __restrict__ cco_base,
                                                            const int32_t* __restrict__ slot_base, const u64* __restrict__ tabs_base,
                                                            u64* __restrict__ d_base) {
-    __shared__ u64 TC[2048], TV[2048];
+    __shared__ u64 TC[2048];
     const int64_t mat = blockIdx.y;
     const RrefState st = states[mat];
     if (st.t == 0) return;
-    for (int idx = threadIdx.x; idx < 2048; idx += 1024) {
-        TC[idx] = st.pending ? tabs_base[mat * 4096 + idx] : 0ull;
-        TV[idx] = tabs_base[mat * 4096 + 2048 + idx];
-    }
+    for (int idx = threadIdx.x; idx < 2048; idx += 1024) TC[idx] = st.pending ? tabs_base[mat * 2048 + idx] : 0ull;
     __syncthreads();
     const int64_t row = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     if (row >= m) return;
-    u64 c = cco_base[mat * m + row];
-    if (st.pending && slot_base[mat * m + row] != -2) c |= byte_lookup(TC, wpan_base[mat * m + row]);
-    d_base[mat * m + row] = byte_lookup(TV, c);
+    u64 d = cco_base[mat * m + row];
+    if (st.pending && slot_base[mat * m + row] != -2) d ^= byte_lookup(TC, wpan_base[mat * m + row]);
+    d_base[mat * m + row] = d;
 }
 
 // The same panel step for matrices with more than 8192 rows: rows are streamed instead of held in registers.  The
@@ -635,7 +618,7 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
                                                                       u64* __restrict__ tabs_base, int member,
                                                                       const u64* __restrict__ dprev_base, u64* __restrict__ fix_base) {
     __shared__ u64 VT[2048], TW[2048];
-    __shared__ u64 V[64], csel[64], pword[64], win_w[RB_WIN], win_c[RB_WIN], fin_w[RB_WIN], fin_c[RB_WIN], CP[64], WP[64];
+    __shared__ u64 win_w[RB_WIN], win_d[RB_WIN], fin_w[RB_WIN], fin_d[RB_WIN], DP[64], WP[64];
     __shared__ int win_row[RB_WIN], win_piv[RB_WIN], pbit[64], prow_l[64], misc[4];
     __shared__ int win_count;
 
@@ -678,7 +661,7 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
                     slot_of[row] = pos;
                     win_row[pos] = (int)row;
                     win_w[pos] = wpan[row];
-                    win_c[pos] = cco[row];
+                    win_d[pos] = cco[row];
                     win_piv[pos] = 0;
                 }
             }
@@ -689,23 +672,23 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
         if (total == 0) break;
         const int nwin = total < RB_WIN ? total : RB_WIN;
         if (wave == 0)
-            window_round(lane, nwin, t, rank, m, unresolved, win_w, win_c, win_row, win_piv, fin_w, fin_c, pword, csel, pbit, prow_l, CP, WP, misc);
+            window_round(lane, nwin, t, rank, m, unresolved, win_w, win_d, win_row, win_piv, fin_w, fin_d, pbit, prow_l, DP, WP, misc);
         __syncthreads();
         const int t_new = misc[0];
         const u64 newbits = ((u64)(unsigned int)misc[2] << 32) | (unsigned int)misc[1];
         const bool again = (unresolved & ~newbits) != 0 && t_new < 64 && rank + t_new < m;    // uniform: another round may follow
-        round_tables(tid, CP, WP, VT, TW, again);
+        round_tables(tid, DP, WP, VT, TW, again);
         __syncthreads();
         if (!again) {
             // the last round: only its pivot rows are settled here (coefficients final, marked -2); every other row takes its
             // coefficients from the probe-row table in panel_coeff_kernel, on the whole chip instead of in this one workgroup
             if (tid < nwin && win_piv[tid]) {
                 const int row = win_row[tid];
-                cco[row] = fin_c[tid];
+                cco[row] = fin_d[tid];
                 used[row] = 1;
                 slot_of[row] = -2;
             }
-            for (int idx = tid; idx < 2048; idx += RB_THREADS) tabs_base[mat * 4096 + idx] = VT[idx];
+            for (int idx = tid; idx < 2048; idx += RB_THREADS) tabs_base[mat * 2048 + idx] = VT[idx];
             pending = 1;
             unresolved &= ~newbits;
             t = t_new;
@@ -717,11 +700,11 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
             if (sl >= 0) slot_of[row] = -1;
             if (sl >= 0 && win_piv[sl]) {                             // a new pivot row: as the wavefront left it
                 wpan[row] = fin_w[sl];
-                cco[row] = fin_c[sl];
+                cco[row] = fin_d[sl];
                 used[row] = 1;
             } else {                                                  // every other row: linear in its word
                 const u64 w0 = wpan[row];
-                cco[row] |= byte_lookup(VT, w0);
+                cco[row] ^= byte_lookup(VT, w0);
                 wpan[row] = byte_lookup(TW, w0);
             }
         }
@@ -754,25 +737,6 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
         if (pivots) pivots[rank + pos] = pw * 64 + pbit[lane];
     }
     if (tid < t) prow_base[mat * 64 + tid] = prow_l[tid];               // for panel_snapshot_kernel, which follows
-    if (wave == 0) {
-        u64 v = lane < t ? 1ull << lane : 0ull;
-        const u64 cs = lane < t ? csel[lane] : 0ull;
-        for (int q = 0; q < t; ++q) {
-            const u64 vq = readlane64(v, q);
-            if ((cs >> q) & 1ull) v ^= vq;
-        }
-        V[lane] = v;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 2048; idx += RB_THREADS) {
-        const int g = idx >> 8, vv = idx & 255;
-        u64 x = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x ^= V[8 * g + k] & (0ull - (u64)((vv >> k) & 1));
-        VT[idx] = x;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 2048; idx += RB_THREADS) tabs_base[mat * 4096 + 2048 + idx] = VT[idx];      // d_i = c_i . V: panel_coeff_kernel
 }
 
 // grid (row blocks, column chunks of 64 words, matrices), block 1024, 128 KiB dynamic LDS.
@@ -1389,7 +1353,7 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
     const size_t dbytes = al((size_t)batch * m * 8), nbytes = al((size_t)batch * 64 * ld * 8);
     const bool stream = rpt > 8;
     const size_t fbytes = al((size_t)batch * 64 * 8);
-    const size_t xbytes = stream ? 2 * dbytes + al((size_t)batch * m * 4) + al((size_t)batch * 64 * 4) + (size_t)batch * 4096 * 8 : 0;
+    const size_t xbytes = stream ? 2 * dbytes + al((size_t)batch * m * 4) + al((size_t)batch * 64 * 4) + (size_t)batch * 2048 * 8 : 0;
     GF2_TRY(gf2_ws_reserve(ctx, 1, abytes + pbytes + sbytes + ubytes + 2 * dbytes + 2 * nbytes + fbytes + xbytes));
     char* q = (char*)ctx->ws[1];
     u64* tmp = (u64*)q; q += abytes;
