@@ -228,111 +228,80 @@ __device__ __forceinline__ u64 transpose64(u64 x, int lane) {
 // ends with the word and the coefficients any row gets for having bit j, and elimination is linear in the row, so every row
 // outside the window is finished with two table lookups instead of replaying the pivots.
 //
-// Lane l holds window rows l and l + 64 and probe row e_l (word and coefficients in registers).  The columns go in strips of
-// RB_STRIP:
-//   1. the strip's columns become bit vectors over the 192 rows (three ballots each) in SCALAR registers, and the strip is
-//      eliminated there: a pivot step is a find-first, and for each later column of the strip in which the pivot row has a bit,
-//      three 64-bit XORs -- no trip between the vector and the scalar unit per pivot (the column-sliced round before this one
-//      spent its 280 ns per pivot on six of them).  What is left of column j afterwards is its TAKE MASK: the rows that take
-//      pivot j.
-//   2. the strip's pivots are applied to the words and coefficients in order: the pivot row (up to date when its turn comes,
-//      because the earlier pivots of the strip have been applied) is broadcast by readlane and XORed into the rows of its take
-//      mask, which serves as the lane mask of the select as it stands.
-#define RB_STRIP 4                                  // columns per strip (8: the 24 column vectors and the kernel's own scalars spill)
+// Lane l holds window rows l and l + 64 and probe row e_l (word and coefficients in registers).  A pivot step: three ballots
+// give column b over the 192 rows; the first window row that has the bit and is no pivot yet becomes the pivot; its word and
+// coefficients come by readlane; the rows of the column (but the pivot row itself) XOR them in, the ballots serving as the lane
+// masks of the selects as they stand.  ~150 ns per pivot.  (Rounds 1 and 2 went through a row-sliced round with ballots over the
+// rows and five readlanes per pivot, and a column-sliced one -- lane = panel column, twelve v_writelane per pivot -- at 325 and
+// 280 ns; eliminating strips of 2, 4 or 8 columns as bit vectors in scalar registers first and applying their pivots afterwards
+// is no faster: 0.99, 1.03, 1.13 ms for the 2048 x 4096 matrix against 0.98.)
 __device__ __forceinline__ void window_round(int lane, int nwin, int t, int64_t rank, int64_t m, u64 unresolved, const u64* win_w,
                                              const u64* win_d, const int* win_row, int* win_piv, u64* fin_w, u64* fin_d,
                                              int* pbit, int* prow_l, u64* DP, u64* WP, int* misc) {
-    u64 w[3], d[3];
-    w[0] = lane < nwin ? win_w[lane] : 0ull;
-    w[1] = lane + 64 < nwin ? win_w[lane + 64] : 0ull;
-    w[2] = 1ull << lane;
-    d[0] = (t > 0 && lane < nwin) ? win_d[lane] : 0ull;               // uniform: coefficients of earlier rounds
-    d[1] = (t > 0 && lane + 64 < nwin) ? win_d[lane + 64] : 0ull;
-    d[2] = 0ull;
+    u64 w0 = lane < nwin ? win_w[lane] : 0ull, w1 = lane + 64 < nwin ? win_w[lane + 64] : 0ull, w2 = 1ull << lane;
+    u64 d0 = (t > 0 && lane < nwin) ? win_d[lane] : 0ull;             // uniform: coefficients of earlier rounds
+    u64 d1 = (t > 0 && lane + 64 < nwin) ? win_d[lane + 64] : 0ull, d2 = 0ull;
     u64 piv0 = 0, piv1 = 0, newbits = 0;                               // (uniform) window rows that are pivots; columns resolved here
     unsigned int my_pbit = 0, my_prow = 0;                             // lane p: pivot p's column and window row
     int tt = t;
-    auto rl = [](unsigned int v, int src) { return (unsigned int)__builtin_amdgcn_readlane((int)v, src); };
-#pragma unroll 1
-    for (int s = 0; s < 64 / RB_STRIP; ++s) {
-        const unsigned int sm = (unsigned int)(unresolved >> (RB_STRIP * s)) & ((1u << RB_STRIP) - 1u);
-        if (!sm || tt >= 64 || rank + tt >= m) continue;              // uniform
-        const unsigned int y0 = (unsigned int)(w[0] >> (RB_STRIP * s)), y1 = (unsigned int)(w[1] >> (RB_STRIP * s)), y2 = (unsigned int)(w[2] >> (RB_STRIP * s));
-        u64 c0[RB_STRIP], c1[RB_STRIP], c2[RB_STRIP];                                       // column j of the strip: window rows 0..63, 64..127, probe rows
-#pragma unroll
-        for (int j = 0; j < RB_STRIP; ++j) {
-            c0[j] = __ballot((y0 >> j) & 1u);
-            c1[j] = __ballot((y1 >> j) & 1u);
-            c2[j] = __ballot((y2 >> j) & 1u);
+    auto rl64 = [](u64 v, int src) {
+        return ((u64)(unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), src) << 32) |
+               (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, src);
+    };
+    u64 todo = unresolved;
+    while (todo && tt < 64 && rank + tt < m) {
+        const int b = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        u64 c0 = __ballot((w0 >> b) & 1ull), c1 = __ballot((w1 >> b) & 1ull);                // column b: window rows 0..63, 64..127
+        const u64 cand0 = c0 & ~piv0, cand1 = c1 & ~piv1;
+        if (!(cand0 | cand1)) continue;                               // no pivot for this column inside the window
+        const u64 c2 = __ballot((w2 >> b) & 1ull);                     // ... and the probe rows
+        int r;
+        u64 P, V;
+        if (cand0) {                                                   // uniform; the usual case: a pivot among the first 64 window rows
+            r = __ffsll((long long)cand0) - 1;
+            piv0 |= 1ull << r;
+            c0 &= ~(1ull << r);                                        // the pivot row does not take itself
+            P = rl64(w0, r);
+            V = rl64(d0, r);
+        } else {
+            r = __ffsll((long long)cand1) - 1;
+            piv1 |= 1ull << r;
+            c1 &= ~(1ull << r);
+            P = rl64(w1, r);
+            V = rl64(d1, r);
+            r += 64;
         }
-        int prow_s[RB_STRIP];
-        unsigned int vm = 0;                                           // columns of the strip that found a pivot
-#pragma unroll
-        for (int j = 0; j < RB_STRIP; ++j) {
-            prow_s[j] = 0;
-            if (!((sm >> j) & 1u) || tt >= 64 || rank + tt >= m) continue;
-            const u64 cand0 = c0[j] & ~piv0, cand1 = c1[j] & ~piv1;
-            if (!(cand0 | cand1)) continue;                           // no pivot for this column inside the window
-            int r;
-            if (cand0) {
-                r = __ffsll((long long)cand0) - 1;
-                piv0 |= 1ull << r;
-                c0[j] &= ~(1ull << r);                                // the pivot row does not take itself
-            } else {
-                r = 64 + __ffsll((long long)cand1) - 1;
-                piv1 |= 1ull << (r - 64);
-                c1[j] &= ~(1ull << (r - 64));
-            }
-#pragma unroll
-            for (int j2 = j + 1; j2 < RB_STRIP; ++j2) {                       // the columns before j are done with: zero in the pivot row
-                const u64 src = r < 64 ? c0[j2] : c1[j2];
-                if ((src >> (r & 63)) & 1ull) {
-                    c0[j2] ^= c0[j];
-                    c1[j2] ^= c1[j];
-                    c2[j2] ^= c2[j];
-                }
-            }
-            prow_s[j] = r;
-            vm |= 1u << j;
-            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0"
-                         : "+v"(my_pbit), "+v"(my_prow)
-                         : "s"(tt), "s"((unsigned int)(RB_STRIP * s + j)), "s"((unsigned int)r)
-                         : "m0");
-            newbits |= 1ull << (RB_STRIP * s + j);
-            tt += 1;
-        }
-        if (!vm) continue;
-        int p = tt - __builtin_popcount(vm);
-#pragma unroll
-        for (int j = 0; j < RB_STRIP; ++j) {
-            if (!((vm >> j) & 1u)) continue;                          // uniform
-            const int r = prow_s[j], rlane = r & 63;
-            const u64 wsrc = r < 64 ? w[0] : w[1], dsrc = r < 64 ? d[0] : d[1];
-            const u64 P = ((u64)rl((unsigned int)(wsrc >> 32), rlane) << 32) | rl((unsigned int)wsrc, rlane);
-            const u64 Vp = (((u64)rl((unsigned int)(dsrc >> 32), rlane) << 32) | rl((unsigned int)dsrc, rlane)) ^ (1ull << p);
-            p += 1;
-            if (__builtin_amdgcn_inverse_ballot_w64(c0[j])) w[0] ^= P, d[0] ^= Vp;
-            if (__builtin_amdgcn_inverse_ballot_w64(c1[j])) w[1] ^= P, d[1] ^= Vp;
-            if (__builtin_amdgcn_inverse_ballot_w64(c2[j])) w[2] ^= P, d[2] ^= Vp;
-        }
+        V ^= 1ull << tt;
+        if (__builtin_amdgcn_inverse_ballot_w64(c0)) w0 ^= P, d0 ^= V;
+        if (__builtin_amdgcn_inverse_ballot_w64(c1)) w1 ^= P, d1 ^= V;
+        if (__builtin_amdgcn_inverse_ballot_w64(c2)) w2 ^= P, d2 ^= V;
+        // lane tt keeps the pivot's column and window row (v_writelane_b32 with the lane in M0: the compiler has no builtin for
+        // it and does not use M0 in these kernels)
+        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0"
+                     : "+v"(my_pbit), "+v"(my_prow)
+                     : "s"(tt), "s"((unsigned int)b), "s"((unsigned int)r)
+                     : "m0");
+        newbits |= 1ull << b;
+        tt += 1;
     }
     // the new pivot rows as they stand at the end of the round
     if ((piv0 >> lane) & 1ull) {
-        fin_w[lane] = w[0];
-        fin_d[lane] = d[0];
+        fin_w[lane] = w0;
+        fin_d[lane] = d0;
         win_piv[lane] = 1;
     }
     if ((piv1 >> lane) & 1ull) {
-        fin_w[lane + 64] = w[1];
-        fin_d[lane + 64] = d[1];
+        fin_w[lane + 64] = w1;
+        fin_d[lane + 64] = d1;
         win_piv[lane + 64] = 1;
     }
     if (lane >= t && lane < tt) {
         pbit[lane] = (int)my_pbit;
         prow_l[lane] = win_row[my_prow];
     }
-    DP[lane] = d[2];                                                   // row j: the coefficients a row takes for having bit j
-    WP[lane] = w[2];                                                   // row j: what becomes of bit j
+    DP[lane] = d2;                                                     // row j: the coefficients a row takes for having bit j
+    WP[lane] = w2;                                                     // row j: what becomes of bit j
     if (lane == 0) {
         misc[0] = tt;
         misc[1] = (int)(unsigned int)newbits;
