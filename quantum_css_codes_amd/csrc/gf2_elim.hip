@@ -38,7 +38,7 @@ struct RrefState {                                  // per matrix, in global scr
     int64_t zero_lo, zero_hi;                       // rows [zero_lo, zero_hi) are rebuilt from zero (normalisation)
     int32_t t;                                      // pivots of the current panel
     int32_t stalled;                                // normalisation: the panel stopped early, a single step must follow
-    int32_t pending;                                // streamed RREF panel: the last round's table waits in tabs (panel_coeff_kernel)
+    int32_t pending;                                // streamed RREF panel: the last round's table waits in tabs (panel_finish_kernel)
     int32_t tg[2];                                  // RREF: pivots of the two panels of the current pair (one trailing update per pair)
 };
 
@@ -513,9 +513,9 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_kernel(u64* __restrict_
 }
 
 
-// Two chores of the streamed panel step (m > 8192) that ONE workgroup is slow at and the whole chip does in microseconds:
-// the panel's column (one word out of every row: strided by the row pitch) into the contiguous round-0 state, and, after the
-// panel, the snapshot of its pivot rows (64 rows of ld words).
+// A chore of the streamed panel step (m > 8192) that ONE workgroup is slow at and the whole chip does in microseconds: the
+// panel's column (one word out of every row: strided by the row pitch) into the contiguous round-0 state.  (The other two --
+// the rows' coefficients and the snapshot of the pivot rows -- are panel_finish_kernel.)
 __global__ __launch_bounds__(256) void panel_column_kernel(const u64* __restrict__ base, int64_t m, int64_t ld, int64_t pw,
                                                            u64* __restrict__ wpan_base, u64* __restrict__ cco_base,
                                                            int32_t* __restrict__ slot_base, int member,
@@ -545,27 +545,27 @@ __global__ __launch_bounds__(256) void panel_column_kernel(const u64* __restrict
     slot_base[mat * m + row] = -1;
 }
 
-__global__ __launch_bounds__(256) void panel_snapshot_kernel(const u64* __restrict__ base, int64_t m, int64_t ld,
-                                                             const RrefState* __restrict__ states, const int32_t* __restrict__ prow_base,
-                                                             u64* __restrict__ snap_base) {
-    const int64_t mat = blockIdx.y;
-    const int p = blockIdx.x;
-    if (p >= states[mat].t) return;
-    const u64* src = base + (mat * m + prow_base[mat * 64 + p]) * ld;
-    u64* dst = snap_base + (mat * 64 + p) * ld;
-    for (int64_t wd = threadIdx.x; wd < ld; wd += blockDim.x) dst[wd] = src[wd];
-}
-
-// After the streamed panel kernel: the coefficients of every row the panel kernel has not settled itself (slot -2) take the last
-// round's probe-row table applied to the row's word, one row per lane on as many workgroups as there are rows for.
-__global__ __launch_bounds__(1024) void panel_coeff_kernel(int64_t m, const RrefState* __restrict__ states,
-                                                           const u64* __restrict__ wpan_base, const u64* __restrict__ cco_base,
-                                                           const int32_t* __restrict__ slot_base, const u64* __restrict__ tabs_base,
-                                                           u64* __restrict__ d_base) {
+// After the streamed panel kernel, one launch for its two leftovers: (1) the coefficients of every row the panel kernel has not
+// settled itself (slot -2) take the last round's probe-row table applied to the row's word, one row per lane on as many
+// workgroups as there are rows for; (2) the last 64 workgroups copy the panel's pivot rows (64 rows of ld words) to the snapshot.
+__global__ __launch_bounds__(1024) void panel_finish_kernel(const u64* __restrict__ base, int64_t m, int64_t ld,
+                                                            const RrefState* __restrict__ states, const u64* __restrict__ wpan_base,
+                                                            const u64* __restrict__ cco_base, const int32_t* __restrict__ slot_base,
+                                                            const u64* __restrict__ tabs_base, u64* __restrict__ d_base,
+                                                            const int32_t* __restrict__ prow_base, u64* __restrict__ snap_base) {
     __shared__ u64 TC[2048];
     const int64_t mat = blockIdx.y;
     const RrefState st = states[mat];
     if (st.t == 0) return;
+    const int coeff_blocks = (int)gridDim.x - 64;
+    if ((int)blockIdx.x >= coeff_blocks) {
+        const int p = (int)blockIdx.x - coeff_blocks;
+        if (p >= st.t) return;
+        const u64* src = base + (mat * m + prow_base[mat * 64 + p]) * ld;
+        u64* dst = snap_base + (mat * 64 + p) * ld;
+        for (int64_t wd = threadIdx.x; wd < ld; wd += blockDim.x) dst[wd] = src[wd];
+        return;
+    }
     for (int idx = threadIdx.x; idx < 2048; idx += 1024) TC[idx] = st.pending ? tabs_base[mat * 2048 + idx] : 0ull;
     __syncthreads();
     const int64_t row = (int64_t)blockIdx.x * 1024 + threadIdx.x;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
     const int64_t cols_here = n - pw * 64;
     const u64 panel_cols = cols_here >= 64 ? ~0ull : ((1ull << cols_here) - 1ull);
     u64 unresolved = panel_cols;
-    int t = 0, pending = 0;                                            // pending: the last round's rows are left to panel_coeff_kernel
+    int t = 0, pending = 0;                                            // pending: the last round's rows are left to panel_finish_kernel
     // round 0 state (wpan = the panel's column, cco = 0, slot_of = -1): panel_column_kernel, launched before this one
     while (unresolved && t < 64 && rank + t < m) {
         if (tid == 0) win_count = 0;
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
         __syncthreads();
         if (!again) {
             // the last round: only its pivot rows are settled here (coefficients final, marked -2); every other row takes its
-            // coefficients from the probe-row table in panel_coeff_kernel, on the whole chip instead of in this one workgroup
+            // coefficients from the probe-row table in panel_finish_kernel, on the whole chip instead of in this one workgroup
             if (tid < nwin && win_piv[tid]) {
                 const int row = win_row[tid];
                 cco[row] = fin_d[tid];
@@ -705,7 +705,7 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
         pivrow[rank + pos] = prow_l[lane];
         if (pivots) pivots[rank + pos] = pw * 64 + pbit[lane];
     }
-    if (tid < t) prow_base[mat * 64 + tid] = prow_l[tid];               // for panel_snapshot_kernel, which follows
+    if (tid < t) prow_base[mat * 64 + tid] = prow_l[tid];               // for panel_finish_kernel, which follows
 }
 
 // grid (row blocks, column chunks of 64 words, matrices), block 1024, 128 KiB dynamic LDS.
@@ -1379,10 +1379,9 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
             hipLaunchKernelGGL(rref_panel_stream_kernel, dim3((unsigned)batch), dim3(RB_THREADS), 0, ctx->stream, a_dev, m, n,
                                ld, pw, pivots_dev, cap, pivrow, states, used, dco, panel_rows, wpan, cco, slot_of, tabs, member,
                                (const u64*)dco2[0], fix);
-            hipLaunchKernelGGL(panel_coeff_kernel, dim3((unsigned)gf2_cdiv(m, 1024), (unsigned)batch), dim3(1024), 0, ctx->stream, m,
-                               (const RrefState*)states, (const u64*)wpan, (const u64*)cco, (const int32_t*)slot_of, (const u64*)tabs, dco);
-            hipLaunchKernelGGL(panel_snapshot_kernel, dim3(64, (unsigned)batch), dim3(256), 0, ctx->stream, (const u64*)a_dev, m, ld,
-                               (const RrefState*)states, (const int32_t*)panel_rows, snap);
+            hipLaunchKernelGGL(panel_finish_kernel, dim3((unsigned)gf2_cdiv(m, 1024) + 64, (unsigned)batch), dim3(1024), 0, ctx->stream,
+                               (const u64*)a_dev, m, ld, (const RrefState*)states, (const u64*)wpan, (const u64*)cco,
+                               (const int32_t*)slot_of, (const u64*)tabs, dco, (const int32_t*)panel_rows, snap);
         } else if (rpt <= 1)
             GF2_RP_LAUNCH(1);
         else if (rpt <= 2)
