@@ -174,14 +174,13 @@ __global__ __launch_bounds__(ELIM_THREADS) void eliminate_kernel(u64* __restrict
 //
 //   rref_panel_kernel (one workgroup per matrix)
 //     1. panel factorisation.  A lane owns rows tid, tid+1024, .. and holds their panel words w_i and 64-bit
-//        coefficients c_i.  Up to 128 unused rows with a bit in a still-unresolved panel column form a window in LDS;
-//        ONE wavefront runs Gauss-Jordan on the window with __ballot / readlane only (no barriers), choosing a pivot
-//        row per column and recording (bit, row, word-when-chosen, coefficients-when-chosen).  Every other row then
-//        replays those pivots on its own word in registers.  If a column found no pivot inside the window but rows
-//        outside it still carry the bit, another round follows; for random matrices one round resolves 64 columns.
-//        With P_p the pivot row's value when chosen, P = V . OLDPIV (V from the coefficients-when-chosen) and
-//        new_i = old_i ^ (c_i . V) . OLDPIV, where OLDPIV are the chosen rows as they stand at the start of the panel.
-//     2. d_i = c_i . V through byte tables of V (LDS); d_i and a snapshot of the OLDPIV rows go to global scratch.
+//        coefficients d_i (new_i = old_i ^ d_i . OLDPIV, OLDPIV = the chosen pivot rows as they stand at the start of
+//        the panel).  Up to 128 unused rows with a bit in a still-unresolved panel column form a window in LDS; ONE wavefront
+//        runs Gauss-Jordan on the window and on 64 probe rows e_j with __ballot / readlane only (no barriers: window_round).
+//        Every other row is then finished with two byte-table lookups made from the probe rows (elimination is linear in the
+//        row).  If a column found no pivot inside the window but rows outside it still carry the bit, another round follows;
+//        for random matrices one round resolves 64 columns.
+//     2. d_i and a snapshot of the OLDPIV rows go to global scratch.
 //   rref_update_pair_kernel (grid: row blocks x 32-word column chunks x matrices -- the whole GPU), once per PAIR of panels
 //     3. A[i] ^= dA_i . OLDPIV_A ^ dB_i . OLDPIV_B', Method of Four Russians: for each group of 4 pivots of either panel the 16
 //        XOR combinations of their rows sit in LDS (2 x 64 KiB); a wavefront moves two rows at a time (32 lanes = 256
