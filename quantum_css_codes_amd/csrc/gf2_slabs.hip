@@ -1348,98 +1348,131 @@ static int launch_redo(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
     return GF2_OK;
 }
 
-// Weight histogram of batch resident sample-major errors (hist: r + 1 bins, accumulated into).
-int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde,
-                       uint64_t* hist_dev, hipStream_t stream, int ws_slot) {
+// One call's worth of constants of the pipeline on one check: workspace pieces, kernel variant, columns left to the redo pass.
+struct SlabCall {
+    const gf2_check* ck;
+    const uint64_t* e_dev;
+    uint64_t* hist_dev;
+    int64_t batch, lde, pass, pad;
+    u32x4* rec;
+    unsigned short* pw;
+    unsigned int* redo_count;
+    unsigned int* redo_list;
+    bool fast, fold;
+    StrayPlan stray;
+};
+
+static int slab_call_setup(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde, uint64_t* hist_dev,
+                           int ws_slot, SlabCall* c) {
     GF2_TRY(slab_lds_optin(ctx));
-    const int64_t pass = slab_pass(ctx, batch);
-    const int64_t pad = gf2_cdiv(pass, 64) * 64;
+    c->ck = ck;
+    c->e_dev = e_dev;
+    c->hist_dev = hist_dev;
+    c->batch = batch;
+    c->lde = lde;
+    c->pass = slab_pass(ctx, batch);
+    c->pad = gf2_cdiv(c->pass, 64) * 64;
     // records and partial weights of one pass; the redo list is the call's (one redo launch at the end)
-    const size_t rec_bytes = (size_t)pad * 64, pw_bytes = (size_t)ck->nslabs512 * pad * 2;
-    const size_t redo_bytes = (size_t)(batch > pad ? gf2_cdiv(batch, 64) * 64 : pad) * 4 + 256;
+    const size_t rec_bytes = (size_t)c->pad * 64, pw_bytes = (size_t)ck->nslabs512 * c->pad * 2;
+    const size_t redo_bytes = (size_t)(batch > c->pad ? gf2_cdiv(batch, 64) * 64 : c->pad) * 4 + 256;
     GF2_TRY(gf2_ws_reserve(ctx, ws_slot, rec_bytes + pw_bytes + redo_bytes));
-    u32x4* rec = (u32x4*)ctx->ws[ws_slot];
-    unsigned short* pw = (unsigned short*)((char*)ctx->ws[ws_slot] + rec_bytes);
-    unsigned int* redo_count = (unsigned int*)((char*)ctx->ws[ws_slot] + rec_bytes + pw_bytes);
-    unsigned int* redo_list = redo_count + 64;
+    c->rec = (u32x4*)ctx->ws[ws_slot];
+    c->pw = (unsigned short*)((char*)ctx->ws[ws_slot] + rec_bytes);
+    c->redo_count = (unsigned int*)((char*)ctx->ws[ws_slot] + rec_bytes + pw_bytes);
+    c->redo_list = c->redo_count + 64;
     // the hand-scheduled gather kernel needs every slab's identity words to be whole 16-byte pieces inside the row
     const int64_t first_dw = ck->ident_off >= 0 ? ck->ident_off >> 5 : 0;
-    const bool fast = ck->ident_off >= 0 && (lde & 1) == 0 && (reinterpret_cast<uintptr_t>(e_dev) & 15) == 0 &&
-                      (first_dw & 3) == 0 && first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) <= lde * 2 &&
-                      !gf2_flag(ctx, GF2_F_GATHER_GENERIC);
-    StrayPlan stray = {0, 0, {0, 0}};
-    if (fast) stray = plan_stray(ctx, ck);
+    c->fast = ck->ident_off >= 0 && (lde & 1) == 0 && (reinterpret_cast<uintptr_t>(e_dev) & 15) == 0 && (first_dw & 3) == 0 &&
+              first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) <= lde * 2 && !gf2_flag(ctx, GF2_F_GATHER_GENERIC);
+    const StrayPlan none = {0, 0, {0, 0}};
+    c->stray = c->fast ? plan_stray(ctx, ck) : none;
     // GF2_F_COMBINE_FOLDED: between two passes of a call the combine step rides in the next pass' compact kernel (its first
     // instructions, before any of its own loads) -- 14 launches fewer per call of 8 passes.  Built because the small kernels sit
     // on the stream's critical path and are stretched by the other stream's big ones; measured: no change on two streams, 5 %
     // slower on one (1280 workgroups' worth of histogram atomics instead of 128: profiles/r02_sweep_fold.log).  Off by default.
-    const bool fold = gf2_flag(ctx, GF2_F_COMBINE_FOLDED) && !gf2_flag(ctx, GF2_F_DIAG_CLOCKS);
-    GF2_HIP(hipMemsetAsync(redo_count, 0, 4, stream));
-    int64_t prev_first = 0, prev_count = 0;
-    for (int64_t first = 0; first < batch; first += pass) {
-        const int64_t count = batch - first < pass ? batch - first : pass;
-        const uint64_t* e = e_dev + first * lde;
+    c->fold = gf2_flag(ctx, GF2_F_COMBINE_FOLDED) && !gf2_flag(ctx, GF2_F_DIAG_CLOCKS);
+    return GF2_OK;
+}
+
+// The compact kernel of the pass that starts at sample `first` (with the previous pass' combine step in it when folded).
+static int launch_compact(gf2_ctx* ctx, const SlabCall& c, int64_t first, hipStream_t stream, u64* clk_dev) {
+    const gf2_check* ck = c.ck;
+    const int64_t count = c.batch - first < c.pass ? c.batch - first : c.pass;
+    CompactArgs ca;
+    ca.clk = clk_dev;
+    ca.e = (const u64*)(c.e_dev + first * c.lde);
+    ca.ht = ck->ht_dev;
+    ca.rec = c.rec;
+    ca.hist = (u64*)c.hist_dev;
+    ca.batch = count;
+    ca.lde = c.lde;
+    ca.r = (int)ck->r;
+    ca.n = (int)ck->n;
+    ca.ident_off = (int)ck->ident_off;
+    ca.null_ord = ck->slab_null;
+    ca.skip_words = c.stray.skip_words;
+    ca.cmb_pw = c.fold && first > 0 ? c.pw : nullptr;
+    ca.cmb_positions = c.pad;                                          // (every pass before the last is a full one)
+    ca.cmb_pad = c.pad;
+    ca.cmb_sample0 = (unsigned int)(first - c.pass);
+    ca.cmb_nslabs = ck->nslabs512;
+    ca.cmb_nbins = (int)ck->r + 1;
+    ca.redo_count = c.redo_count;
+    ca.redo_list = c.redo_list;
+    int64_t cblocks = gf2_cdiv(gf2_cdiv(count, 64), CMP_WAVES);
+    // rounds per sub-pass: ceil(8 * words with non-identity columns / 64); workgroups per CU as the variant's registers allow
+    const int rounds = (CMP_SUB * non_identity_words(ck, c.stray.skip_words) + 63) / 64;
+    const int per_cu = rounds <= 4 ? 5 : (rounds <= 5 ? 4 : 3);
+    if (cblocks > (int64_t)ctx->num_cus * per_cu) cblocks = (int64_t)ctx->num_cus * per_cu;
+    const dim3 cgrid((unsigned)cblocks), cblock(CMP_THREADS);
+    if (rounds <= 4)
+        hipLaunchKernelGGL(slab_compact_kernel<4>, cgrid, cblock, 0, stream, ca);
+    else if (rounds <= 5)
+        hipLaunchKernelGGL(slab_compact_kernel<5>, cgrid, cblock, 0, stream, ca);
+    else if (rounds <= 6)
+        hipLaunchKernelGGL(slab_compact_kernel<6>, cgrid, cblock, 0, stream, ca);
+    else
+        hipLaunchKernelGGL(slab_compact_kernel<8>, cgrid, cblock, 0, stream, ca);
+    GF2_HIP(hipGetLastError());
+    return GF2_OK;
+}
+
+// gather and (unless it rides in the next compact kernel) combine of the pass that starts at `first`.
+static int launch_rest_of_pass(gf2_ctx* ctx, const SlabCall& c, int64_t first, hipStream_t stream, u64* clk_dev) {
+    const int64_t count = c.batch - first < c.pass ? c.batch - first : c.pass;
+    GF2_TRY(launch_gather(ctx, c.ck, c.e_dev + first * c.lde, c.rec, c.pw, count, c.pad, c.lde, c.fast, c.stray, stream, clk_dev));
+    if (!c.fold || first + c.pass >= c.batch)
+        GF2_TRY(launch_combine(ctx, c.ck, c.pw, c.redo_count, c.redo_list, count, c.pad, (unsigned int)first, c.hist_dev, stream, clk_dev));
+    return GF2_OK;
+}
+
+// Weight histogram of batch resident sample-major errors (hist: r + 1 bins, accumulated into).
+int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde,
+                       uint64_t* hist_dev, hipStream_t stream, int ws_slot) {
+    SlabCall c;
+    GF2_TRY(slab_call_setup(ctx, ck, e_dev, batch, lde, hist_dev, ws_slot, &c));
+    GF2_HIP(hipMemsetAsync(c.redo_count, 0, 4, stream));
+    for (int64_t first = 0; first < batch; first += c.pass) {
         u64* clk_dev = nullptr;
         if (gf2_flag(ctx, GF2_F_DIAG_CLOCKS)) {
             static const u64 init[6] = {~0ull, 0, ~0ull, 0, ~0ull, 0};
             GF2_HIP(hipMalloc((void**)&clk_dev, 64));
             GF2_HIP(hipMemcpy(clk_dev, init, 48, hipMemcpyHostToDevice));
         }
-        CompactArgs ca;
-        ca.clk = clk_dev;
-        ca.e = (const u64*)e;
-        ca.ht = ck->ht_dev;
-        ca.rec = rec;
-        ca.hist = (u64*)hist_dev;
-        ca.batch = count;
-        ca.lde = lde;
-        ca.r = (int)ck->r;
-        ca.n = (int)ck->n;
-        ca.ident_off = (int)ck->ident_off;
-        ca.null_ord = ck->slab_null;
-        ca.skip_words = stray.skip_words;
-        ca.cmb_pw = fold && first > 0 ? pw : nullptr;
-        ca.cmb_positions = gf2_cdiv(prev_count, 64) * 64;
-        ca.cmb_pad = pad;
-        ca.cmb_sample0 = (unsigned int)prev_first;
-        ca.cmb_nslabs = ck->nslabs512;
-        ca.cmb_nbins = (int)ck->r + 1;
-        ca.redo_count = redo_count;
-        ca.redo_list = redo_list;
-        int64_t cblocks = gf2_cdiv(gf2_cdiv(count, 64), CMP_WAVES);
-        // rounds per sub-pass: ceil(8 * words with non-identity columns / 64); workgroups per CU as the variant's registers allow
-        {
-            const int rounds = (CMP_SUB * non_identity_words(ck, stray.skip_words) + 63) / 64;
-            const int per_cu = rounds <= 4 ? 5 : (rounds <= 5 ? 4 : 3);
-            if (cblocks > (int64_t)ctx->num_cus * per_cu) cblocks = (int64_t)ctx->num_cus * per_cu;
-            const dim3 cgrid((unsigned)cblocks), cblock(CMP_THREADS);
-            if (rounds <= 4)
-                hipLaunchKernelGGL(slab_compact_kernel<4>, cgrid, cblock, 0, stream, ca);
-            else if (rounds <= 5)
-                hipLaunchKernelGGL(slab_compact_kernel<5>, cgrid, cblock, 0, stream, ca);
-            else if (rounds <= 6)
-                hipLaunchKernelGGL(slab_compact_kernel<6>, cgrid, cblock, 0, stream, ca);
-            else
-                hipLaunchKernelGGL(slab_compact_kernel<8>, cgrid, cblock, 0, stream, ca);
-        }
-        GF2_HIP(hipGetLastError());
-        GF2_TRY(launch_gather(ctx, ck, e, rec, pw, count, pad, lde, fast, stray, stream, clk_dev));
-        if (!fold || first + pass >= batch)
-            GF2_TRY(launch_combine(ctx, ck, pw, redo_count, redo_list, count, pad, (unsigned int)first, hist_dev, stream, clk_dev));
-        prev_first = first;
-        prev_count = count;
+        GF2_TRY(launch_compact(ctx, c, first, stream, clk_dev));
+        GF2_TRY(launch_rest_of_pass(ctx, c, first, stream, clk_dev));
         if (clk_dev) {
-            u64 c[6];
+            u64 t[6];
             GF2_HIP(hipStreamSynchronize(stream));
-            GF2_HIP(hipMemcpy(c, clk_dev, 48, hipMemcpyDeviceToHost));
+            GF2_HIP(hipMemcpy(t, clk_dev, 48, hipMemcpyDeviceToHost));
             fprintf(stderr, "pipeline: compact %.1f .. %.1f us, combine %.1f .. %.1f us (from compact's first workgroup)\n", 0.0,
-                    (double)(c[1] - c[0]) / 100.0, (double)(c[4] - c[0]) / 100.0, (double)(c[5] - c[0]) / 100.0);
-            fprintf(stderr, "pipeline: gather %.1f .. %.1f us\n", (double)((int64_t)(c[2] - c[0])) / 100.0,
-                    (double)((int64_t)(c[3] - c[0])) / 100.0);
+                    (double)(t[1] - t[0]) / 100.0, (double)(t[4] - t[0]) / 100.0, (double)(t[5] - t[0]) / 100.0);
+            fprintf(stderr, "pipeline: gather %.1f .. %.1f us\n", (double)((int64_t)(t[2] - t[0])) / 100.0,
+                    (double)((int64_t)(t[3] - t[0])) / 100.0);
             GF2_HIP(hipFree(clk_dev));
         }
     }
-    if (stray.n_cols) GF2_TRY(launch_redo(ctx, ck, e_dev, batch, lde, redo_count, redo_list, hist_dev, stream));
+    if (c.stray.n_cols) GF2_TRY(launch_redo(ctx, ck, e_dev, batch, lde, c.redo_count, c.redo_list, hist_dev, stream));
     return GF2_OK;
 }
 
