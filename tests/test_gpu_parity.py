@@ -89,6 +89,33 @@ def test_rref_random_vs_oracle(shape, ctx):
     assert np.array_equal(packed, want)
 
 
+@pytest.mark.parametrize("shape", [(1500, 300, 1), (3000, 700, 1), (700, 256, 5), (5000, 640, 1)])
+def test_rref_panels_that_need_several_rounds(shape, ctx):
+    # the first column of every 64-column panel has its only entries far down the matrix, beyond the 128 rows a window holds:
+    # the panel's first round resolves the other columns, a second one (with the coefficients of the first carried along)
+    # this one; sparse upper rows make some windows short of pivots altogether
+    m, n, batch = shape
+    rng = np.random.default_rng(m + n)
+    mats = []
+    for b in range(batch):
+        a = (rng.random((m, n)) < (0.5 if b % 2 == 0 else 0.03)).astype(np.uint8)
+        a[: (2 * m) // 3, ::64] = 0
+        a[m // 3: m // 2, :] = 0                         # a stretch of empty rows
+        mats.append(a)
+    packed = np.stack([_native.pack_rows(a) for a in mats])
+    if batch == 1:
+        pivots, rank = ctx.rref(packed[0], m, n)
+        want, want_piv, want_rank = c_oracle.rref(c_oracle.pack_rows(mats[0]), m, n)
+        assert rank == want_rank and list(pivots) == list(want_piv)
+        assert np.array_equal(packed[0], want)
+    else:
+        pivots, ranks = ctx.rref_batch(packed, batch, m, n)
+        for b in range(batch):
+            want, want_piv, want_rank = c_oracle.rref(c_oracle.pack_rows(mats[b]), m, n)
+            assert ranks[b] == want_rank and np.array_equal(packed[b], want)
+            assert list(pivots[b, :want_rank]) == list(want_piv)
+
+
 def test_rref_big512(golden):
     a = np.random.default_rng(1024).integers(0, 2, (512, 1024)).astype(np.int64)
     out = bin_matrix.reduced_row_echelon_form(a)
