@@ -1065,6 +1065,51 @@ def test_transform_stabilisers_golden_sequences():
     assert np.array_equal(rows, g["h_truth_out"])
 
 
+@pytest.mark.parametrize("n", [70, 128, 200, 257])
+def test_transform_stabilisers_runs_of_cnots_with_one_control(n):
+    # gf2_conjugate_gates folds runs of CNOTs that share a control into one operation per 64-column word of targets; against
+    # the restatement of css_code.py:737-781 on gate lists made of such runs: long and short, targets in the control's own word
+    # (not folded), a target named twice (cancels), single gates of another control in between, H gates that end a run, CNOT(c, c),
+    # a Z half that starts inside a word (n not a multiple of 64), and a refused H in the middle of it all
+    rng = np.random.default_rng(n)
+    k = 40
+    for trial in range(4):
+        mat = np.zeros((k, 2 * n), dtype=int)
+        mat[:, :n] = rng.integers(0, 2, (k, n))
+        if trial != 3:
+            mat[: k // 2, :n] = 0
+            mat[: k // 2, n:] = rng.integers(0, 2, (k // 2, n))            # CSS rows: all X or all Z
+        else:
+            mat[:, n:] = rng.integers(0, 2, (k, n))                         # rows with both: some H will be refused
+        gates = []
+        for run in range(12):
+            c = int(rng.integers(0, n))
+            targets = rng.permutation(n)[: int(rng.integers(1, n))]
+            for t in targets:
+                gates.append((1, c, int(t)))
+            if run % 3 == 0:
+                gates.append((1, c, int(targets[0])))                       # named twice
+            if run % 4 == 1:
+                gates.append((1, c, c))
+            if run % 2 == 0:
+                gates.append((0, int(rng.integers(0, n)), 0))
+            gates.append((1, int(rng.integers(0, n)), int(rng.integers(0, n))))
+        gates = np.array(gates, dtype=np.int32)
+        want, got = mat.copy(), mat.copy()
+        try:
+            cpu_ref.transform_stabilisers(want, gates)
+            refused = False
+        except NotImplementedError:
+            refused = True
+        if refused:
+            with pytest.raises(NotImplementedError, match="only handles CSS codes"):
+                css_code.transform_stabilisers(got, gates)
+        else:
+            css_code.transform_stabilisers(got, gates)
+        assert np.array_equal(got & 1, want & 1), (n, trial)
+    assert refused                                                          # the last trial must have exercised the refusal
+
+
 def test_steane_encoders_known_answers(steane_h):
     # test/test_css_code.py:61-106
     code = css_code.CSSCode(steane_h, steane_h)
