@@ -932,10 +932,12 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_pair_kernel(u64* __res
     // per-lane 64-bit pointers for 8 rows x 3 arrays would take 48 registers
     const int rl = 2 * wave + half;                                    // this lane's row among the 32 of a slot
     const unsigned int lane_word = (unsigned int)rl * (unsigned int)ld + (unsigned int)hl;
-    for (int64_t rb = (int64_t)blockIdx.x * rows_per_wg; rb < row_end; rb += 2 * NW * 8) {
-        u64 x[8], dA[8], dB[8];
+    // Four slots (8 rows of a wavefront, 128 of the workgroup) are worked on while the next four are on their way from memory:
+    // all wavefronts of a workgroup reach the loads together after the table build, and a CU holds one workgroup.
+    constexpr int STEP = 2 * NW * 4;
+    auto load4 = [&](int64_t rb, u64* x, u64* dA, u64* dB) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {                                  // 16 rows' loads in flight per wavefront
+        for (int u = 0; u < 4; ++u) {
             const int64_t rs = rb + (int64_t)u * 2 * NW;               // uniform
             const bool in = rs + rl < row_end;
             const u64* dau = da + rs;
@@ -943,23 +945,33 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_pair_kernel(u64* __res
             const u64* au = a + rs * ld + cw0;
             dA[u] = (in && ta > 0) ? dau[(unsigned int)rl] : 0ull;
             dB[u] = (in && tb > 0) ? dbu[(unsigned int)rl] : 0ull;
-            x[u] = (in && word_live) ? au[lane_word] : 0ull;             // (not made to wait for d: rows with d = 0 are rare)
+            x[u] = (in && word_live) ? au[lane_word] : 0ull;           // (not made to wait for d: rows with d = 0 are rare)
         }
-        unsigned int pas[8], pbs[8];
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto work4 = [&](int64_t rb, u64* x, const u64* dA, const u64* dB) {
+        unsigned int pas[4], pbs[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) pas[u] = at_a, pbs[u] = at_b;
-        // (scheduling barriers: left alone, the scheduler hoists all 256 reads of a row block and spills)
-#define GF2_PAIR_BYTE(B)                                                                                                \
-    pair_lookups4<B>(x, dA, dB, pas, pbs, c0f); __builtin_amdgcn_sched_barrier(0);                                      \
-    pair_lookups4<B>(x + 4, dA + 4, dB + 4, pas + 4, pbs + 4, c0f); __builtin_amdgcn_sched_barrier(0)
+        for (int u = 0; u < 4; ++u) pas[u] = at_a, pbs[u] = at_b;
+        // (scheduling barriers: left alone, the scheduler hoists all the reads of a row block and spills)
+#define GF2_PAIR_BYTE(B) pair_lookups4<B>(x, dA, dB, pas, pbs, c0f); __builtin_amdgcn_sched_barrier(0)
         GF2_PAIR_BYTE(0); GF2_PAIR_BYTE(1); GF2_PAIR_BYTE(2); GF2_PAIR_BYTE(3);
         GF2_PAIR_BYTE(4); GF2_PAIR_BYTE(5); GF2_PAIR_BYTE(6); GF2_PAIR_BYTE(7);
 #undef GF2_PAIR_BYTE
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < 4; ++u) {
             u64* au = a + (rb + (int64_t)u * 2 * NW) * ld + cw0;
             if ((dA[u] | dB[u]) && word_live) au[lane_word] = x[u];
         }
+    };
+    u64 x0[4], dA0[4], dB0[4], x1[4], dA1[4], dB1[4];
+    const int64_t rb0 = (int64_t)blockIdx.x * rows_per_wg;
+    load4(rb0, x0, dA0, dB0);
+    for (int64_t rb = rb0; rb < row_end; rb += 2 * STEP) {
+        load4(rb + STEP, x1, dA1, dB1);
+        work4(rb, x0, dA0, dB0);
+        load4(rb + 2 * STEP, x0, dA0, dB0);
+        if (rb + STEP < row_end) work4(rb + STEP, x1, dA1, dB1);       // uniform
     }
 }
 
