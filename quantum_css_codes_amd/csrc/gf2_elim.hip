@@ -806,38 +806,41 @@ __device__ __forceinline__ void nibble_hi_to_byte1(unsigned int& addr, unsigned 
     if constexpr (B == 3) asm("v_lshrrev_b32_sdwa %0, 4, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_3" : "+v"(addr) : "v"(d));
 }
 
-// One byte (two groups of 4 pivots) of both panels' coefficients for four rows: 16 table reads issued together, then the XORs.
+// One byte (two groups of 4 pivots) of both panels' coefficients for two slots (a lane's two words of two rows): 8 table reads of
+// 16 bytes issued together, then the XORs.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 template <int BYTE>
-__device__ __forceinline__ void pair_lookups4(u64* x, const u64* dA, const u64* dB, unsigned int* pas, unsigned int* pbs, unsigned int c0f) {
-    typedef const __attribute__((address_space(3))) u64* lds_u64_ptr;
+__device__ __forceinline__ void pair_lookups2(u32x4_t* x, const u64* dA, const u64* dB, unsigned int* pas, unsigned int* pbs, unsigned int c0f) {
+    typedef const __attribute__((address_space(3))) u32x4_t* lds_v4_ptr;
     constexpr unsigned int off = (unsigned int)BYTE * 8192u;          // groups 2*BYTE and 2*BYTE + 1: 4096 bytes each
-    u64 t[16];
+    u32x4_t t[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 2; ++u) {
         const unsigned int a = BYTE < 4 ? (unsigned int)dA[u] : (unsigned int)(dA[u] >> 32);
         const unsigned int b = BYTE < 4 ? (unsigned int)dB[u] : (unsigned int)(dB[u] >> 32);
         unsigned int pa = pas[u], pb = pbs[u];                         // byte 1 is rewritten by every lookup, the rest stays
         nibble_lo_to_byte1<BYTE & 3>(pa, a, c0f);
-        t[4 * u] = *(lds_u64_ptr)(uintptr_t)(pa + off);
+        t[4 * u] = *(lds_v4_ptr)(uintptr_t)(pa + off);
         nibble_hi_to_byte1<BYTE & 3>(pa, a);
-        t[4 * u + 1] = *(lds_u64_ptr)(uintptr_t)(pa + off + 4096u);
+        t[4 * u + 1] = *(lds_v4_ptr)(uintptr_t)(pa + off + 4096u);
         nibble_lo_to_byte1<BYTE & 3>(pb, b, c0f);
-        t[4 * u + 2] = *(lds_u64_ptr)(uintptr_t)(pb + off);
+        t[4 * u + 2] = *(lds_v4_ptr)(uintptr_t)(pb + off);
         nibble_hi_to_byte1<BYTE & 3>(pb, b);
-        t[4 * u + 3] = *(lds_u64_ptr)(uintptr_t)(pb + off + 4096u);
+        t[4 * u + 3] = *(lds_v4_ptr)(uintptr_t)(pb + off + 4096u);
         pas[u] = pa, pbs[u] = pb;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const unsigned int lo = __builtin_amdgcn_bitop3_b32((unsigned int)x[u], (unsigned int)t[4 * u], (unsigned int)t[4 * u + 1], 0x96);
-        const unsigned int hi = __builtin_amdgcn_bitop3_b32((unsigned int)(x[u] >> 32), (unsigned int)(t[4 * u] >> 32),
-                                                            (unsigned int)(t[4 * u + 1] >> 32), 0x96);
-        unsigned int lo2 = __builtin_amdgcn_bitop3_b32(lo, (unsigned int)t[4 * u + 2], (unsigned int)t[4 * u + 3], 0x96);
-        unsigned int hi2 = __builtin_amdgcn_bitop3_b32(hi, (unsigned int)(t[4 * u + 2] >> 32), (unsigned int)(t[4 * u + 3] >> 32), 0x96);
-        // pins the XORs here: they have no side effects, and instruction selection otherwise places all 256 of a row block after
+    for (int u = 0; u < 2; ++u) {
+        u32x4_t r;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const unsigned int y = __builtin_amdgcn_bitop3_b32(x[u][c], t[4 * u][c], t[4 * u + 1][c], 0x96);
+            r[c] = __builtin_amdgcn_bitop3_b32(y, t[4 * u + 2][c], t[4 * u + 3][c], 0x96);
+        }
+        // pins the XORs here: they have no side effects, and instruction selection otherwise places all of a row block's after
         // its last read, with every table word spilled in between
-        asm volatile("" : "+v"(lo2), "+v"(hi2));
-        x[u] = ((u64)hi2 << 32) | lo2;
+        asm volatile("" : "+v"(r));
+        x[u] = r;
     }
 }
 
@@ -845,8 +848,9 @@ __device__ __forceinline__ void pair_lookups4(u64* x, const u64* dA, const u64* 
 // matrices; block 1024; 128 KiB of dynamic LDS: two Four-Russians tables of 16 groups x 16 entries x 32 words).
 //   new_i = old_i ^ dA_i . SA ^ dB_i . SB',   SB'_q = SB_q ^ fix_q . SA
 // SA: the first panel's pivot rows as they stood before it; SB: the second panel's pivot rows as they stand in memory, that
-// is without the first panel's update, which the table build adds (fix_q = dA of that row).  A wavefront moves two rows
-// at a time, 32 lanes = 256 contiguous bytes each; a lookup is v_bfe + v_lshl_add + ds_read_b64 with an immediate offset.
+// is without the first panel's update, which the table build adds (fix_q = dA of that row).  A wavefront moves four rows
+// per slot, 16 lanes = 256 contiguous bytes each; a lookup is one SDWA instruction (a nibble of d into byte 1 of the address) + one
+// ds_read_b128 with an immediate offset.
 #define U2_CW 32
 __global__ __launch_bounds__(RB_THREADS) void rref_update_pair_kernel(u64* __restrict__ base, int64_t m, int64_t ld,
                                                                      int64_t rows_per_wg, const RrefState* __restrict__ states,
@@ -921,57 +925,72 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_pair_kernel(u64* __res
     u64* a = base + mat * m * ld;
     const u64* da = da_base + mat * m;
     const u64* db = db_base + mat * m;
-    // the second half-wave takes its row's words rotated by 16: whichever 32 lanes the LDS serves together (0..31, or 0..15 with
-    // 32..47), their 256 bytes then fall on 64 different banks (without the rotation the pair kernel ran at half speed)
-    const int half = lane >> 5, hl = (lane & (U2_CW - 1)) ^ (half << 4);
-    const bool word_live = hl < wc_n && !((cw0 + hl) * 64 >= st.skip_lo && (cw0 + hl + 1) * 64 <= st.skip_hi);
-    const unsigned int at_a = (unsigned int)hl * 8u, at_b = at_a + 65536u, c0f = 0x0fu;
+    // A lane moves two words (16 bytes) of a row, sixteen lanes a row's 256 bytes of the chunk, a wavefront four rows per slot: a
+    // lookup is a ds_read_b128, half as many read and address instructions per word as with 8-byte lookups (the pass is bound by
+    // issuing them: with its loads and stores removed it ran 13 % faster, no more).
+    const int quarter = lane >> 4, hw = (lane & 15) * 2;               // row of the slot, first of this lane's two words
+    const bool valid0 = hw < wc_n, valid1 = hw + 1 < wc_n;
+    auto skippable = [&](int wd) { return (cw0 + wd) * 64 >= st.skip_lo && (cw0 + wd + 1) * 64 <= st.skip_hi; };
+    const bool lane_live = valid0 && !(skippable(hw) && (!valid1 || skippable(hw + 1)));     // (a word that cannot change is XORed with zeros)
+    const unsigned int at_a = (unsigned int)hw * 8u, at_b = at_a + 65536u, c0f = 0x0fu;
     const int64_t row_end = ((int64_t)blockIdx.x + 1) * rows_per_wg < m ? ((int64_t)blockIdx.x + 1) * rows_per_wg : m;
     constexpr int NW = RB_THREADS / 64;
-    // addresses = a wavefront-uniform base (scalar registers) + one 32-bit lane offset that serves all eight rows of a lane:
-    // per-lane 64-bit pointers for 8 rows x 3 arrays would take 48 registers
-    const int rl = 2 * wave + half;                                    // this lane's row among the 32 of a slot
-    const unsigned int lane_word = (unsigned int)rl * (unsigned int)ld + (unsigned int)hl;
-    // Four slots (8 rows of a wavefront, 128 of the workgroup) are worked on while the next four are on their way from memory:
-    // all wavefronts of a workgroup reach the loads together after the table build, and a CU holds one workgroup.
-    constexpr int STEP = 2 * NW * 4;
-    auto load4 = [&](int64_t rb, u64* x, u64* dA, u64* dB) {
+    // addresses = a wavefront-uniform base (scalar registers) + one 32-bit lane offset that serves all rows of a lane:
+    // per-lane 64-bit pointers would take dozens of registers
+    const int rl = 4 * wave + quarter;                                 // this lane's row among the 64 of a slot
+    const unsigned int lane_word = (unsigned int)rl * (unsigned int)ld + (unsigned int)hw;
+    // Two slots (8 rows of a wavefront, 128 of the workgroup) are worked on while the next two are on their way from memory.
+    constexpr int STEP = 4 * NW * 2;
+    auto load2 = [&](int64_t rb, u32x4_t* x, u64* dA, u64* dB) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int64_t rs = rb + (int64_t)u * 2 * NW;               // uniform
+        for (int u = 0; u < 2; ++u) {
+            const int64_t rs = rb + (int64_t)u * 4 * NW;               // uniform
             const bool in = rs + rl < row_end;
             const u64* dau = da + rs;
             const u64* dbu = db + rs;
             const u64* au = a + rs * ld + cw0;
             dA[u] = (in && ta > 0) ? dau[(unsigned int)rl] : 0ull;
             dB[u] = (in && tb > 0) ? dbu[(unsigned int)rl] : 0ull;
-            x[u] = (in && word_live) ? au[lane_word] : 0ull;           // (not made to wait for d: rows with d = 0 are rare)
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (in && lane_live) {                                     // (not made to wait for d: rows with d = 0 are rare)
+                if (valid1) {
+                    v = *reinterpret_cast<const u32x4_t*>(au + lane_word);
+                } else {
+                    const u64 one = au[lane_word];
+                    v[0] = (unsigned int)one, v[1] = (unsigned int)(one >> 32);
+                }
+            }
+            x[u] = v;
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto work4 = [&](int64_t rb, u64* x, const u64* dA, const u64* dB) {
-        unsigned int pas[4], pbs[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) pas[u] = at_a, pbs[u] = at_b;
+    auto work2 = [&](int64_t rb, u32x4_t* x, const u64* dA, const u64* dB) {
+        unsigned int pas[2] = {at_a, at_a}, pbs[2] = {at_b, at_b};
         // (scheduling barriers: left alone, the scheduler hoists all the reads of a row block and spills)
-#define GF2_PAIR_BYTE(B) pair_lookups4<B>(x, dA, dB, pas, pbs, c0f); __builtin_amdgcn_sched_barrier(0)
+#define GF2_PAIR_BYTE(B) pair_lookups2<B>(x, dA, dB, pas, pbs, c0f); __builtin_amdgcn_sched_barrier(0)
         GF2_PAIR_BYTE(0); GF2_PAIR_BYTE(1); GF2_PAIR_BYTE(2); GF2_PAIR_BYTE(3);
         GF2_PAIR_BYTE(4); GF2_PAIR_BYTE(5); GF2_PAIR_BYTE(6); GF2_PAIR_BYTE(7);
 #undef GF2_PAIR_BYTE
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            u64* au = a + (rb + (int64_t)u * 2 * NW) * ld + cw0;
-            if ((dA[u] | dB[u]) && word_live) au[lane_word] = x[u];
+        for (int u = 0; u < 2; ++u) {
+            u64* au = a + (rb + (int64_t)u * 4 * NW) * ld + cw0;
+            if ((dA[u] | dB[u]) && lane_live) {
+                if (valid1)
+                    *reinterpret_cast<u32x4_t*>(au + lane_word) = x[u];
+                else
+                    au[lane_word] = ((u64)x[u][1] << 32) | x[u][0];
+            }
         }
     };
-    u64 x0[4], dA0[4], dB0[4], x1[4], dA1[4], dB1[4];
+    u32x4_t x0[2], x1[2];
+    u64 dA0[2], dB0[2], dA1[2], dB1[2];
     const int64_t rb0 = (int64_t)blockIdx.x * rows_per_wg;
-    load4(rb0, x0, dA0, dB0);
+    load2(rb0, x0, dA0, dB0);
     for (int64_t rb = rb0; rb < row_end; rb += 2 * STEP) {
-        load4(rb + STEP, x1, dA1, dB1);
-        work4(rb, x0, dA0, dB0);
-        load4(rb + 2 * STEP, x0, dA0, dB0);
-        if (rb + STEP < row_end) work4(rb + STEP, x1, dA1, dB1);       // uniform
+        load2(rb + STEP, x1, dA1, dB1);
+        work2(rb, x0, dA0, dB0);
+        load2(rb + 2 * STEP, x0, dA0, dB0);
+        if (rb + STEP < row_end) work2(rb + STEP, x1, dA1, dB1);       // uniform
     }
 }
 
