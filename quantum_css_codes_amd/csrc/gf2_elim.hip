@@ -892,36 +892,6 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_pair_kernel(u64* __res
         o[6 * U2_CW] = r2 ^ c23;
         o[7 * U2_CW] = r2 ^ c123;
     };
-    u64* TA = T;
-    u64* TB = T + 16 * 16 * U2_CW;
-    u64 sb[2];
-    {
-        u64 sa[2];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {                               // 64 x 32 words / 1024 lanes
-            const int idx = tid + RB_THREADS * it, p = idx / U2_CW, wd = idx & (U2_CW - 1);
-            sa[it] = (p < ta && wd < wc_n) ? snapa_base[(mat * 64 + p) * ld + cw0 + wd] : 0ull;
-            sb[it] = (p < tb && wd < wc_n) ? snapb_base[(mat * 64 + p) * ld + cw0 + wd] : 0ull;
-        }
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = tid + RB_THREADS * it, p = idx / U2_CW, wd = idx & (U2_CW - 1);
-            TA[((p >> 2) * 16 + (1 << (p & 3))) * U2_CW + wd] = sa[it];
-        }
-    }
-    __syncthreads();
-    combos(TA);
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int idx = tid + RB_THREADS * it, p = idx / U2_CW, wd = idx & (U2_CW - 1);
-        u64 x = sb[it];
-        if (ta > 0 && p < tb) x ^= lookup16((unsigned int)wd * 8u, fix_base[mat * 64 + p]);
-        TB[((p >> 2) * 16 + (1 << (p & 3))) * U2_CW + wd] = x;
-    }
-    __syncthreads();
-    combos(TB);
-    __syncthreads();
     u64* a = base + mat * m * ld;
     const u64* da = da_base + mat * m;
     const u64* db = db_base + mat * m;
@@ -964,6 +934,41 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_pair_kernel(u64* __res
         }
         __builtin_amdgcn_sched_barrier(0);
     };
+    u32x4_t x0[2], x1[2];
+    u64 dA0[2], dB0[2], dA1[2], dB1[2];
+    const int64_t rb0 = (int64_t)blockIdx.x * rows_per_wg;
+    load2(rb0, x0, dA0, dB0);                                          // on their way while the tables are built
+    u64* TA = T;
+    u64* TB = T + 16 * 16 * U2_CW;
+    u64 sb[2], fixv[2];
+    {
+        u64 sa[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {                               // 64 x 32 words / 1024 lanes; everything the build reads from memory now
+            const int idx = tid + RB_THREADS * it, p = idx / U2_CW, wd = idx & (U2_CW - 1);
+            sa[it] = (p < ta && wd < wc_n) ? snapa_base[(mat * 64 + p) * ld + cw0 + wd] : 0ull;
+            sb[it] = (p < tb && wd < wc_n) ? snapb_base[(mat * 64 + p) * ld + cw0 + wd] : 0ull;
+            fixv[it] = (ta > 0 && p < tb) ? fix_base[mat * 64 + p] : 0ull;
+        }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + RB_THREADS * it, p = idx / U2_CW, wd = idx & (U2_CW - 1);
+            TA[((p >> 2) * 16 + (1 << (p & 3))) * U2_CW + wd] = sa[it];
+        }
+    }
+    __syncthreads();
+    combos(TA);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int idx = tid + RB_THREADS * it, p = idx / U2_CW, wd = idx & (U2_CW - 1);
+        u64 x = sb[it];
+        if (ta > 0 && p < tb) x ^= lookup16((unsigned int)wd * 8u, fixv[it]);
+        TB[((p >> 2) * 16 + (1 << (p & 3))) * U2_CW + wd] = x;
+    }
+    __syncthreads();
+    combos(TB);
+    __syncthreads();
     auto work2 = [&](int64_t rb, u32x4_t* x, const u64* dA, const u64* dB) {
         unsigned int pas[2] = {at_a, at_a}, pbs[2] = {at_b, at_b};
         // (scheduling barriers: left alone, the scheduler hoists all the reads of a row block and spills)
@@ -982,10 +987,6 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_pair_kernel(u64* __res
             }
         }
     };
-    u32x4_t x0[2], x1[2];
-    u64 dA0[2], dB0[2], dA1[2], dB1[2];
-    const int64_t rb0 = (int64_t)blockIdx.x * rows_per_wg;
-    load2(rb0, x0, dA0, dB0);
     for (int64_t rb = rb0; rb < row_end; rb += 2 * STEP) {
         load2(rb + STEP, x1, dA1, dB1);
         work2(rb, x0, dA0, dB0);
