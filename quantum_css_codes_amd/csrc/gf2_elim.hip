@@ -1148,20 +1148,44 @@ __global__ __launch_bounds__(RB_THREADS) void norm_panel_kernel(u64* __restrict_
     }
 }
 
-// out row k (k < rank) = in row pivrow[k]; rows >= rank are zero.  grid (m, batch), block 64.
-__global__ void gather_rows_kernel(const u64* __restrict__ in, u64* __restrict__ out, const int32_t* __restrict__ pivrow,
-                                   const RrefState* __restrict__ states, int64_t* __restrict__ rank_out, int64_t m,
-                                   int64_t ld, int64_t cap) {
-    const int64_t k = blockIdx.x, mat = blockIdx.y;
-    const u64* src = in + mat * m * ld;
-    u64* dst = out + mat * m * ld + k * ld;
+// first_free = n (no pivot-free column seen yet) in the zeroed per-matrix states.
+__global__ void rref_state_init_kernel(RrefState* __restrict__ states, int64_t batch, int64_t n) {
+    const int64_t mat = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (mat < batch) states[mat].first_free = n;
+}
+
+// out row k (k < rank) = in row pivrow[k]; rows >= rank are zero.  grid (ceil(m / 16), batch), block 256: sixteen rows per
+// workgroup, moved as 16-byte pieces when the row pitch is even (8-byte words otherwise).
+#define GATHER_ROWS 16
+__global__ __launch_bounds__(256) void gather_rows_kernel(const u64* __restrict__ in, u64* __restrict__ out,
+                                                          const int32_t* __restrict__ pivrow, const RrefState* __restrict__ states,
+                                                          int64_t* __restrict__ rank_out, int64_t m, int64_t ld, int64_t cap) {
+    typedef unsigned int v4 __attribute__((ext_vector_type(4)));
+    __shared__ int64_t src_row[GATHER_ROWS];
+    const int64_t k0 = (int64_t)blockIdx.x * GATHER_ROWS, mat = blockIdx.y;
     const int64_t rank = states[mat].rank;
-    if (k == 0 && threadIdx.x == 0) rank_out[mat] = rank;
-    if (k < rank) {
-        const u64* row = src + (int64_t)pivrow[mat * cap + k] * ld;
-        for (int64_t wd = threadIdx.x; wd < ld; wd += 64) dst[wd] = row[wd];
+    if (blockIdx.x == 0 && threadIdx.x == 0) rank_out[mat] = rank;
+    if (threadIdx.x < GATHER_ROWS) {
+        const int64_t k = k0 + threadIdx.x;
+        src_row[threadIdx.x] = k < rank ? (int64_t)pivrow[mat * cap + k] : -1;
+    }
+    __syncthreads();
+    const u64* src = in + mat * m * ld;
+    u64* dst = out + (mat * m + k0) * ld;
+    const int64_t rows = m - k0 < GATHER_ROWS ? m - k0 : GATHER_ROWS;
+    if ((ld & 1) == 0) {
+        const int64_t ppr = ld >> 1;                                   // 16-byte pieces per row
+        for (int64_t idx = threadIdx.x; idx < rows * ppr; idx += 256) {
+            const int64_t r = idx / ppr, piece = idx - r * ppr;
+            v4 v = {0u, 0u, 0u, 0u};
+            if (src_row[r] >= 0) v = *reinterpret_cast<const v4*>(src + src_row[r] * ld + 2 * piece);
+            *reinterpret_cast<v4*>(dst + r * ld + 2 * piece) = v;
+        }
     } else {
-        for (int64_t wd = threadIdx.x; wd < ld; wd += 64) dst[wd] = 0ull;
+        for (int64_t idx = threadIdx.x; idx < rows * ld; idx += 256) {
+            const int64_t r = idx / ld, wd = idx - r * ld;
+            dst[r * ld + wd] = src_row[r] >= 0 ? src[src_row[r] * ld + wd] : 0ull;
+        }
     }
 }
 
@@ -1374,12 +1398,7 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
     u64* tabs = (u64*)(q + 2 * dbytes + al((size_t)batch * m * 4) + al((size_t)batch * 64 * 4));
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
     GF2_HIP(hipMemsetAsync(states, 0, sbytes + ubytes, ctx->stream));          // rank = 0, used = 0 ...
-    {
-        std::vector<RrefState> init((size_t)batch);
-        for (auto& st : init) { memset(&st, 0, sizeof(st)); st.first_free = n; }
-        GF2_HIP(hipMemcpyAsync(states, init.data(), (size_t)batch * sizeof(RrefState), hipMemcpyHostToDevice, ctx->stream));
-        GF2_HIP(hipStreamSynchronize(ctx->stream));                              // init lives on the host stack
-    }
+    hipLaunchKernelGGL(rref_state_init_kernel, dim3((unsigned)gf2_cdiv(batch, 256)), dim3(256), 0, ctx->stream, states, batch, n);
     if (!ctx->lds_optin[4]) {
         GF2_HIP(hipFuncSetAttribute((const void*)rref_update_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
         ctx->lds_optin[4] = true;
@@ -1439,8 +1458,8 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
         }
     }
     GF2_HIP(hipGetLastError());
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)m, (unsigned)batch), dim3(64), 0, ctx->stream, (const u64*)a_dev,
-                       tmp, pivrow, states, rank_dev, m, ld, cap);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)gf2_cdiv(m, GATHER_ROWS), (unsigned)batch), dim3(256), 0, ctx->stream,
+                       (const u64*)a_dev, tmp, pivrow, states, rank_dev, m, ld, cap);
     GF2_HIP(hipGetLastError());
     GF2_HIP(hipMemcpyAsync(a_dev, tmp, (size_t)batch * m * ld * 8, hipMemcpyDeviceToDevice, ctx->stream));
     GF2_TRY(gf2_prof_end(ctx));
