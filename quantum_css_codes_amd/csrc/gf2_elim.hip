@@ -183,9 +183,9 @@ __global__ __launch_bounds__(ELIM_THREADS) void eliminate_kernel(u64* __restrict
 //     2. d_i and a snapshot of the OLDPIV rows go to global scratch.
 //   rref_update_pair_kernel (grid: row blocks x 32-word column chunks x matrices -- the whole GPU), once per PAIR of panels
 //     3. A[i] ^= dA_i . OLDPIV_A ^ dB_i . OLDPIV_B', Method of Four Russians: for each group of 4 pivots of either panel the 16
-//        XOR combinations of their rows sit in LDS (2 x 64 KiB); a wavefront moves two rows at a time (32 lanes = 256
+//        XOR combinations of their rows sit in LDS (2 x 64 KiB); a wavefront moves four rows per slot (16 lanes = 256
 //        contiguous bytes each), a lookup is one SDWA instruction that drops a nibble of d into the address + one
-//        ds_read_b64.  The second panel of a pair runs BEFORE the first panel's update has been applied: it brings its own
+//        ds_read_b128.  The second panel of a pair runs BEFORE the first panel's update has been applied: it brings its own
 //        column up to date on the way in (one byte-table lookup per row) and the table build of this kernel does the same
 //        for its pivot rows (OLDPIV_B' = OLDPIV_B ^ fix . OLDPIV_A), so the matrix makes one trip through HBM per 128
 //        columns.  Chunks left of the pair are skipped while no pivot-free column has been seen there (they cannot change).
