@@ -624,6 +624,35 @@ def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, route):
     assert np.array_equal(hot_records[0], hot_fused[0]) and np.array_equal(hot_records[1], hot_fused[1])
 
 
+@pytest.mark.parametrize("case", [(1023, 511, 511, 512, 0.02), (2047, 1023, 1023, 1024, 0.012), (3000, 1500, 1400, 1536, 0.008),
+                                  (4096, 1536, 2048, 2048, 0.007), (1100, 512, 500, 512, 0.02)])
+def test_monte_carlo_record_sampler_other_shapes(case, ctx, route):
+    # the record sampler away from the benchmark's shape: a last segment of fewer than 512 qubits, identity blocks of other sizes
+    # and positions (H1 = [I | A], H2 = [A' | I | ...] with its block starting at a multiple of 512), a second block that ends
+    # inside a segment; against the fused kernel, the packed-row route and, on a prefix, the oracle
+    n, r1, r2, off2, p_total = case
+    rng = np.random.default_rng(n + r1)
+    hm1, hm2 = rng.integers(0, 2, (r1, n)), rng.integers(0, 2, (r2, n))
+    hm1[:, :r1] = np.identity(r1, dtype=int)
+    hm2[:, off2:off2 + r2] = np.identity(r2, dtype=int)
+    h1, h2 = _native.pack_rows(hm1), _native.pack_rows(hm2)
+    c1, c2 = ctx.check_create(h1, r1, n), ctx.check_create(h2, r2, n)
+    args = (31, 500, 70001 + n, p_total / 2, p_total / 4, p_total / 4, _native.HIST_WEIGHT)
+    records = ctx.mc_run(c1, c2, *args)
+    route.force("GF2_MC_FUSED")
+    fused = ctx.mc_run(c1, c2, *args)
+    route.release("GF2_MC_FUSED")
+    route.force("GF2_MC_ROWS")
+    rows = ctx.mc_run(c1, c2, *args)
+    route.release("GF2_MC_ROWS")
+    assert int(records[0].sum()) == args[2] and int(records[1].sum()) == args[2]
+    for got in (fused, rows):
+        assert np.array_equal(got[0], records[0]) and np.array_equal(got[1], records[1])
+    want = c_oracle.mc(h1, r1, h2, r2, n, 31, 500, 3000, p_total / 2, p_total / 4, p_total / 4, 1)
+    small = ctx.mc_run(c1, c2, 31, 500, 3000, p_total / 2, p_total / 4, p_total / 4, _native.HIST_WEIGHT)
+    assert np.array_equal(small[0], want[0]) and np.array_equal(small[1], want[1])
+
+
 @pytest.mark.parametrize("case", [(127, 63, 64), (255, 127, 127), (511, 255, 250), (300, 100, 150)])
 def test_monte_carlo_mid_size_checks_take_the_lane_kernel(case, ctx, route):
     # n <= 512, r <= 256: gf2_mc_run draws dense rows and runs the lane-per-sample kernel per component; same histograms
