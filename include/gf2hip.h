@@ -80,7 +80,7 @@ int gf2_ctx_sync(gf2_ctx* ctx);
 #define GF2_F_RREF_SEQUENTIAL      (1u << 8)   /* gf2_rref*: one pivot per step                                         */
 #define GF2_F_RREF_NO_SMALL        (1u << 9)   /* gf2_rref*: no wavefront-per-matrix kernel                             */
 #define GF2_F_NORMALIZE_SEQUENTIAL (1u << 10)  /* gf2_normalize*: one pivot per step                                    */
-#define GF2_F_SAMPLER_GENERIC      (1u << 11)  /* gf2_sample_errors_dev: lane-per-word kernel                           */
+#define GF2_F_SAMPLER_GENERIC      (1u << 11)  /* gf2_sample_errors_dev: lane-per-segment kernel                        */
 #define GF2_F_DIAG_CLOCKS          (1u << 12)  /* slab pipeline: print wall-clock stamps of its kernels to stderr       */
 #define GF2_F_DIAG_MC_TIMES        (1u << 13)  /* gf2_mc_run: print the host's phases to stderr                         */
 #define GF2_F_MC_ROWS              (1u << 14)  /* gf2_mc_run: packed rows from the sampler, records by the compact kernel */
@@ -260,7 +260,11 @@ int gf2_sample_errors_dev(gf2_ctx* ctx, int64_t n, uint64_t seed, int64_t first_
                           uint64_t* ex_dev, uint64_t* ez_dev, int64_t lde, int layout);
 
 /* Full pipeline: sample -> syndromes -> histograms, chunked through device workspace owned by ctx.
- * hist_z (from H1 . e_z) and hist_x (from H2 . e_x) are host uint64 arrays, overwritten. */
+ * hist_z (from H1 . e_z) and hist_x (from H2 . e_x) are host uint64 arrays, overwritten.  The same histograms whatever the
+ * route: n <= 64: one fused kernel; mid-size checks: sampler + lane-per-sample kernel; n <= 4096 at sparse
+ * rates with both checks in standard form: the record sampler (no packed rows) + gather / combine kernels of the LDS row-slab
+ * pipeline; otherwise packed rows from the sampler through the sparse or the dense syndrome kernels.  The first call of a size
+ * allocates the workspaces. */
 int gf2_mc_run(gf2_ctx* ctx, const gf2_check* check_c1, const gf2_check* check_c2,
                uint64_t seed, int64_t first_sample, int64_t count,
                double p_x, double p_y, double p_z, int mode,
