@@ -189,7 +189,7 @@ __global__ __launch_bounds__(ELIM_THREADS) void eliminate_kernel(u64* __restrict
 //        column up to date on the way in (one byte-table lookup per row) and the table build of this kernel does the same
 //        for its pivot rows (OLDPIV_B' = OLDPIV_B ^ fix . OLDPIV_A), so the matrix makes one trip through HBM per 128
 //        columns.  Chunks left of the pair are skipped while no pivot-free column has been seen there (they cannot change).
-//        (rref_update_kernel, one panel per pass at 64-word chunks with scalar d, still serves the normalisation.)
+//        (The normalisation uses the same kernel with its panel as the first of a pair that has no second.)
 //   gather_rows_kernel: after the last panel the pivot rows are gathered into rows 0..rank-1, the rest zeroed.
 #define RB_THREADS 1024
 #define RB_WIN 128
@@ -707,88 +707,6 @@ __global__ __launch_bounds__(RB_THREADS) void rref_panel_stream_kernel(u64* __re
     if (tid < t) prow_base[mat * 64 + tid] = prow_l[tid];               // for panel_finish_kernel, which follows
 }
 
-// grid (row blocks, column chunks of 64 words, matrices), block 1024, 128 KiB dynamic LDS.
-__global__ __launch_bounds__(RB_THREADS) void rref_update_kernel(u64* __restrict__ base, int64_t m, int64_t ld,
-                                                                int64_t rows_per_wg, const RrefState* __restrict__ states,
-                                                                const u64* __restrict__ d_base, const u64* __restrict__ snap_base) {
-    extern __shared__ __attribute__((aligned(16))) u64 T[];           // 16 groups x 16 entries x 64 words
-    const int64_t mat = blockIdx.z;
-    const RrefState st = states[mat];
-    const int t = st.t;
-    const int64_t cw0 = (int64_t)blockIdx.y * 64;
-    if (t == 0 || (cw0 * 64 >= st.skip_lo && (cw0 + 64) * 64 <= st.skip_hi)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wc_n = ld - cw0 < 64 ? (int)(ld - cw0) : 64;
-    const u64* snap = snap_base + mat * 64 * ld;
-    // single-pivot entries T[(g*16 + (1<<k)) * 64 + wd] = OLDPIV[4g+k][cw0+wd], then the combinations
-    {
-        u64 sv[4];                                                     // 64 x 64 words / 1024 lanes: 4 loads in flight
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = tid + RB_THREADS * it, p = idx >> 6, wd = idx & 63;
-            sv[it] = (p < t && wd < wc_n) ? snap[(int64_t)p * ld + cw0 + wd] : 0ull;
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = tid + RB_THREADS * it, p = idx >> 6, wd = idx & 63;
-            T[((p >> 2) * 16 + (1 << (p & 3))) * 64 + wd] = sv[it];
-        }
-    }
-    __syncthreads();
-#pragma unroll 2
-    for (int idx = tid; idx < 16 * 16 * 64; idx += RB_THREADS) {
-        const int wd = idx & 63, vv = (idx >> 6) & 15, g = idx >> 10;
-        if (vv & (vv - 1)) {                                           // two or more pivots
-            u64 x = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) x ^= T[(g * 16 + (1 << k)) * 64 + wd] & (0ull - (u64)((vv >> k) & 1));
-            T[idx] = x;
-        } else if (vv == 0) {
-            T[idx] = 0;
-        }
-    }
-    __syncthreads();
-    u64* a = base + mat * m * ld;
-    const u64* dd = d_base + mat * m;
-    const bool word_live = lane < wc_n && !((cw0 + lane) * 64 >= st.skip_lo && (cw0 + lane + 1) * 64 <= st.skip_hi);
-    // T is the kernel's only LDS, so it starts at LDS address 0: an entry is addressed as (lane*8 [+64 KiB]) +
-    // nibble*512 (scalar) + an immediate below 64 KiB
-    typedef const __attribute__((address_space(3))) u64* lds_u64_ptr;
-    const unsigned int lane8 = lane * 8u;
-    const int64_t row_end = ((int64_t)blockIdx.x + 1) * rows_per_wg < m ? ((int64_t)blockIdx.x + 1) * rows_per_wg : m;
-    constexpr int NW = RB_THREADS / 64;
-    for (int64_t r0 = (int64_t)blockIdx.x * rows_per_wg + wave; r0 < row_end; r0 += NW * 8) {
-        u64 x[8], d[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {                                  // 8 rows' loads in flight
-            const int64_t row = r0 + (int64_t)u * NW;
-            const bool from_zero = row >= st.zero_lo && row < st.zero_hi;     // uniform: rebuilt rows start from 0
-            d[u] = row < row_end ? readlane64(dd[row < row_end ? row : r0], 0) : 0ull;
-            x[u] = (d[u] && word_live && !from_zero) ? a[row * ld + cw0 + lane] : 0ull;
-        }
-#pragma unroll 1
-        for (int g = 0; g < 16; g += 2) {                              // group pairs outside, rows inside: 16 reads in flight
-            const unsigned int goff = (unsigned int)g * 8192u;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const unsigned int soff0 = goff + (unsigned int)((d[u] >> (4 * g)) & 15ull) * 512u;             // scalar
-                const unsigned int soff1 = goff + 8192u + (unsigned int)((d[u] >> (4 * g + 4)) & 15ull) * 512u;
-                const u64 t0 = *(lds_u64_ptr)(uintptr_t)(lane8 + soff0), t1 = *(lds_u64_ptr)(uintptr_t)(lane8 + soff1);
-                // v_bitop3_b32 with truth table 0x96: a three-way XOR per dword
-                const unsigned int lo = __builtin_amdgcn_bitop3_b32((unsigned int)x[u], (unsigned int)t0, (unsigned int)t1, 0x96);
-                const unsigned int hi = __builtin_amdgcn_bitop3_b32((unsigned int)(x[u] >> 32), (unsigned int)(t0 >> 32),
-                                                                    (unsigned int)(t1 >> 32), 0x96);
-                x[u] = ((u64)hi << 32) | lo;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t row = r0 + (int64_t)u * NW;
-            if (d[u] && word_live) a[row * ld + cw0 + lane] = x[u];
-        }
-    }
-}
-
 // addr.byte1 = low / high nibble of byte B of d, the other bytes of addr kept (SDWA): one instruction turns the table's base
 // address into the address of entry (nibble) -- entries are 256 bytes apart, byte 0 holds the lane's word offset.
 template <int B>
@@ -922,7 +840,8 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_pair_kernel(u64* __res
             dA[u] = (in && ta > 0) ? dau[(unsigned int)rl] : 0ull;
             dB[u] = (in && tb > 0) ? dbu[(unsigned int)rl] : 0ull;
             u32x4_t v = {0u, 0u, 0u, 0u};
-            if (in && lane_live) {                                     // (not made to wait for d: rows with d = 0 are rare)
+            const bool from_zero = rs + rl >= st.zero_lo && rs + rl < st.zero_hi;   // normalisation: rebuilt rows start from 0
+            if (in && lane_live && !from_zero) {                       // (not made to wait for d: rows with d = 0 are rare)
                 if (valid1) {
                     v = *reinterpret_cast<const u32x4_t*>(au + lane_word);
                 } else {
@@ -1021,6 +940,7 @@ __global__ __launch_bounds__(RB_THREADS) void norm_panel_kernel(u64* __restrict_
     if (i0 >= r || status[0] != 0) {
         if (tid == 0) {
             st->t = 0;
+            st->tg[0] = st->tg[1] = 0;
             st->stalled = 0;
         }
         return;
@@ -1088,6 +1008,8 @@ __global__ __launch_bounds__(RB_THREADS) void norm_panel_kernel(u64* __restrict_
     const int t = misc[0];
     if (tid == 0) {
         st->t = t;
+        st->tg[0] = t;                                               // the trailing pass takes this panel as the first of a pair without a second
+        st->tg[1] = 0;
         st->stalled = t < steps ? 1 : 0;
         st->rank = i0 + t;
         st->skip_lo = offset;
@@ -1560,13 +1482,13 @@ int gf2_normalize_dev(gf2_ctx* ctx, uint64_t* h_dev, int64_t r, int64_t n, int64
     u64* dco = (u64*)q; q += dbytes;
     u64* snap = (u64*)q;
     GF2_HIP(hipMemsetAsync(st, 0, sizeof(RrefState), ctx->stream));
-    if (!ctx->lds_optin[1]) {
-        GF2_HIP(hipFuncSetAttribute((const void*)rref_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        ctx->lds_optin[1] = true;
+    if (!ctx->lds_optin[4]) {
+        GF2_HIP(hipFuncSetAttribute((const void*)rref_update_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ctx->lds_optin[4] = true;
     }
     const int rpt = (int)gf2_cdiv(r, RB_THREADS);
-    const int64_t rows_per_wg = gf2_cdiv(ld, 64) >= 8 ? 256 : 128;
-    const dim3 ugrid((unsigned)gf2_cdiv(r, rows_per_wg), (unsigned)gf2_cdiv(ld, 64), 1);
+    const int64_t rows_per_wg = gf2_cdiv(ld, U2_CW) >= 16 ? 256 : 128;
+    const dim3 ugrid((unsigned)gf2_cdiv(r, rows_per_wg), (unsigned)gf2_cdiv(ld, U2_CW), 1);
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
     int64_t last_rank = 0;
     for (int64_t round = 0;; ++round) {
@@ -1582,8 +1504,9 @@ int gf2_normalize_dev(gf2_ctx* ctx, uint64_t* h_dev, int64_t r, int64_t n, int64
         else
             GF2_NP_LAUNCH(8);
 #undef GF2_NP_LAUNCH
-        hipLaunchKernelGGL(rref_update_kernel, ugrid, dim3(RB_THREADS), 128 * 1024, ctx->stream, (u64*)h_dev, r, ld, rows_per_wg,
-                           st, dco, snap);
+        // the RREF's trailing pass with this panel as the first of a pair that has no second (diagonal rows rebuilt from zero)
+        hipLaunchKernelGGL(rref_update_pair_kernel, ugrid, dim3(RB_THREADS), 128 * 1024, ctx->stream, (u64*)h_dev, r, ld, rows_per_wg,
+                           (const RrefState*)st, (const u64*)dco, (const u64*)dco, (const u64*)snap, (const u64*)snap, (const u64*)dco);
         hipLaunchKernelGGL(eliminate_kernel<ELIM_NORMALIZE>, dim3(1), dim3(ELIM_THREADS), 0, ctx->stream, (u64*)h_dev, r, n, ld,
                            offset, (int64_t*)nullptr, (int64_t)0, (int64_t*)nullptr, swaps_dev, nswaps_dev, status_dev, st);
         GF2_HIP(hipGetLastError());

@@ -57,7 +57,7 @@ struct gf2_ctx {
     void* ws[4];
     size_t ws_bytes[4];
     // large dynamic-LDS opt-in (hipFuncSetAttribute) done for this context's device: [0] syndrome_tiled_kernel,
-    // [1] rref_update_kernel, [2] slab_gather_kernel, [3] conjugate_kernel
+    // [1] (unused), [2] slab_gather_kernel, [3] conjugate_kernel, [4] rref_update_pair_kernel
     bool lds_optin[5];
     // routing flags (GF2_F_*) and tunables (GF2_OPT_*, -1 = default): gf2_ctx_set_flags / gf2_ctx_set_option
     uint32_t flags;
