@@ -932,8 +932,8 @@ __global__ __launch_bounds__(RB_THREADS) void norm_panel_kernel(u64* __restrict_
                                                                int64_t offset, RrefState* __restrict__ st,
                                                                const int* __restrict__ status, u64* __restrict__ dout,
                                                                u64* __restrict__ snap) {
-    __shared__ u64 VT[2048];
-    __shared__ u64 V[64], csel[64], pword[64], win_w[RB_WIN], win_c[RB_WIN];
+    __shared__ u64 VT[2048];                                            // byte tables of the probe rows' coefficients
+    __shared__ u64 win_w[RB_WIN], win_d[RB_WIN], DP[64];
     __shared__ int donor[64], misc[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t i0 = st->rank;
@@ -950,12 +950,11 @@ __global__ __launch_bounds__(RB_THREADS) void norm_panel_kernel(u64* __restrict_
     const int steps = r - i0 < 64 ? (int)(r - i0) : 64;
     const u64 stepmask = steps >= 64 ? ~0ull : ((1ull << steps) - 1ull);
 
-    u64 w[RPT], c[RPT];
+    u64 w[RPT];
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int64_t row = tid + (int64_t)RB_THREADS * k;
         w[k] = 0;
-        c[k] = 0;
         if (row < r) {
             u64 v = a[row * ld + cw] >> sh;
             if (sh && cw + 1 < ld) v |= a[row * ld + cw + 1] << (64 - sh);
@@ -966,7 +965,11 @@ __global__ __launch_bounds__(RB_THREADS) void norm_panel_kernel(u64* __restrict_
     if (tid < RB_WIN && i0 + tid >= r) win_w[tid] = 0;
     __syncthreads();
     if (wave == 0) {
-        u64 ew[2] = {win_w[lane], win_w[lane + 64]}, ec[2] = {0ull, 0ull};
+        // Coefficients in their final form, as in the RREF's window_round: the rebuilt diagonal row of step p is
+        // (e_p ^ d_diag ^ [diagonal even] d_donor) . B from zero, a row that takes it takes those coefficients, and 64 probe rows
+        // e_j, eliminated along, give every row outside the window its coefficients by table lookup (such a row is never a
+        // diagonal row or a donor of this panel, so what happens to it is linear in its word).
+        u64 ew[3] = {win_w[lane], win_w[lane + 64], 1ull << lane}, ed[3] = {0ull, 0ull, 0ull};
         int tt = 0;
         for (int sidx = 0; sidx < steps; ++sidx) {
             const u64 bal0 = __ballot(lane >= sidx && ((ew[0] >> sidx) & 1ull));
@@ -974,34 +977,30 @@ __global__ __launch_bounds__(RB_THREADS) void norm_panel_kernel(u64* __restrict_
             if (!(bal0 | bal1)) break;                                 // no donor inside the window
             const int h = bal0 ? 0 : 1;
             const int src = __ffsll((long long)(bal0 ? bal0 : bal1)) - 1;
-            u64 pwd = readlane64(ew[0], sidx), pcs = readlane64(ec[0], sidx);
+            u64 pwd = readlane64(ew[0], sidx), pd = readlane64(ed[0], sidx);
             int dn = -1;
             if (!(h == 0 && src == sidx)) {                             // diagonal entry is even: add the donor
                 pwd ^= readlane64(h ? ew[1] : ew[0], src);
-                pcs ^= readlane64(h ? ec[1] : ec[0], src);
+                pd ^= readlane64(h ? ed[1] : ed[0], src);
                 dn = (int)(i0 + src + 64 * h);
             }
+            pd ^= 1ull << sidx;
 #pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
+            for (int hh = 0; hh < 3; ++hh) {
                 if (hh == 0 && lane == sidx) {
                     ew[0] = pwd;
-                    ec[0] = 1ull << sidx;
+                    ed[0] = pd;
                 } else if ((ew[hh] >> sidx) & 1ull) {
                     ew[hh] ^= pwd;
-                    ec[hh] |= 1ull << sidx;
+                    ed[hh] ^= pd;
                 }
             }
-            if (lane == 0) {
-                pword[sidx] = pwd;
-                csel[sidx] = pcs;
-                donor[sidx] = dn;
-            }
+            if (lane == 0) donor[sidx] = dn;
             tt += 1;
         }
-        win_w[lane] = ew[0];
-        win_w[lane + 64] = ew[1];
-        win_c[lane] = ec[0];
-        win_c[lane + 64] = ec[1];
+        win_d[lane] = ed[0];
+        win_d[lane + 64] = ed[1];
+        DP[lane] = ed[2];
         if (lane == 0) misc[0] = tt;
     }
     __syncthreads();
@@ -1018,20 +1017,6 @@ __global__ __launch_bounds__(RB_THREADS) void norm_panel_kernel(u64* __restrict_
         st->zero_hi = i0 + t;
     }
     if (t == 0) return;
-#pragma unroll
-    for (int k = 0; k < RPT; ++k) {
-        const int64_t row = tid + (int64_t)RB_THREADS * k;
-        if (row >= i0 && row < i0 + RB_WIN) {
-            c[k] = win_c[row - i0];
-        } else {
-#pragma unroll 4
-            for (int p = 0; p < t; ++p) {
-                const u64 hit = 0ull - ((w[k] >> p) & 1ull);
-                w[k] ^= pword[p] & hit;
-                c[k] |= (1ull << p) & hit;
-            }
-        }
-    }
     // B_p = old diagonal row (+ old donor row)
     for (int64_t idx = tid; idx < (int64_t)t * ld; idx += RB_THREADS) {
         const int p = (int)(idx / ld);
@@ -1040,33 +1025,18 @@ __global__ __launch_bounds__(RB_THREADS) void norm_panel_kernel(u64* __restrict_
         if (donor[p] >= 0) v ^= a[(int64_t)donor[p] * ld + wd];
         snap[idx] = v;
     }
-    if (wave == 0) {
-        u64 v = lane < t ? 1ull << lane : 0ull;
-        const u64 cs = lane < t ? csel[lane] : 0ull;
-        for (int q = 0; q < t; ++q) {
-            const u64 vq = readlane64(v, q);
-            if ((cs >> q) & 1ull) v ^= vq;
-        }
-        V[lane] = v;
-    }
-    __syncthreads();
     for (int idx = tid; idx < 2048; idx += RB_THREADS) {
         const int g = idx >> 8, vv = idx & 255;
         u64 x = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x ^= V[8 * g + k] & (0ull - (u64)((vv >> k) & 1));
+        for (int k = 0; k < 8; ++k) x ^= DP[8 * g + k] & (0ull - (u64)((vv >> k) & 1));
         VT[idx] = x;
     }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int64_t row = tid + (int64_t)RB_THREADS * k;
-        if (row < r) {
-            u64 d = 0;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) d ^= VT[g * 256 + (int)((c[k] >> (8 * g)) & 255ull)];
-            dout[row] = d;
-        }
+        if (row < r) dout[row] = (row >= i0 && row < i0 + RB_WIN) ? win_d[row - i0] : byte_lookup(VT, w[k]);
     }
 }
 
