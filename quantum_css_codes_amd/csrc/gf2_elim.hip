@@ -923,8 +923,9 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_pair_kernel(u64* __res
 // them on a window of the rows i0 .. i0+127 in position order (the donor of step i is the first window entry at or after
 // the diagonal with the bit set).  With P_p the vector the reference adds to the other rows at step p,
 //     P_p = B_p ^ sum_{q<p} csel_p[q] P_q,   B_p = old_{i0+p} ^ [diagonal was even] old_{donor_p},
-// every other row ends as old_j ^ (c_j . V) . B and diagonal row p as (c_p . V) . B with c_p = {p} + later pivots that
-// hit it -- the same trailing update as the RREF, rebuilt rows starting from zero.  When the window holds no donor for
+// every other row ends as old_j ^ d_j . B and diagonal row p as d_p . B -- the same trailing update as the RREF, rebuilt rows
+// starting from zero.  The coefficients d are kept in that final form while the steps are simulated (a row that takes P_p takes
+// d of the rebuilt diagonal row, e_p ^ d_diagonal ^ [diagonal was even] d_donor), as in the RREF's window_round.  When the window holds no donor for
 // a step (the donor is further down, or a column swap is due) the panel stops there, its steps are applied, and that one
 // step is done by the sequential kernel on the materialised matrix.
 template <int RPT>
