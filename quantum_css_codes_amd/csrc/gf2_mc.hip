@@ -38,14 +38,15 @@ __global__ __launch_bounds__(GEN_THREADS) void sampler_kernel(u64 seed, int64_t 
             const bool last = s == th.nseg - 1;
             sample_segment(sample_key(seed, (u64)(first_sample + i)), s, last ? th.nb_last : GF2_SEG_BITS,
                            cdf_lds + (last ? GF2_SEG_CDF : 0), th.t_1, th.t_2, xz);
-        } else {
-#pragma unroll
-            for (int q = 0; q < 32; ++q) xz[q] = 0;
         }
+        // (a segment has zeroed and set the words below ceil(nb / 64) only; the words beyond are zero without being read)
+        const bool drawn = i < count && s < th.nseg;
+        const int used = drawn ? (((s == th.nseg - 1 ? th.nb_last : GF2_SEG_BITS) + 63) >> 6) * 2 : 0;
 #pragma unroll
         for (int q = 0; q < GF2_SEG_WORDS; ++q) {
             const int64_t w = (int64_t)s * GF2_SEG_WORDS + q;
-            const u64 x = ((u64)xz[2 * q + 1] << 32) | xz[2 * q], z = ((u64)xz[16 + 2 * q + 1] << 32) | xz[16 + 2 * q];
+            u64 x = 0, z = 0;
+            if (2 * q < used) x = ((u64)xz[2 * q + 1] << 32) | xz[2 * q], z = ((u64)xz[16 + 2 * q + 1] << 32) | xz[16 + 2 * q];
             if (TILED) {
                 if (w < lde) {                                    // the tiled pitch: the words rounded up to an even number
                     const int64_t at = (i >> 6) * 64 * lde + (w >> 1) * 128 + (i & 63) * 2 + (w & 1);

@@ -85,8 +85,8 @@ __device__ __forceinline__ void error_draw(u64 d, int k, int K, int nb, u64 t_1,
 
 // One segment, start to end, by one lane: xz = 32 dwords of this lane's own (x: 0..15, z: 16..31), zeroed here.
 __device__ static inline void sample_segment(u64 ks, int s, int nb, const u64* cdf, u64 t_1, u64 t_2, unsigned int* xz) {
-#pragma unroll
-    for (int i = 0; i < 32; ++i) xz[i] = 0;
+    const int used = ((nb + 63) >> 6) * 2;                             // dwords per component of the words this segment has (the callers read no more)
+    for (int i = 0; i < used; ++i) xz[i] = 0, xz[16 + i] = 0;
     const u64 d = segment_draw(ks, (u64)s);
     const int K = error_count(d, nb, cdf);
     for (int k = 0; k < K; ++k) {
