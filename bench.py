@@ -6,12 +6,14 @@ GF(2) RREF GB/s beside it.
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...        (no launcher, WORLD_SIZE unset: starts its N ranks itself, one process per GPU,
+                                         before this process has touched the GPU, and exits with their worst code)
 
 Workload (BASELINE.json configs[4]): the random dual code of config 4 --
 H1 = default_rng(4096) 2048 x 4096, H2 = first 2047 rows of nullspace(H1), both put in standard form by
 CSSCode exactly as css_code.py:51-61 does -- and depolarising errors (p = 0.01) from the counter-based
-sampler, pre-materialised in HBM before the timed region (2^20 samples per GPU, 1 GiB of packed errors:
-larger than the 256 MiB Infinity Cache, so every step streams from HBM).
+sampler, pre-materialised in HBM before the timed region (2^24 samples per GPU by default, --batch-log2: 16 GiB of
+packed errors, 64 times the 256 MiB Infinity Cache, so every step streams from HBM).
 
 One step = one pass of the hot path over that batch: s_z = H1 . e_z and s_x = H2 . e_x for every sample and
 the two syndrome-weight histograms.  Two implementations, same results bit for bit:
@@ -23,7 +25,9 @@ the two syndrome-weight histograms.  Two implementations, same results bit for b
   --algo dense             Four-Russians table kernel on tiled errors, slab-major syndromes written, then the
                            histogram kernel.  Data-independent.
 Per-GPU work is fixed as N grows ("weak"); ranks never exchange data on the path; the histograms are summed
-once with one all-reduce (RCCL) inside the timed region.  value = N * K * batch / max-over-ranks time.
+once with one all-reduce inside the timed region -- gf2_hist_allreduce: libgf2hip's own RCCL communicator, from the
+device buffer the kernels accumulate into, on the compute context's stream (--allreduce torch: torch.distributed's
+all_reduce on a copy instead).  value = N * K * batch / max-over-ranks time.
 
 The JSON line also carries
   roofline      the path against the HBM roofline: algorithmic bytes per launch (n/8 read [+ r/8
@@ -114,7 +118,9 @@ class Path(object):
         # that the two slab pipelines, which stress HBM and the SIMDs at different moments, overlap; None: one stream
         self.ctx2 = ctx2 if (ctx2 is not None and algo == "sparse") else None
         self.ls1, self.ls2 = _native.words_for(R1), _native.words_for(R2)
-        self.hz, self.hx = ctx.alloc((R1 + 1) * 8), ctx.alloc((R2 + 1) * 8)
+        # one buffer for both histograms, so that the ranks' sum is one all-reduce of (R1 + 1) + (R2 + 1) words
+        self.hist = ctx.alloc((R1 + 1 + R2 + 1) * 8)
+        self.hz, self.hx = self.hist.view(0, (R1 + 1) * 8), self.hist.view((R1 + 1) * 8, (R2 + 1) * 8)
         p = P_TOTAL / 3
         if algo == "sparse":
             # sample-major packed errors resident in HBM; histogram-only output (no syndromes written)
@@ -200,7 +206,7 @@ class Path(object):
             assert np.array_equal(got_z, want_z) and np.array_equal(got_x, want_x), "slab pipeline differs from the oracle"
 
     def free(self):
-        for name in ("ex", "ez", "s1", "s2", "hz", "hx"):
+        for name in ("ex", "ez", "s1", "s2", "hist"):
             buf = getattr(self, name, None)
             if buf is not None:
                 buf.free()
@@ -377,6 +383,36 @@ def small_code_numbers(ctx):
     return res
 
 
+def launch_ranks(gpus):
+    """`python bench.py --gpus N` without a launcher: the N ranks as child processes of this one, which never touches the
+    GPU (no re-exec of a process that has: the children are started first thing).  Rank 0 prints the JSON line on the
+    inherited stdout; the exit code is the worst of the ranks'; when one rank fails the others are stopped."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for proc in list(live):
+            rc = proc.poll()
+            if rc is None:
+                continue
+            live.remove(proc)
+            if rc != 0:
+                worst = worst or (rc if rc > 0 else 128 - rc)
+                for other in live:
+                    other.terminate()                  # exactly the processes started above
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -389,6 +425,9 @@ def main():
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo lets several ranks share one GPU to rehearse the multi-process path (histograms are "
                          "then all-reduced on the host); the driver's runs use nccl = RCCL")
+    ap.add_argument("--allreduce", choices=("gf2", "torch"), default="gf2",
+                    help="the histogram all-reduce of N > 1 ranks on the nccl backend: gf2 = gf2_hist_allreduce (libgf2hip's own "
+                         "RCCL communicator, device buffer, the context's stream), torch = torch.distributed.all_reduce")
     ap.add_argument("--algo", choices=("sparse", "dense"), default="sparse")
     ap.add_argument("--slab-pass-log2", type=int, default=None,
                     help="samples per pass of the slab pipeline through its workspace (GF2_OPT_SLAB_PASS_LOG2)")
@@ -399,6 +438,8 @@ def main():
                     help="issue both components of a step on one HIP stream (default: H2.e_x goes to a second context)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -418,8 +459,11 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from quantum_css_codes_amd import _native
-    from quantum_css_codes_amd.montecarlo import all_reduce_histograms
+    from quantum_css_codes_amd.montecarlo import all_reduce_histograms, rccl_comm
     ctx = _native.default_context()
+    # the ranks' own RCCL communicator (its id travels over the process group's rendezvous); ranks that share a GPU
+    # (--dist-backend gloo) cannot form one and sum on the host
+    comm = rccl_comm(ctx=ctx) if (world > 1 and args.dist_backend == "nccl" and args.allreduce == "gf2") else None
     code, h1, h2 = build_code()
     chk1, chk2 = ctx.check_create(h1, R1, N_QUBITS), ctx.check_create(h2, R2, N_QUBITS)
     batch = 1 << args.batch_log2
@@ -461,8 +505,10 @@ def main():
         path.sync()
     for _ in range(args.warmup):
         path.step()
-    if world > 1:
-        # the first collective sets up the communicator: keep that out of the timed region
+    path.sync()
+    if comm is not None:
+        comm.allreduce(path.hist, R1 + 1 + R2 + 1)       # the first collective sets up the channels: untimed
+    elif world > 1:
         all_reduce_histograms([path.hz.download((R1 + 1,), np.uint64), path.hx.download((R2 + 1,), np.uint64)])
     path.sync()
     path.hz.zero(), path.hx.zero()
@@ -480,9 +526,11 @@ def main():
     if path.ctx2 is not None:
         path.ctx2.sync()                                 # the side stream's work ends inside the timed interval
     gpu_ms = ctx.timer_stop()
+    if comm is not None:
+        comm.allreduce(path.hist, R1 + 1 + R2 + 1)       # in place, on the context's stream, behind the last step
     hist_z = path.hz.download((R1 + 1,), np.uint64)
     hist_x = path.hx.download((R2 + 1,), np.uint64)
-    if world > 1:
+    if world > 1 and comm is None:
         hist_z, hist_x = all_reduce_histograms([hist_z, hist_x])
     fence()
     elapsed = time.perf_counter() - t0
@@ -533,7 +581,9 @@ def main():
                                    "standard form), depolarising p=0.01, errors resident in HBM",
                        "algo": args.algo, "samples_per_gpu_per_step": batch, "global_samples_per_step": batch * world,
                        "streams": 2 if path.ctx2 is not None else 1,
-                       "parallelism": "sample-range shards, 1 histogram all-reduce"},
+                       "parallelism": "sample-range shards, 1 histogram all-reduce"
+                                      + ("" if world == 1 else " (gf2_hist_allreduce over librccl)" if comm is not None else
+                                         " (torch.distributed, %s)" % args.dist_backend)},
             "roofline": roof,
             "checks": {"histogram_total": int(hist_z.sum()), "expected_total": int(total),
                        "oracle_prefix": "512 samples of this rank's batch through the timed path == oracle/gf2_oracle.c",
@@ -546,8 +596,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(code)
         if world == 1 and not args.no_secondary:
             single_z = (hist_z // np.uint64(args.steps)).astype(np.uint64)      # same batch every step
-            # end to end: nothing resident, gf2_mc_run draws the errors itself (sampler || slab pipelines, three streams); its
-            # histogram over this rank's batch must be the timed path's
+            # end to end: nothing resident, gf2_mc_run draws the errors itself (record sampler, then gather / combine / misfits per
+            # component, in line on one stream); its histogram over this rank's batch must be the timed path's
             mc_count = max(batch, 1 << 24)
             # (the first call of this size allocates the context's workspaces: untimed)
             ctx.mc_run(chk1, chk2, SEED, 0, mc_count, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3, _native.HIST_WEIGHT)
@@ -611,8 +661,8 @@ def main():
             assert np.array_equal(other_z, sec_z * np.uint64(10)), "the two syndrome kernels disagree"
             out["secondary"] = {
                 "monte_carlo_end_to_end": {"value": mc_count / t_mc, "unit": "syndromes/s",
-                                           "what": "gf2_mc_run: the record sampler of chunk k+1 (records and identity words, no packed rows) beside the gather / "
-                                                   "combine / misfit kernels of chunk k on three streams, no resident input, host wall time incl. "
+                                           "what": "gf2_mc_run: record sampler (records and identity words, no packed rows), gather, combine, misfit "
+                                                   "kernels in line on one stream, chunks of 2^22 samples, no resident input, host wall time incl. "
                                                    "histogram download, %d samples, best of two calls after one untimed call" % mc_count},
                 other.algo + "_kernel": {"value": 10 * sec / (o_ms / 1e3), "unit": "syndromes/s", "ms_per_step": o_ms / 10,
                                          "roofline": roofline(other, o_launch, o_n), "histogram_ms_per_step": o_hist / 10},
@@ -623,6 +673,8 @@ def main():
             out["secondary"]["small_codes"] = small_code_numbers(ctx)
             other.free()
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -38,6 +38,7 @@ extern "C" {
 #define GF2_E_HIP        (-4)  /* HIP runtime error / no device                                  */
 #define GF2_E_NOMEM      (-5)  /* allocation failure                                             */
 #define GF2_E_NOTCSS     (-6)  /* NotImplementedError("only handles CSS codes"), css_code.py:762-763 */
+#define GF2_E_RCCL       (-7)  /* RCCL error (gf2_comm_*, gf2_hist_allreduce)                    */
 
 #define GF2_LAYOUT_SAMPLE_MAJOR 0  /* E: B rows of lde words (one error per row); S: B rows of lds words */
 #define GF2_LAYOUT_BIT_SLICED   1  /* E: n rows of ceil(B/64) words (word b of row q = qubit q of samples
@@ -85,13 +86,14 @@ int gf2_ctx_sync(gf2_ctx* ctx);
 #define GF2_F_DIAG_MC_TIMES        (1u << 13)  /* gf2_mc_run: print the host's phases to stderr                         */
 #define GF2_F_MC_ROWS              (1u << 14)  /* gf2_mc_run: packed rows from the sampler, records by the compact kernel */
 #define GF2_F_COMBINE_FOLDED       (1u << 15)  /* slab pipeline: the combine step of a pass inside the next pass' compact kernel */
+#define GF2_F_ALL                  ((1u << 16) - 1u)   /* every defined flag; gf2_ctx_set_flags refuses other bits              */
 int gf2_ctx_set_flags(gf2_ctx* ctx, uint32_t flags);
 int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
 /* Tunables of a context (value < 0 restores the default). */
 #define GF2_OPT_SLAB_PASS_LOG2  0   /* slab pipeline: 2^k samples per pass through the workspace, 12 <= k <= 22 (default 21) */
 #define GF2_OPT_COMBINE_BLOCKS  1   /* slab pipeline: workgroups of the combine kernel (default 128 * 1024 / threads)        */
 #define GF2_OPT_GATHER_REVERSE   2   /* slab pipeline: 1 (default) = the gather kernel walks the records last tile first  */
-#define GF2_OPT_REDO_BLOCKS_PER_CU 3 /* slab pipeline: workgroups per CU of the redo kernel (default 8)                       */
+#define GF2_OPT_REDO_BLOCKS_PER_CU 3 /* slab pipeline: workgroups per CU of the redo kernel, 1..64 (default 8)                 */
 #define GF2_OPT_MC_CHUNK_LOG2   4   /* gf2_mc_run at n <= 4096, sparse rates: 2^k samples per chunk, 16 <= k <= 22 (default 22; 21 with GF2_F_MC_ROWS) */
 #define GF2_OPT_COMBINE_THREADS 5   /* slab pipeline: threads per workgroup of the combine kernel, 64 / 128 / 256 / 512 / 1024 (default 1024) */
 #define GF2_OPT_COUNT           6
@@ -282,6 +284,27 @@ int gf2_mc_decode(gf2_ctx* ctx, const gf2_check* check_c1, const gf2_check* chec
                   const uint64_t* table_c1, const uint64_t* table_c2, uint64_t x_operator, uint64_t z_operator,
                   uint64_t seed, int64_t first_sample, int64_t count, double p_x, double p_y, double p_z,
                   uint64_t* counts_out);
+
+/* ---- multi-GPU: the histogram all-reduce -------------------------------------------------------------
+ * [build-defined, SURVEY.md 8e]  The Monte-Carlo run shards by sample range (sample i = f(seed, i)); ranks never exchange
+ * anything on the data path.  The one collective is the sum of the histograms -- keys as css_code.py:729, X errors against
+ * parity_check_c2 and Z errors against parity_check_c1 (css_code.py:457-470) -- over RCCL (xGMI inside a node).  librccl is
+ * loaded on first use; without it these calls fail with GF2_E_RCCL and nothing else is affected. */
+typedef struct gf2_comm gf2_comm;
+#define GF2_COMM_ID_BYTES 128
+/* One process per GPU: one rank makes an id, every rank receives it out of band (the launcher's store) and joins with the
+ * context whose device and stream the collective runs on.  Collective: returns when all `nranks` ranks have called it. */
+int gf2_comm_unique_id(void* id_out, size_t bytes);
+int gf2_comm_create(gf2_ctx* ctx, const void* id, int nranks, int rank, gf2_comm** comm_out);
+/* One process, `count` contexts on `count` different devices (ncclCommInitAll). */
+int gf2_comm_create_all(gf2_ctx* const* ctxs, int count, gf2_comm** comm_out);
+int gf2_comm_size(const gf2_comm* comm, int* nranks_out, int* nlocal_out);
+int gf2_comm_destroy(gf2_comm* comm);
+/* In-place sum over all ranks of `nbins` uint64 bins in device memory; hist_dev[i] lives on the device of the i-th context the
+ * communicator was created with (one entry for gf2_comm_create).  Enqueued on each context's stream behind whatever produced
+ * the bins; synchronous at return. */
+int gf2_hist_allreduce(gf2_comm* comm, uint64_t* const* hist_dev, int64_t nbins);
+int gf2_rccl_version(int* version_out);
 
 #ifdef __cplusplus
 }

@@ -119,6 +119,7 @@ int orc_nullspace(const u64* a, int64_t m, int64_t n, int64_t ld, u64* out, int6
 int orc_syndrome_batch(const u64* h, int64_t r, int64_t n, int64_t ldh, const u64* e, int64_t batch, int64_t lde,
                        u64* s, int64_t lds) {
     const int64_t words = (n + 63) >> 6;
+#pragma omp parallel for schedule(static) if (batch * r * words > (1 << 22))      /* samples are independent */
     for (int64_t b = 0; b < batch; ++b) {
         u64* out = s + b * lds;
         memset(out, 0, (size_t)lds * 8);

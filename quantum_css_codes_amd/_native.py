@@ -14,7 +14,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgf2hip.so")
 
-GF2_OK, GF2_E_ARG, GF2_E_COLUMNS, GF2_E_DEPENDENT, GF2_E_HIP, GF2_E_NOMEM, GF2_E_NOTCSS = 0, -1, -2, -3, -4, -5, -6
+GF2_OK, GF2_E_ARG, GF2_E_COLUMNS, GF2_E_DEPENDENT, GF2_E_HIP, GF2_E_NOMEM, GF2_E_NOTCSS, GF2_E_RCCL = 0, -1, -2, -3, -4, -5, -6, -7
+COMM_ID_BYTES = 128
 LAYOUT_SAMPLE_MAJOR, LAYOUT_BIT_SLICED, LAYOUT_TILED = 0, 1, 2
 HIST_FULL, HIST_WEIGHT = 0, 1
 K_SYNDROME, K_HIST, K_SAMPLER, K_ELIM = 0, 1, 2, 3
@@ -93,6 +94,13 @@ SIGNATURES = {
                       ctypes.c_double, _p],
     "gf2_mc_run": [_p, _p, _p, _c_u64, _c_i64, _c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                    ctypes.c_int, _p, _c_i64, _p, _c_i64],
+    "gf2_comm_unique_id": [_p, ctypes.c_size_t],
+    "gf2_comm_create": [_p, _p, ctypes.c_int, ctypes.c_int, _pp],
+    "gf2_comm_create_all": [_pp, ctypes.c_int, _pp],
+    "gf2_comm_size": [_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
+    "gf2_comm_destroy": [_p],
+    "gf2_hist_allreduce": [_p, _pp, _c_i64],
+    "gf2_rccl_version": [ctypes.POINTER(ctypes.c_int)],
 }
 _RESTYPES = {"gf2_last_error": ctypes.c_char_p, "gf2_tiled_ld": _c_i64, "gf2_tiled_words": _c_i64}
 
@@ -264,6 +272,12 @@ class DeviceBuffer(object):
         check(lib().gf2_dev_zero(self.ctx.handle, self.ptr, self.nbytes))
         return self
 
+    def view(self, offset, nbytes):
+        """A window of this buffer (same upload / download / zero interface; the parent keeps the memory)."""
+        if offset < 0 or nbytes < 0 or offset + nbytes > self.nbytes:
+            raise ValueError("view outside the buffer")
+        return DeviceView(self, int(offset), int(nbytes))
+
     def free(self):
         if self.ptr:
             check(lib().gf2_dev_free(self.ctx.handle, self.ptr))
@@ -275,6 +289,20 @@ class DeviceBuffer(object):
                 lib().gf2_dev_free(self.ctx.handle, self.ptr)
         except Exception:
             pass
+
+
+class DeviceView(DeviceBuffer):
+    """Part of a DeviceBuffer: owns nothing."""
+
+    def __init__(self, parent, offset, nbytes):
+        self.ctx, self.parent, self.nbytes = parent.ctx, parent, nbytes
+        self.ptr = parent.ptr + offset
+
+    def free(self):
+        self.ptr = None
+
+    def __del__(self):
+        pass
 
 
 class Check(object):
@@ -535,6 +563,76 @@ class Context(object):
         check(lib().gf2_mc_decode(self.handle, chk1.handle, chk2.handle, _ptr(t1), _ptr(t2), int(x_operator),
                                   int(z_operator), seed & 0xFFFFFFFFFFFFFFFF, first, count, p_x, p_y, p_z, _ptr(counts)))
         return counts
+
+
+class Comm(object):
+    """An RCCL communicator for the histogram all-reduce (gf2_comm_*).
+
+    Comm.unique_id()                     bytes to hand to every rank out of band (rank 0 makes them)
+    Comm(ctx, id, nranks, rank)          one process per GPU
+    Comm.all_local([ctx0, ctx1, ...])    one process, one context per device
+    """
+
+    def __init__(self, ctx, unique_id, nranks, rank):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("the communicator id has %d bytes" % COMM_ID_BYTES)
+        out = ctypes.c_void_p()
+        ident = ctypes.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        check(lib().gf2_comm_create(ctx.handle, ident, int(nranks), int(rank), ctypes.byref(out)))
+        self.handle, self.contexts, self.nranks = out.value, [ctx], int(nranks)
+
+    @staticmethod
+    def unique_id():
+        ident = ctypes.create_string_buffer(COMM_ID_BYTES)
+        check(lib().gf2_comm_unique_id(ident, COMM_ID_BYTES))
+        return ident.raw
+
+    @classmethod
+    def all_local(cls, contexts):
+        self = cls.__new__(cls)
+        handles = (ctypes.c_void_p * len(contexts))(*[c.handle for c in contexts])
+        out = ctypes.c_void_p()
+        check(lib().gf2_comm_create_all(handles, len(contexts), ctypes.byref(out)))
+        self.handle, self.contexts, self.nranks = out.value, list(contexts), len(contexts)
+        return self
+
+    def allreduce(self, bufs, nbins):
+        """In-place sum of `nbins` uint64 bins over all ranks; bufs: one DeviceBuffer per context of this communicator."""
+        bufs = list(bufs) if isinstance(bufs, (list, tuple)) else [bufs]
+        if len(bufs) != len(self.contexts):
+            raise ValueError("one buffer per context")
+        if any(b.nbytes < 8 * nbins for b in bufs):
+            raise ValueError("buffer smaller than nbins words")
+        ptrs = (ctypes.c_void_p * len(bufs))(*[b.ptr for b in bufs])
+        check(lib().gf2_hist_allreduce(self.handle, ptrs, int(nbins)))
+
+    def allreduce_host(self, hists):
+        """Sums a list of host uint64 arrays over the ranks (one all-reduce of the concatenation, through device memory of
+        this process's context)."""
+        if len(self.contexts) != 1:
+            raise ValueError("allreduce_host is for one context per process")
+        sizes = [int(np.asarray(h).size) for h in hists]
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(h, dtype=np.uint64).ravel() for h in hists]))
+        buf = self.contexts[0].alloc(flat.nbytes).upload(flat)
+        self.allreduce(buf, flat.size)
+        total = buf.download((flat.size,), np.uint64)
+        buf.free()
+        out, pos = [], 0
+        for size in sizes:
+            out.append(total[pos:pos + size].copy())
+            pos += size
+        return out
+
+    def close(self):
+        if self.handle:
+            handle, self.handle = self.handle, None
+            check(lib().gf2_comm_destroy(handle))
+
+
+def rccl_version():
+    out = ctypes.c_int(0)
+    check(lib().gf2_rccl_version(ctypes.byref(out)))
+    return int(out.value)
 
 
 _default = None

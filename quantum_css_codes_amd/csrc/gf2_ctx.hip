@@ -129,7 +129,7 @@ int gf2_ctx_create(int device, gf2_ctx** ctx_out) {
     ctx->num_cus = prop.multiProcessorCount;
     for (int k = 0; k < GF2_OPT_COUNT; ++k) ctx->opt[k] = -1;
     const char* env_flags = getenv("GF2_FLAGS");                    // read once, here: the initial routing flags
-    ctx->flags = env_flags ? (uint32_t)strtoul(env_flags, nullptr, 0) : 0u;
+    ctx->flags = env_flags ? (uint32_t)strtoul(env_flags, nullptr, 0) & GF2_F_ALL : 0u;     // unknown bits are dropped
     const int rc = create_streams_and_events(ctx);
     if (rc != GF2_OK) {                                             // the message of the failing call stays in g_error
         destroy_streams_and_events(ctx);
@@ -142,6 +142,7 @@ int gf2_ctx_create(int device, gf2_ctx** ctx_out) {
 
 int gf2_ctx_set_flags(gf2_ctx* ctx, uint32_t flags) {
     if (!ctx) GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_flags: null context");
+    if (flags & ~GF2_F_ALL) GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_flags: unknown flag bits 0x%x", flags & ~GF2_F_ALL);
     ctx->flags = flags;
     return GF2_OK;
 }
@@ -163,6 +164,10 @@ int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value) {
             GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_COMBINE_THREADS must be 64, 128, 256, 512 or 1024");
         if (option == GF2_OPT_COMBINE_BLOCKS && (value < 1 || value > 65535))
             GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_COMBINE_BLOCKS must be in 1..65535");
+        if (option == GF2_OPT_REDO_BLOCKS_PER_CU && (value < 1 || value > 64))
+            GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_REDO_BLOCKS_PER_CU must be in 1..64");
+        if (option == GF2_OPT_GATHER_REVERSE && value > 1)
+            GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_GATHER_REVERSE must be 0 or 1");
     }
     ctx->opt[option] = value < 0 ? -1 : value;
     return GF2_OK;
@@ -382,6 +387,8 @@ int gf2_prof_drain(gf2_ctx* ctx) {
     return GF2_OK;
 }
 
+// A slot is taken by gf2_prof_end, not by gf2_prof_begin: an entry point that returns with an error between the two leaves
+// nothing open -- the next gf2_prof_begin records into the same slot again.
 int gf2_prof_begin(gf2_ctx* ctx, int family) {
     if (!ctx->profile_on) return GF2_OK;
     if (ctx->prof_used == gf2_ctx::kProfSlots) GF2_TRY(gf2_prof_drain(ctx));

@@ -1461,36 +1461,39 @@ int gf2_normalize_dev(gf2_ctx* ctx, uint64_t* h_dev, int64_t r, int64_t n, int64
     const int64_t rows_per_wg = gf2_cdiv(ld, U2_CW) >= 16 ? 256 : 128;
     const dim3 ugrid((unsigned)gf2_cdiv(r, rows_per_wg), (unsigned)gf2_cdiv(ld, U2_CW), 1);
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
-    int64_t last_rank = 0;
-    for (int64_t round = 0;; ++round) {
+    // The host looks at the state when the work can be over at the earliest -- after ceil(remaining rows / 64) rounds -- and not
+    // every 8 rounds (a Steane- or Reed-Muller-sized check is done after one round; seven more would be 21 empty launches).
+    auto rounds = [&]() -> int {
+        int64_t last_rank = 0, last_round = -1, next_check = gf2_cdiv(r, 64) - 1;
+        for (int64_t round = 0;; ++round) {
 #define GF2_NP_LAUNCH(RPT)                                                                                              \
     hipLaunchKernelGGL((norm_panel_kernel<RPT>), dim3(1), dim3(RB_THREADS), 0, ctx->stream, (u64*)h_dev, r, n, ld, offset, \
                        st, status_dev, dco, snap)
-        if (rpt <= 1)
-            GF2_NP_LAUNCH(1);
-        else if (rpt <= 2)
-            GF2_NP_LAUNCH(2);
-        else if (rpt <= 4)
-            GF2_NP_LAUNCH(4);
-        else
-            GF2_NP_LAUNCH(8);
+            if (rpt <= 1)
+                GF2_NP_LAUNCH(1);
+            else if (rpt <= 2)
+                GF2_NP_LAUNCH(2);
+            else if (rpt <= 4)
+                GF2_NP_LAUNCH(4);
+            else
+                GF2_NP_LAUNCH(8);
 #undef GF2_NP_LAUNCH
-        // the RREF's trailing pass with this panel as the first of a pair that has no second (diagonal rows rebuilt from zero)
-        hipLaunchKernelGGL(rref_update_pair_kernel, ugrid, dim3(RB_THREADS), 128 * 1024, ctx->stream, (u64*)h_dev, r, ld, rows_per_wg,
-                           (const RrefState*)st, (const u64*)dco, (const u64*)dco, (const u64*)snap, (const u64*)snap, (const u64*)dco);
-        hipLaunchKernelGGL(eliminate_kernel<ELIM_NORMALIZE>, dim3(1), dim3(ELIM_THREADS), 0, ctx->stream, (u64*)h_dev, r, n, ld,
-                           offset, (int64_t*)nullptr, (int64_t)0, (int64_t*)nullptr, swaps_dev, nswaps_dev, status_dev, st);
-        GF2_HIP(hipGetLastError());
-        if ((round & 7) == 7 || round >= r) {
+            // the RREF's trailing pass with this panel as the first of a pair that has no second (diagonal rows rebuilt from zero)
+            hipLaunchKernelGGL(rref_update_pair_kernel, ugrid, dim3(RB_THREADS), 128 * 1024, ctx->stream, (u64*)h_dev, r, ld, rows_per_wg,
+                               (const RrefState*)st, (const u64*)dco, (const u64*)dco, (const u64*)snap, (const u64*)snap, (const u64*)dco);
+            hipLaunchKernelGGL(eliminate_kernel<ELIM_NORMALIZE>, dim3(1), dim3(ELIM_THREADS), 0, ctx->stream, (u64*)h_dev, r, n, ld,
+                               offset, (int64_t*)nullptr, (int64_t)0, (int64_t*)nullptr, swaps_dev, nswaps_dev, status_dev, st);
+            GF2_HIP(hipGetLastError());
+            if (round < next_check) continue;
             RrefState host;
             int status = 0;
             GF2_HIP(hipMemcpyAsync(&host, st, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
             GF2_HIP(hipMemcpyAsync(&status, status_dev, 4, hipMemcpyDeviceToHost, ctx->stream));
             GF2_HIP(hipStreamSynchronize(ctx->stream));
-            if (status != 0 || (host.rank >= r && !host.stalled)) break;
-            if (host.rank - last_rank < 64) {
-                // mostly stalls (a matrix that needs a column swap at nearly every step): the panels do not pay;
-                // let the sequential kernel take every remaining step from here
+            if (status != 0 || (host.rank >= r && !host.stalled)) return GF2_OK;
+            if (host.rank - last_rank < 8 * (round - last_round)) {
+                // mostly stalls (a matrix that needs a column swap at nearly every step: fewer than 8 rows per round): the panels
+                // do not pay; let the sequential kernel take every remaining step from here
                 host.stalled = 2;
                 GF2_HIP(hipMemcpyAsync(st, &host, sizeof(host), hipMemcpyHostToDevice, ctx->stream));
                 GF2_HIP(hipStreamSynchronize(ctx->stream));
@@ -1498,13 +1501,17 @@ int gf2_normalize_dev(gf2_ctx* ctx, uint64_t* h_dev, int64_t r, int64_t n, int64
                                    n, ld, offset, (int64_t*)nullptr, (int64_t)0, (int64_t*)nullptr, swaps_dev, nswaps_dev,
                                    status_dev, st);
                 GF2_HIP(hipGetLastError());
-                break;
+                return GF2_OK;
             }
             last_rank = host.rank;
+            last_round = round;
+            const int64_t more = gf2_cdiv(r - host.rank, 64);
+            next_check = round + (more < 1 ? 1 : (more > 8 ? 8 : more));
         }
-    }
-    GF2_TRY(gf2_prof_end(ctx));
-    return GF2_OK;
+    };
+    const int rc = rounds();
+    const int rc_prof = gf2_prof_end(ctx);                            // the profile slot is closed on the error paths too
+    return rc != GF2_OK ? rc : rc_prof;
 }
 
 int gf2_normalize(gf2_ctx* ctx, uint64_t* h, int64_t r, int64_t n, int64_t ld, int64_t offset, int64_t* swaps_out,

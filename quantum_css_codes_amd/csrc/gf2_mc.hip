@@ -343,7 +343,8 @@ __global__ __launch_bounds__(256) void mc_small_kernel(DecodeRows rows, int r1, 
 }
 
 // The sampler's tables for (rates, n) in the context's device buffer; uploaded only when they change (a Monte-Carlo run asks
-// once per chunk).  The upload waits for the context's stream: a kernel in flight may still read the old tables.
+// once per chunk).  The upload waits for the context's stream AND its side streams: a kernel in flight on any of them (the
+// packed-row route's pipelines run there) may still read the old tables.
 int gf2_seg_tables(gf2_ctx* ctx, double p_x, double p_y, double p_z, int64_t n, SegTables* out) {
     GF2_TRY(check_probabilities(p_x, p_y, p_z));
     const double p_t = p_x + p_y + p_z, p_xy = p_x + p_y;
@@ -361,6 +362,7 @@ int gf2_seg_tables(gf2_ctx* ctx, double p_x, double p_y, double p_z, int64_t n, 
         binomial_cdf_table(t_any, GF2_SEG_BITS, host.data(), GF2_SEG_CDF);
         binomial_cdf_table(t_any, out->nb_last, host.data() + GF2_SEG_CDF, GF2_SEG_CDF);
         GF2_TRY(gf2_stream_wait(ctx->stream));
+        for (int k = 0; k < 2; ++k) GF2_TRY(gf2_stream_wait(ctx->side[k]));
         GF2_HIP(hipMemcpy(ctx->seg_cdf_dev, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice));
         ctx->seg_key_nb = out->nb_last;
         ctx->seg_key_t = t_any;

@@ -126,7 +126,12 @@ def encode_plus(code, prog, block, ancilla, scratch):
 
 
 def _pauli_program(code, gate_name, blocks):
-    """css_code.py:386-409: the logical Pauli as physical Paulis read off the operator matrices (Y where X and Z meet)."""
+    """css_code.py:386-409: the logical Pauli as physical Paulis read off the operator matrices (Y where X and Z meet).
+
+    Y is i * X_op * Z_op (css_code.py:163-172); every qubit the two share contributes X * Z = -i Y, so the product's coefficient
+    is i * (-i)^m for m shared qubits, and the reference asserts that it is 1: m = 1 (mod 4), or AssertionError.  Instruction
+    order is the order of the product's factors: the qubits of X_op ascending (Y where Z_op acts too), then the qubits only
+    Z_op acts on, ascending."""
     if gate_name == 'I':
         return Program()
     if gate_name not in ('X', 'Y', 'Z'):
@@ -134,13 +139,15 @@ def _pauli_program(code, gate_name, blocks):
     assert len(blocks) == 1
     x_row = code.x_operator_matrix()[0] if gate_name in ('X', 'Y') else np.zeros(code.n, dtype=int)
     z_row = code.z_operator_matrix()[0] if gate_name in ('Z', 'Y') else np.zeros(code.n, dtype=int)
+    if gate_name == 'Y':
+        shared = int(np.count_nonzero(np.logical_and(x_row, z_row)))
+        assert shared % 4 == 1, "logical Y = i X Z has coefficient i * (-i)^%d, not 1" % shared
     prog = Program()
     for q in range(code.n):
-        if x_row[q] and z_row[q]:
-            prog += gates.Y(blocks[0].qubits[q])
-        elif x_row[q]:
-            prog += gates.X(blocks[0].qubits[q])
-        elif z_row[q]:
+        if x_row[q]:
+            prog += gates.Y(blocks[0].qubits[q]) if z_row[q] else gates.X(blocks[0].qubits[q])
+    for q in range(code.n):
+        if z_row[q] and not x_row[q]:
             prog += gates.Z(blocks[0].qubits[q])
     return prog
 

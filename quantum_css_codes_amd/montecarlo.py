@@ -43,10 +43,27 @@ def run_local(code, num_samples, p_x, p_y, p_z, seed=0, first_sample=0, mode=Non
     return {'hist_z': hist_z, 'hist_x': hist_x, 'mode': mode}
 
 
-def all_reduce_histograms(hists, group=None, device=None):
-    """Sum a list of uint64 histograms over the ranks of torch.distributed (one all-reduce of the
-    concatenation).  Counts stay below 2^63, so the int64 transport is exact.  With no process group
-    initialised the input is returned unchanged."""
+def rccl_comm(group=None, ctx=None):
+    """A communicator of libgf2hip's own (gf2_comm_create over librccl) spanning the ranks of the torch.distributed group:
+    rank 0 makes the id, the group's rendezvous carries its 128 bytes to the others (any backend; gloo needs no GPU
+    runtime in torch).  The histogram all-reduce then runs on the compute context's stream from device memory, with no
+    second GPU runtime in between.  None when no process group is initialised."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [_native.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return _native.Comm(ctx or _native.default_context(), box[0], world, rank)
+
+
+def all_reduce_histograms(hists, group=None, device=None, comm=None):
+    """Sum a list of uint64 histograms over the ranks (one all-reduce of the concatenation).  With `comm` (a _native.Comm,
+    see rccl_comm) the sum runs over libgf2hip's RCCL communicator; otherwise over torch.distributed -- RCCL on the
+    "nccl" backend, gloo on CPU; counts stay below 2^63, so the int64 transport is exact.  With neither a communicator nor
+    a process group the input is returned unchanged."""
+    if comm is not None:
+        return comm.allreduce_host(hists)
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
@@ -67,9 +84,10 @@ def all_reduce_histograms(hists, group=None, device=None):
     return out
 
 
-def run_sharded(code, num_samples, p_x, p_y, p_z, seed=0, first_sample=0, mode=None, group=None, local_fn=None):
-    """This rank's shard of the global range, then the histogram all-reduce.  `local_fn` (same signature
-    as run_local) replaces the GPU computation; the CPU tests of the sharding use it."""
+def run_sharded(code, num_samples, p_x, p_y, p_z, seed=0, first_sample=0, mode=None, group=None, local_fn=None, comm=None):
+    """This rank's shard of the global range, then the histogram all-reduce (over `comm` when given, see
+    all_reduce_histograms).  `local_fn` (same signature as run_local) replaces the GPU computation; the CPU tests of the
+    sharding use it."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -78,7 +96,7 @@ def run_sharded(code, num_samples, p_x, p_y, p_z, seed=0, first_sample=0, mode=N
     start, mine = shard_range(first_sample, num_samples, rank, world)
     fn = local_fn or run_local
     part = fn(code, mine, p_x, p_y, p_z, seed=seed, first_sample=start, mode=mode)
-    hist_z, hist_x = all_reduce_histograms([part['hist_z'], part['hist_x']], group=group)
+    hist_z, hist_x = all_reduce_histograms([part['hist_z'], part['hist_x']], group=group, comm=comm)
     return {'hist_z': hist_z, 'hist_x': hist_x, 'mode': part['mode'], 'shard': (start, mine)}
 
 

@@ -469,6 +469,35 @@ def test_monte_carlo_n4096_weight_histograms(ctx):
     assert int(hz.sum()) == count and int(hx.sum()) == count
 
 
+def test_monte_carlo_on_the_config4_code_itself(ctx, route):
+    # BASELINE.json configs[4] as bench.py builds it -- H2 the dual of H1, both in the reference's standard form (digests of
+    # config4_golden.npz asserted by build_code) -- not a stand-in with independent random checks: 2^17 + 4097 samples through
+    # gf2_mc_run's default route (record sampler -> gather -> combine -> misfits), through the packed-row route (sampler ->
+    # compact -> gather -> combine -> redo) and through the resident-error entry point the benchmark times, against the oracle
+    import bench
+    code, h1, h2 = bench.build_code()
+    c1, c2 = ctx.check_create(h1, bench.R1, bench.N_QUBITS), ctx.check_create(h2, bench.R2, bench.N_QUBITS)
+    count, first, p = (1 << 17) + 4097, 3 * 10**9, bench.P_TOTAL / 3
+    want = c_oracle.mc(h1, bench.R1, h2, bench.R2, bench.N_QUBITS, bench.SEED, first, count, p, p, p, 1)
+    assert int(want[0].sum()) == count and int(want[1].sum()) == count
+    got = ctx.mc_run(c1, c2, bench.SEED, first, count, p, p, p, _native.HIST_WEIGHT)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), "record-sampler route"
+    route.force("GF2_MC_ROWS")
+    rows = ctx.mc_run(c1, c2, bench.SEED, first, count, p, p, p, _native.HIST_WEIGHT)
+    route.release("GF2_MC_ROWS")
+    assert np.array_equal(rows[0], want[0]) and np.array_equal(rows[1], want[1]), "packed-row route"
+    lde = _native.words_for(bench.N_QUBITS)
+    ex, ez = ctx.alloc(count * lde * 8), ctx.alloc(count * lde * 8)
+    ctx.sample_errors_dev(bench.N_QUBITS, bench.SEED, first, count, p, p, p, ex, ez, lde)
+    hz, hx = ctx.alloc((bench.R1 + 1) * 8).zero(), ctx.alloc((bench.R2 + 1) * 8).zero()
+    ctx.syndrome_sparse_dev(c1, ez, count, lde, None, 0, hz, bench.R1 + 1)
+    ctx.syndrome_sparse_dev(c2, ex, count, lde, None, 0, hx, bench.R2 + 1)
+    assert np.array_equal(hz.download((bench.R1 + 1,), np.uint64), want[0]), "resident errors, slab pipeline, H1.e_z"
+    assert np.array_equal(hx.download((bench.R2 + 1,), np.uint64), want[1]), "resident errors, slab pipeline, H2.e_x"
+    for b in (ex, ez, hz, hx):
+        b.free()
+
+
 # ---- tiled device layout -----------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("shape", [(70, 1), (130, 64), (200, 65), (4096, 300), (4100, 130)])
@@ -613,6 +642,9 @@ def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, route):
     assert int(piped[0].sum()) == big[2] and int(piped[1].sum()) == big[2]
     for got in (piped_again, fused_big, serial_big):
         assert np.array_equal(got[0], piped[0]) and np.array_equal(got[1], piped[1])
+    # ... and the default route's 2.2 million samples against the oracle directly, not only against the other routes
+    want_big = c_oracle.mc(h1, 2048, h2, 2047, 4096, *big[:-1], 1)
+    assert np.array_equal(piped[0], want_big[0]) and np.array_equal(piped[1], want_big[1])
     # a rate at which most tiles have samples that do not fit their records (17 columns per sample on average): the misfit
     # kernel draws those again; and a ragged last tile
     hot = (0x5EED, 99, 70001, 0.005, 0.0035, 0.002, _native.HIST_WEIGHT)
@@ -622,6 +654,8 @@ def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, route):
     route.release("GF2_MC_FUSED")
     assert int(hot_records[0].sum()) == hot[2] and int(hot_records[1].sum()) == hot[2]
     assert np.array_equal(hot_records[0], hot_fused[0]) and np.array_equal(hot_records[1], hot_fused[1])
+    want_hot = c_oracle.mc(h1, 2048, h2, 2047, 4096, *hot[:-1], 1)
+    assert np.array_equal(hot_records[0], want_hot[0]) and np.array_equal(hot_records[1], want_hot[1])
 
 
 @pytest.mark.parametrize("case", [(1023, 511, 511, 512, 0.02), (2047, 1023, 1023, 1024, 0.012), (3000, 1500, 1400, 1536, 0.008),
@@ -648,6 +682,8 @@ def test_monte_carlo_record_sampler_other_shapes(case, ctx, route):
     assert int(records[0].sum()) == args[2] and int(records[1].sum()) == args[2]
     for got in (fused, rows):
         assert np.array_equal(got[0], records[0]) and np.array_equal(got[1], records[1])
+    want_all = c_oracle.mc(h1, r1, h2, r2, n, *args[:-1], 1)           # the default route's whole call against the oracle
+    assert np.array_equal(records[0], want_all[0]) and np.array_equal(records[1], want_all[1])
     want = c_oracle.mc(h1, r1, h2, r2, n, 31, 500, 3000, p_total / 2, p_total / 4, p_total / 4, 1)
     small = ctx.mc_run(c1, c2, 31, 500, 3000, p_total / 2, p_total / 4, p_total / 4, _native.HIST_WEIGHT)
     assert np.array_equal(small[0], want[0]) and np.array_equal(small[1], want[1])

@@ -218,7 +218,13 @@ def test_apply_gate_paulis_transversals_and_refusals(steane_h):
     start = len(prog)
     code.apply_gate(prog, 'Y', a)
     assert [(i[1], a.qubits.index(i[2][0])) for i in prog.instructions[start:]] == \
-        [('Z', 1), ('Z', 2), ('X', 3), ('X', 4), ('Y', 6)]                                                            # :55-59
+        [('X', 3), ('X', 4), ('Y', 6), ('Z', 1), ('Z', 2)]       # test_css_code.py:55-59's factors, in the order of i * X_op * Z_op
+    # css_code.py:163-172 asserts the coefficient of i * X_op * Z_op: one shared qubit (mod 4), as here; a code whose logical
+    # X and Z share none raises AssertionError in the reference, and here
+    shifted = OracleCode(steane_h, steane_h)
+    shifted.x_operator_matrix = lambda: np.array([[0, 0, 0, 1, 1, 1, 0]])
+    with pytest.raises(AssertionError):
+        shifted.apply_gate(Program(), 'Y', a)
     start = len(prog)
     code.apply_gate(prog, 'CNOT', a, b)
     assert [(i[1], i[2]) for i in prog.instructions[start:]] == [('CNOT', (a.qubits[q], b.qubits[q])) for q in range(7)]

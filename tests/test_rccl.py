@@ -1,0 +1,155 @@
+"""
+The one collective of the path: the sum of the ranks' histograms over RCCL.
+
+CPU part: librccl loads through the C ABI (gf2_rccl_version) and the communicator entry points refuse bad arguments without
+a GPU.  GPU part (one MI355X): RCCL runs for real with one rank -- gf2_comm_create_all / gf2_comm_create + gf2_hist_allreduce in
+this process, torch.distributed's "nccl" backend in a fresh child process under montecarlo.run_sharded -- and bench.py starts its
+own ranks when no launcher did.  More than one rank over RCCL needs more than one GPU: the driver's scaling run.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from quantum_css_codes_amd import _native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_rccl_loads_through_the_abi():
+    assert _native.rccl_version() >= 20000                 # NCCL-style version number, e.g. 22707
+    with open("/proc/self/maps") as maps:
+        assert "librccl" in maps.read()
+
+
+def test_comm_argument_errors_without_a_gpu():
+    lib = _native.lib()
+    import ctypes
+    out = ctypes.c_void_p()
+    assert lib.gf2_comm_unique_id(None, 128) == _native.GF2_E_ARG
+    small = ctypes.create_string_buffer(64)
+    assert lib.gf2_comm_unique_id(small, 64) == _native.GF2_E_ARG
+    assert lib.gf2_comm_create(None, small, 1, 0, ctypes.byref(out)) == _native.GF2_E_ARG
+    assert lib.gf2_comm_create_all(None, 1, ctypes.byref(out)) == _native.GF2_E_ARG
+    assert lib.gf2_hist_allreduce(None, None, 8) == _native.GF2_E_ARG
+    assert lib.gf2_comm_destroy(None) == _native.GF2_OK
+    assert b"gf2_hist_allreduce" in lib.gf2_last_error() or b"bad argument" in lib.gf2_last_error()
+
+
+@pytest.mark.gpu
+def test_hist_allreduce_one_rank_in_this_process():
+    # RCCL initialises on the device, all-reduces the 32 KiB of configs[4]'s two weight histograms in place on the context's
+    # stream; with one rank the sum is the input
+    ctx = _native.default_context()
+    nbins = 2049 + 2048
+    rng = np.random.default_rng(3)
+    bins = rng.integers(0, 2**62, nbins, dtype=np.int64).view(np.uint64)
+    for make in (lambda: _native.Comm.all_local([ctx]), lambda: _native.Comm(ctx, _native.Comm.unique_id(), 1, 0)):
+        comm = make()
+        buf = ctx.alloc(nbins * 8).upload(bins)
+        comm.allreduce(buf, nbins)
+        comm.allreduce(buf, nbins)
+        assert np.array_equal(buf.download((nbins,), np.uint64), bins)
+        parts = comm.allreduce_host([bins[:2049], bins[2049:]])
+        assert np.array_equal(parts[0], bins[:2049]) and np.array_equal(parts[1], bins[2049:])
+        buf.free()
+        comm.close()
+    with open("/proc/self/maps") as maps:
+        assert "librccl" in maps.read()
+    with pytest.raises(_native.GF2Error):
+        _native.Comm.all_local([ctx, ctx])                  # one communicator cannot hold a device twice
+
+
+NCCL_CHILD = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch
+import torch.distributed as dist
+from quantum_css_codes_amd import _native, montecarlo
+from quantum_css_codes_amd.css_code import CSSCode
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+h = np.array([[0, 0, 0, 1, 1, 1, 1], [0, 1, 1, 0, 0, 1, 1], [1, 0, 1, 0, 1, 0, 1]])
+code = CSSCode(h, h)
+want = montecarlo.run_local(code, 200001, 0.02, 0.01, 0.03, seed=5, first_sample=17)
+# torch.distributed's all_reduce on the nccl backend (= RCCL), the buffer on the compute context's device
+got = montecarlo.run_sharded(code, 200001, 0.02, 0.01, 0.03, seed=5, first_sample=17)
+assert got['shard'] == (17, 200001)
+assert np.array_equal(got['hist_z'], want['hist_z']) and np.array_equal(got['hist_x'], want['hist_x'])
+# libgf2hip's own communicator, its id carried by the process group
+comm = montecarlo.rccl_comm()
+again = montecarlo.run_sharded(code, 200001, 0.02, 0.01, 0.03, seed=5, first_sample=17, comm=comm)
+assert np.array_equal(again['hist_z'], want['hist_z']) and np.array_equal(again['hist_x'], want['hist_x'])
+big = np.arange(4097, dtype=np.uint64) * np.uint64(1 << 40)            # 32 KiB, values beyond 2^32
+assert np.array_equal(montecarlo.all_reduce_histograms([big])[0], big)
+assert np.array_equal(montecarlo.all_reduce_histograms([big], comm=comm)[0], big)
+comm.close()
+dist.destroy_process_group()
+maps = open("/proc/self/maps").read()
+assert "librccl" in maps and "libgf2hip.so" in maps
+print("nccl child ok", int(got['hist_z'].sum()))
+"""
+
+
+@pytest.mark.gpu
+def test_world_size_one_nccl_process_group_in_a_child_process(tmp_path):
+    script = tmp_path / "nccl_child.py"
+    script.write_text(NCCL_CHILD % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), GF2_DEVICE="0")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    done = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=600, text=True)
+    assert done.returncode == 0, done.stderr[-3000:]
+    assert "nccl child ok 200001" in done.stdout
+
+
+def bench_line(done):
+    lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, done.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    # `python bench.py --gpus 2` with WORLD_SIZE unset: two child ranks started before anything touches the GPU (they share this
+    # box's one GPU, hence gloo; the nccl default needs one GPU per rank)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GF2_DEVICE"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "2", "--warmup", "1",
+           "--batch-log2", "17", "--no-cpu-baseline", "--no-secondary", "--no-settle"]
+    done = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert done.returncode == 0, done.stderr[-3000:]
+    out = bench_line(done)
+    assert out["n_gpus"] == 2 and out["config"]["global_samples_per_step"] == 2 << 17
+    assert out["checks"]["histogram_total"] == 2 * (2 << 17)
+
+
+@pytest.mark.gpu
+def test_bench_one_rank_under_the_launcher_uses_the_nccl_backend():
+    # the driver's launch line with N = 1: torch.distributed.run, nccl backend; a world of one has no process group, and the line
+    # is the plain one
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--batch-log2", "17", "--no-cpu-baseline", "--no-secondary", "--no-settle"]
+    done = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert done.returncode == 0, done.stderr[-3000:]
+    out = bench_line(done)
+    assert out["n_gpus"] == 1 and out["checks"]["histogram_total"] == 2 << 17
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=120, text=True)
+    assert done.returncode != 0 and "WORLD_SIZE=3" in done.stderr
