@@ -23,7 +23,8 @@ K_SYNDROME, K_HIST, K_SAMPLER, K_ELIM = 0, 1, 2, 3
 (F_SPARSE_GATHER, F_SPARSE_SLABS, F_NO_REDO, F_GATHER_GENERIC, F_MC_UNFUSED, F_MC_DENSE, F_MC_FUSED, F_MC_PIPELINE,
  F_RREF_SEQUENTIAL, F_RREF_NO_SMALL, F_NORMALIZE_SEQUENTIAL, F_SAMPLER_GENERIC, F_DIAG_CLOCKS,
  F_DIAG_MC_TIMES, F_MC_ROWS, F_COMBINE_FOLDED) = (1 << k for k in range(16))
-OPT_SLAB_PASS_LOG2, OPT_COMBINE_BLOCKS, OPT_GATHER_REVERSE, OPT_REDO_BLOCKS_PER_CU, OPT_MC_CHUNK_LOG2, OPT_COMBINE_THREADS = 0, 1, 2, 3, 4, 5
+(OPT_SLAB_PASS_LOG2, OPT_COMBINE_BLOCKS, OPT_GATHER_REVERSE, OPT_REDO_BLOCKS_PER_CU, OPT_MC_CHUNK_LOG2, OPT_COMBINE_THREADS,
+ OPT_GATHER_CROSS) = range(7)
 
 
 class GF2Error(RuntimeError):

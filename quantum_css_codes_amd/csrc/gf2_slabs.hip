@@ -31,9 +31,9 @@
 #define CMP_WAVES 4
 #define CMP_THREADS (64 * CMP_WAVES)
 #define CMP_SUB 8                             // samples per compaction sub-pass
-#define REC_SLOTS 32                          // 16-bit slots per record: count + 31 columns
+#define REC_SLOTS 32                          // 16-bit slots per record: 31 columns (slots 0 .. 30) + the header in the LAST slot
 #define REC_OVER 0xFFu                        // count byte of a sample that was finished by the slow routine
-#define REC_DONE 0x4000u                      // slot 0 of a sample finished by the slow routine whose count byte still stands
+#define REC_DONE 0x4000u                      // header of a sample finished by the slow routine whose count byte still stands
 #define REC_FLAG 0xFFFFu                      // its partial weights
 #define REC_STRAY 0xFF80u                     // | tile-local sample index: partial weight of a sample that has a column compact left out
 #define GAT_THREADS 1024
@@ -44,10 +44,13 @@
 #define SLAB_MAX_BATCH (1 << 22)              // most samples per pass through the workspace (32-bit byte offsets of 512-byte rows)
 #define SLAB_DEFAULT_BATCH (1 << 21)
 
-// Records of a tile of 64 samples, sorted by count: the 32 shortest as 32-byte records (slot 0 + 15 columns), the 32 longest
-// as 64-byte records (slot 0 + 31 columns) -- 3 KiB per tile instead of 4.  Seven samples in ten list at most 15 columns at the
+// Records of a tile of 64 samples, sorted by count: the 32 shortest as 32-byte records (15 columns + header), the 32 longest
+// as 64-byte records (31 columns + header) -- 3 KiB per tile instead of 4.  Seven samples in ten list at most 15 columns at the
 // benchmark's rate, so the lower half of a sorted tile fits (a tile where it does not -- more than 32 samples with 16 or more
 // columns -- has the misfits finished on the spot like samples beyond 31 columns).  Group g = tile * 4 + quartile holds 16 records.
+// The header (count | tile-local sample << 8 | flags) is the record's LAST slot (15 or 31), the columns start at slot 0: the
+// gather kernels look up ceil(count / 2) slot pairs and never the header (round 2 kept it in slot 0 and paid a lookup of the
+// zero entry per record for it).
 #define TILE_REC_BYTES 3072
 #define SHORT_SLOTS 16
 __device__ __forceinline__ unsigned int record_quarter_offset(unsigned int g, unsigned int lane_rec, unsigned int part) {
@@ -101,8 +104,8 @@ struct CompactArgs {
 // LDS per wavefront.  Non-zero (sample, word) pairs wait in a ring of 128 until 64 of them are there, so every pass over them
 // has all lanes busy; a pass writes the FIRST column of each word and moves words with more columns to the `left` list,
 // which is worked off when it fills up and at the end of the tile.  The 64 records of the tile are 64 contiguous bytes each
-// (slot k of sample j at 64 j + 2 k); a column beyond slot 31 is written to the next record's slot 0, which is filled in
-// last (the 16 bytes after the records take sample 63's).
+// (slot k of sample j at 64 j + 2 k); a column beyond slot 30 is written to the record's own slot 31, the header's place,
+// which is filled in last.
 #define CMP_RING 128
 #define CMP_LEFT 128
 struct alignas(16) CompactWaveLds {
@@ -290,7 +293,7 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void sl
                 while (v) {
                     const unsigned int bit = (unsigned int)(__ffsll((long long)v) - 1);
                     v &= v - 1;
-                    *reinterpret_cast<unsigned short*>(p < rj + 64 ? p : rj + 64) = (unsigned short)ord16(cb, bit);
+                    *reinterpret_cast<unsigned short*>(p < rj + 62 ? p : rj + 62) = (unsigned short)ord16(cb, bit);
                     p += 2;
                 }
             }
@@ -308,14 +311,14 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void sl
             v = L.ring_v[at];
             const unsigned int m = L.ring_m[at];
             const unsigned int j = m >> 6, col0 = (m & 63u) << 6;
-            const unsigned int slot = atomicAdd(&L.cnt[j], (unsigned int)__popcll(v)) + 1u;
+            const unsigned int slot = atomicAdd(&L.cnt[j], (unsigned int)__popcll(v));
             const unsigned int bit = (unsigned int)(__ffsll((long long)v) - 1);
             const unsigned int cb = col_base16(col0, bit);
             unsigned char* const rj = L.rec + j * 64;
-            *reinterpret_cast<unsigned short*>(rj + (slot < REC_SLOTS ? slot * 2 : 64u)) = (unsigned short)ord16(cb, bit);
+            *reinterpret_cast<unsigned short*>(rj + (slot < REC_SLOTS - 1 ? slot * 2 : 62u)) = (unsigned short)ord16(cb, bit);
             v &= v - 1;
             more = v != 0;
-            meta = (slot + 1 < REC_SLOTS ? slot + 1 : (unsigned int)REC_SLOTS) | (j << 6) | (cb << 16);
+            meta = (slot + 1 < REC_SLOTS - 1 ? slot + 1 : (unsigned int)(REC_SLOTS - 1)) | (j << 6) | (cb << 16);
         }
         const u64 mact = __ballot(more);
         if (more) {
@@ -442,7 +445,13 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void sl
         for (int q = 0; q < 4; ++q) R[q] = reinterpret_cast<const u32x4*>(L.rec)[lane * 4 + q];
         // a misfit of the lower half keeps its place and its (truncated) count, so that the last record of its step still
         // carries the step's largest count; the gather kernel does its lookups and throws the result away
-        R[0].x = (R[0].x & 0xFFFF0000u) | (over ? REC_OVER : (misfit ? REC_DONE | (SHORT_SLOTS - 1) : c)) | ((unsigned int)lane << 8);
+        {
+            const unsigned int header = ((over ? REC_OVER : (misfit ? REC_DONE | (SHORT_SLOTS - 1) : c)) | ((unsigned int)lane << 8)) << 16;
+            if (rank < 32)
+                R[1].w = (R[1].w & 0xFFFFu) | header;               // slot 15 of a 32-byte record
+            else
+                R[3].w = (R[3].w & 0xFFFFu) | header;               // slot 31
+        }
         // four store instructions per tile whatever the data (the wait counts above): two for every record, two more for the long ones
         char* const tile_out = reinterpret_cast<char*>(a.rec) + tile * TILE_REC_BYTES;
         u32x4* const out = reinterpret_cast<u32x4*>(tile_out + (rank < 32 ? rank * 32u : 1024u + (rank - 32u) * 64u));
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
                         cnt[c] += is_rec ? 1u : 0u;
                         const unsigned int ord = (unsigned int)((int)pos + ((int)pos < lo[c] ? base : base - sd.r)) << 4;
                         unsigned short* const at = (is_rec && cnt[c] < REC_SLOTS)
-                                                       ? reinterpret_cast<unsigned short*>(L.rec[c] + lane * 64 + cnt[c] * 2)
+                                                       ? reinterpret_cast<unsigned short*>(L.rec[c] + lane * 64 + (cnt[c] - 1u) * 2)
                                                        : &L.sink[lane];
                         *at = (unsigned short)ord;
                     }
@@ -641,7 +650,13 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
             u32x4 R[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) R[q] = reinterpret_cast<const u32x4*>(L.rec[c])[lane * 4 + q];
-            R[0].x = (R[0].x & 0xFFFF0000u) | (over ? REC_OVER : (misfit ? REC_DONE | (SHORT_SLOTS - 1) : cc)) | ((unsigned int)lane << 8);
+            {
+                const unsigned int header = ((over ? REC_OVER : (misfit ? REC_DONE | (SHORT_SLOTS - 1) : cc)) | ((unsigned int)lane << 8)) << 16;
+                if (rank < 32)
+                    R[1].w = (R[1].w & 0xFFFFu) | header;
+                else
+                    R[3].w = (R[3].w & 0xFFFFu) | header;
+            }
             char* const tile_out = reinterpret_cast<char*>(sd.rec) + tile * TILE_REC_BYTES;
             u32x4* const out = reinterpret_cast<u32x4*>(tile_out + (rank < 32 ? rank * 32u : 1024u + (rank - 32u) * 64u));
             out[0] = R[0];
@@ -696,6 +711,7 @@ struct GatherArgs {
     int tab_stride, nslabs, r, ident_off, null_ord;   // tab_stride: entries per row-part plane (= 4 mod 16)
     int stray_n, stray_col[2];   // columns compact left out (hand-scheduled kernel only): a sample that has one is flagged REC_STRAY
     int reverse;               // hand-scheduled kernel: walk the records from the last tile to the first (see gf2_syndrome_slabs)
+    int cross;                 // hand-scheduled kernel: a step takes ranks 4k .. 4k + 3 of FOUR tiles instead of a quartile of one
     u64* clk;                  // debugging (GF2_GATHER_CLOCK): earliest entry / latest exit of the workgroups at [2], [3], else null
 };
 
@@ -769,39 +785,45 @@ __device__ __forceinline__ unsigned int quad_pick(unsigned int v, int q) {
     }
 }
 
-// XORs the table entries of slots 0 .. 4 NB - 1 of a record into X.  Block b (slots 4b .. 4b + 3) is dwords (x, y) or (z, w)
-// of record quarter b / 2, i.e. of quad lane b / 2; `first_pair` replaces the dword that holds slot 0.  Straight-line code:
-// the four ds_read_b128 of block b are issued before block b - AHEAD is consumed, so LDS latency (and its bank conflicts)
-// overlaps the XORs of the same wavefront instead of relying on the other three wavefronts of the SIMD.
-template <int NB>
-__device__ __forceinline__ void lookup_blocks(unsigned int part_base, const u32x4& R, unsigned int first_pair,
+// XORs the table entries of slots 0 .. 2 NH - 1 of a record into X.  Pair h (slots 2h, 2h + 1) is dword h mod 4 of record
+// quarter h / 4, i.e. of quad lane h / 4.  The header sits in the high half of dword 7 of a 32-byte record (`mask7` = 0xFFFF
+// there, all ones for a 64-byte record, whose dword 7 is two columns) and of dword 15 of a 64-byte one: it is replaced by the
+// zero entry.  Straight-line code: the two ds_read_b128 of pair h are issued before pair h - AHEAD is consumed, so LDS latency
+// (and its bank conflicts) overlaps the XORs of the same wavefront instead of relying on the other three wavefronts of the SIMD.
+__device__ __forceinline__ unsigned int record_dword(const u32x4& R, int k) {
+    return k == 0 ? R.x : (k == 1 ? R.y : (k == 2 ? R.z : R.w));
+}
+template <int NH>
+__device__ __forceinline__ void lookup_halves(unsigned int part_base, const u32x4& R, unsigned int mask7, unsigned int nullpair,
                                               unsigned int (&X)[4]) {
-    constexpr int AHEAD = 2;
-    u32x4 v[NB][4];
+    constexpr int AHEAD = 4;
+    u32x4 v[NH][2];
 #pragma unroll
-    for (int b = 0; b < NB + AHEAD; ++b) {
-        if (b < NB) {
-            const unsigned int lo = b == 0 ? first_pair : quad_pick((b & 1) ? R.z : R.x, b >> 1);
-            const unsigned int hi = quad_pick((b & 1) ? R.w : R.y, b >> 1);
-            v[b][0] = *(lds_u32x4_ptr)(uintptr_t)entry_addr_lo(part_base, lo);
-            v[b][1] = *(lds_u32x4_ptr)(uintptr_t)entry_addr_hi(part_base, lo);
-            v[b][2] = *(lds_u32x4_ptr)(uintptr_t)entry_addr_lo(part_base, hi);
-            v[b][3] = *(lds_u32x4_ptr)(uintptr_t)entry_addr_hi(part_base, hi);
+    for (int h = 0; h < NH + AHEAD; ++h) {
+        if (h < NH) {
+            unsigned int pair = quad_pick(record_dword(R, h & 3), h >> 2);
+            if (h == 7) pair = (pair & mask7) | (nullpair & ~mask7);
+            if (h == 15) pair = (pair & 0xFFFFu) | (nullpair & 0xFFFF0000u);
+            v[h][0] = *(lds_u32x4_ptr)(uintptr_t)entry_addr_lo(part_base, pair);
+            v[h][1] = *(lds_u32x4_ptr)(uintptr_t)entry_addr_hi(part_base, pair);
         }
-        if (b >= AHEAD) {
-            const int c = b - AHEAD;
-            X[0] = xor3(xor3(X[0], v[c][0].x, v[c][1].x), v[c][2].x, v[c][3].x);
-            X[1] = xor3(xor3(X[1], v[c][0].y, v[c][1].y), v[c][2].y, v[c][3].y);
-            X[2] = xor3(xor3(X[2], v[c][0].z, v[c][1].z), v[c][2].z, v[c][3].z);
-            X[3] = xor3(xor3(X[3], v[c][0].w, v[c][1].w), v[c][2].w, v[c][3].w);
+        if (h >= AHEAD && h - AHEAD < NH) {
+            const int c = h - AHEAD;
+            X[0] = xor3(X[0], v[c][0].x, v[c][1].x);
+            X[1] = xor3(X[1], v[c][0].y, v[c][1].y);
+            X[2] = xor3(X[2], v[c][0].z, v[c][1].z);
+            X[3] = xor3(X[3], v[c][0].w, v[c][1].w);
         }
     }
 }
 
-// Sample a record belongs to: records are permuted inside their tile of 64 (slot 0 carries the tile-local index).
-__device__ __forceinline__ unsigned int record_sample(unsigned int pos, unsigned int slot0) {
-    return (pos & ~63u) + ((slot0 >> 8) & 63u);
+// Sample a record belongs to: records are permuted inside their tile of 64 (the header carries the tile-local index).
+__device__ __forceinline__ unsigned int record_sample(unsigned int pos, unsigned int header) {
+    return (pos & ~63u) + ((header >> 8) & 63u);
 }
+// The header of this lane's record: the last slot, i.e. the high half of dword w of quarter 3 (a 32-byte record's quarters
+// 2 and 3 are loaded as copies of 0 and 1).
+__device__ __forceinline__ unsigned int record_header(const u32x4& R) { return quad_bcast<3>(R.w) >> 16; }
 
 __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];            // the only LDS: the table starts at LDS address 0
@@ -867,16 +889,16 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
     auto rec_pos = [&](unsigned int g, unsigned int rot) { return rec_grp(g, rot) * 16 + lane_rec; };
     RA = fetch_record(rec_rsrc, rec_grp(grp, 0), lane_rec, (unsigned int)part);
     RB = fetch_record(rec_rsrc, rec_grp(grp + stride, 1), lane_rec, (unsigned int)part);
-    fetch_ident(a, record_sample(rec_pos(grp, 0), quad_bcast<0>(RA.x)), row_bytes, dw0, row_dwords, aligned16, id_sh,
+    fetch_ident(a, record_sample(rec_pos(grp, 0), record_header(RA)), row_bytes, dw0, row_dwords, aligned16, id_sh,
                 part == 3, iwA);
 
     auto step = [&](const u32x4& R, unsigned int (&iw)[5], const u32x4& Rnext, u32x4& Rfar, unsigned int (&iwnext)[5]) {
         const unsigned int pos = rec_pos(grp, k);
         Rfar = fetch_record(rec_rsrc, rec_grp(grp + 2 * stride, k + 2), lane_rec, (unsigned int)part);
-        fetch_ident(a, record_sample(rec_pos(grp + stride, k + 1), quad_bcast<0>(Rnext.x)), row_bytes, dw0, row_dwords, aligned16, id_sh,
+        fetch_ident(a, record_sample(rec_pos(grp + stride, k + 1), record_header(Rnext)), row_bytes, dw0, row_dwords, aligned16, id_sh,
                     part == 3, iwnext);
-        const unsigned int head = quad_bcast<0>(R.x);               // slot 0 (count, tile-local sample) and slot 1
-        const unsigned int slot0 = head & 0xFFFFu;
+        const unsigned int slot0 = record_header(R);                // count, tile-local sample, flags
+        const bool is_short = (rec_grp(grp, k) & 3u) < 2u;          // uniform: 32-byte records, header in dword 7
         // finished by the compact kernel: REC_OVER sorts first (count 0); a REC_DONE record sits where its count put it, at
         // the top of the tile's lower half, and keeps the count byte, because the step's last record sets the lookups of all
         const bool flagged = (slot0 & 0xFFu) == REC_OVER || (slot0 & REC_DONE) != 0;
@@ -898,7 +920,8 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
             for (int q = 0; q < 4; ++q) X[q] &= keep[q];
         }
         // the tile is sorted by count (finished and out-of-batch samples first, as 0): the last record has the most slots
-        const unsigned int mx = (unsigned int)__builtin_amdgcn_readlane((int)c, 63) + 1u;
+        const unsigned int mx = (unsigned int)__builtin_amdgcn_readlane((int)c, 63);
+        const unsigned int null_hi = null_ent << 16;
         auto lookups = [&](unsigned int lo, unsigned int hi) {      // four slots = two record dwords
             const u32x4 v0 = *(lds_u32x4_ptr)(uintptr_t)entry_addr_lo(part_base, lo);
             const u32x4 v1 = *(lds_u32x4_ptr)(uintptr_t)entry_addr_hi(part_base, lo);
@@ -910,15 +933,15 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
             X[2] = xor3(xor3(X[2], v0.z, v1.z), v2.z, v3.z);
             X[3] = xor3(xor3(X[3], v0.w, v1.w), v2.w, v3.w);
         };
-        // slots 4g .. 4g + 3 are dwords (x, y) or (z, w) of quarter g / 2; slot 0 becomes a zero entry
-        lookups((head & 0xFFFF0000u) | null_ent, quad_bcast<0>(R.y));
+        // slots 4g .. 4g + 3 are dwords (x, y) or (z, w) of quarter g / 2; the header (last slot) becomes a zero entry
+        if (mx > 0) lookups(quad_bcast<0>(R.x), quad_bcast<0>(R.y));
         if (mx > 4) lookups(quad_bcast<0>(R.z), quad_bcast<0>(R.w));
         if (mx > 8) lookups(quad_bcast<1>(R.x), quad_bcast<1>(R.y));
-        if (mx > 12) lookups(quad_bcast<1>(R.z), quad_bcast<1>(R.w));
+        if (mx > 12) lookups(quad_bcast<1>(R.z), is_short ? (quad_bcast<1>(R.w) & 0xFFFFu) | null_hi : quad_bcast<1>(R.w));
         if (mx > 16) lookups(quad_bcast<2>(R.x), quad_bcast<2>(R.y));
         if (mx > 20) lookups(quad_bcast<2>(R.z), quad_bcast<2>(R.w));
         if (mx > 24) lookups(quad_bcast<3>(R.x), quad_bcast<3>(R.y));
-        if (mx > 28) lookups(quad_bcast<3>(R.z), quad_bcast<3>(R.w));
+        if (mx > 28) lookups(quad_bcast<3>(R.z), (quad_bcast<3>(R.w) & 0xFFFFu) | null_hi);
         unsigned int wt = __popc(X[0]) + __popc(X[1]) + __popc(X[2]) + __popc(X[3]);
         wt += __builtin_amdgcn_update_dpp(0u, wt, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
         wt += __builtin_amdgcn_update_dpp(0u, wt, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
@@ -1023,23 +1046,40 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
     const char* const ident_base = reinterpret_cast<const char*>(a.e) + dw0 * 4u;
     const unsigned int fifth_off = ((dw0 + 4 < row_dwords ? dw0 + 4 : 0u) - dw0) * 4u;       // from ident_base, wraps
 
-    const unsigned int ngroups = (unsigned int)(((a.batch + 63) >> 6) << 2);
+    // A step looks up as many slot pairs as its longest record has.  The tiles are sorted by count, so the 16 records of a step
+    // should sit close together in that order: a quartile of one tile spans a quarter of the tile's spread, the four records of
+    // ranks 4k .. 4k + 3 taken from FOUR consecutive tiles span a sixteenth (`cross`; 17.4 instead of 18.3 lookups per record at
+    // the benchmark's rate before the pairs, 15.4 with them and without the header's lookup).  Group g of a super-tile of four
+    // tiles: k = g mod 16; a step's records are 32-byte ones for k < 8.
+    const unsigned int ntiles = (unsigned int)((a.batch + 63) >> 6);
+    const unsigned int ngroups = a.cross ? ((ntiles + 3u) >> 2) << 4 : ntiles << 2;
     const unsigned int stride = (unsigned int)shares * GAT_WAVES;
     const unsigned int lane_rec = lane >> 2;
     const unsigned int part16 = (unsigned int)part * 16u;
+    const unsigned int positions = ntiles << 6;
 
     // reverse: group g stands for group ngroups - 1 - g (groups past the end stay past the end: their records read as zeros)
     const unsigned int last_group = a.reverse ? ngroups - 1u : 0u;
-    // the record quarter of this lane in group g (uniform): 32-byte records in the lower half of a tile, 64-byte ones above
-    const unsigned int short_lane = lane_rec * 32u + ((unsigned int)part & 1u) * 16u, long_lane = lane_rec * 64u + part16;
+    // the record quarter of this lane in its group: 32-byte records in the lower half of a tile, 64-byte ones above
+    const unsigned int lane_tile = a.cross ? (lane_rec >> 2) : 0u, lane_sub = a.cross ? (lane_rec & 3u) : lane_rec;
+    const unsigned int short_lane = lane_tile * TILE_REC_BYTES + lane_sub * 32u + ((unsigned int)part & 1u) * 16u;
+    const unsigned int long_lane = lane_tile * TILE_REC_BYTES + lane_sub * 64u + part16;
+    const unsigned int pos_lane = a.cross ? lane_tile * 64u + lane_sub : lane_rec;
+    auto the_group = [&](unsigned int g) { return a.reverse && g < ngroups ? last_group - g : g; };
     auto issue_record = [&](u32x4& R, unsigned int g) {
-        const unsigned int group = a.reverse && g < ngroups ? last_group - g : g;
-        const unsigned int q = group & 3u;
-        const unsigned int off = (group >> 2) * TILE_REC_BYTES + (q < 2 ? q * 512u + short_lane : (q - 1u) * 1024u + long_lane);
+        const unsigned int group = the_group(g);
+        unsigned int off;
+        if (a.cross) {
+            const unsigned int k = group & 15u;
+            off = (group >> 4) * (4u * TILE_REC_BYTES) + (k < 8 ? k * 128u + short_lane : 1024u + (k - 8u) * 256u + long_lane);
+        } else {
+            const unsigned int q = group & 3u;
+            off = (group >> 2) * TILE_REC_BYTES + (q < 2 ? q * 512u + short_lane : (q - 1u) * 1024u + long_lane);
+        }
         asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(R) : "v"(off), "s"(rsrc) : "memory");
     };
-    auto issue_ident = [&](u32x4& I, unsigned int& E, unsigned int pos, unsigned int slot0_dword) {
-        const unsigned int sample = record_sample(pos, slot0_dword);
+    auto issue_ident = [&](u32x4& I, unsigned int& E, unsigned int pos, unsigned int header) {
+        const unsigned int sample = record_sample(pos, header);
         const char* p = ident_base + (u64)(sample < (unsigned int)a.batch ? sample : 0u) * row_bytes;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(I) : "v"(p) : "memory");
         if (EXTRA) {
@@ -1057,15 +1097,21 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
         return (unsigned int)share * GAT_WAVES + (t & (GAT_WAVES - 1)) + (t / GAT_WAVES) * stride;
     };
-    auto rec_pos = [&](unsigned int g) { return (a.reverse && g < ngroups ? last_group - g : g) * 16 + lane_rec; };
+    // position of this lane's record (tile * 64 + rank in the sorted tile)
+    auto rec_pos = [&](unsigned int g) {
+        const unsigned int group = the_group(g);
+        return (a.cross ? ((group >> 4) << 8) + ((group & 15u) << 2) : group << 4) + pos_lane;
+    };
+    auto short_records = [&](unsigned int g) { return a.cross ? (the_group(g) & 15u) < 8u : (the_group(g) & 3u) < 2u; };
+    const unsigned int nullpair = null_ent | (null_ent << 16);
     unsigned int G0 = take(), G1 = take(), G2 = take(), G3 = take();
     issue_record(R0, G0);
     issue_record(R1, G1);
     issue_record(R2, G2);
     issue_record(R3, G3);
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(R0), "+v"(R1), "+v"(R2), "+v"(R3)::"memory");
-    issue_ident(I0, E0, rec_pos(G0), quad_bcast<0>(R0.x));
-    issue_ident(I1, E1, rec_pos(G1), quad_bcast<0>(R1.x));
+    issue_ident(I0, E0, rec_pos(G0), record_header(R0));
+    issue_ident(I1, E1, rec_pos(G1), record_header(R1));
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(I0), "+v"(I1), "+v"(E0), "+v"(E1)::"memory");
 
     // One step: R, I, E = record and identity words of this step (requested four and two steps ago), Rp2 = record of the
@@ -1076,10 +1122,9 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         else
             asm volatile("s_waitcnt vmcnt(3)" : "+v"(R), "+v"(I), "+v"(E), "+v"(Rp2)::"memory");
         const unsigned int pos = rec_pos(G);
-        const unsigned int head = quad_bcast<0>(R.x);               // slot 0 (count, tile-local sample) and slot 1
-        const unsigned int slot0 = head & 0xFFFFu;
+        const unsigned int slot0 = record_header(R);                // count, tile-local sample, flags
         // finished by the compact kernel: REC_OVER sorts first (count 0); a REC_DONE record sits where its count put it, at
-        // the top of the tile's lower half, and keeps the count byte, because the step's last record sets the lookups of all
+        // the top of the tile's lower half, and keeps the count byte, because the longest record sets the lookups of all
         const bool flagged = (slot0 & 0xFFu) == REC_OVER || (slot0 & REC_DONE) != 0;
         const bool valid = record_sample(pos, slot0) < (unsigned int)a.batch;
         const unsigned int c = (slot0 & 0xFFu) == REC_OVER || !valid ? 0u : (slot0 & 0xFFu);
@@ -1103,29 +1148,44 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
 #pragma unroll
             for (int q = 0; q < 4; ++q) X[q] = iw[q] & keep[q];
         }
-        // the tile is sorted by count (finished and out-of-batch samples first, as 0): the last record has the most slots
-        const unsigned int nblk = ((unsigned int)__builtin_amdgcn_readlane((int)c, 63) + 4u) >> 2;
-        const unsigned int first_pair = (head & 0xFFFF0000u) | null_ent;
-        switch (nblk) {
-            case 1: lookup_blocks<1>(part_base, R, first_pair, X); break;
-            case 2: lookup_blocks<2>(part_base, R, first_pair, X); break;
-            case 3: lookup_blocks<3>(part_base, R, first_pair, X); break;
-            case 4: lookup_blocks<4>(part_base, R, first_pair, X); break;
-            case 5: lookup_blocks<5>(part_base, R, first_pair, X); break;
-            case 6: lookup_blocks<6>(part_base, R, first_pair, X); break;
-            case 7: lookup_blocks<7>(part_base, R, first_pair, X); break;
-            default: lookup_blocks<8>(part_base, R, first_pair, X); break;
+        // the tiles are sorted by count (finished and out-of-batch samples first, as 0): the longest record of the step is the
+        // last one of a tile's run, i.e. of lanes 15, 31, 47 or 63 (one run of 16 without `cross`: lane 63)
+        unsigned int cmax = (unsigned int)__builtin_amdgcn_readlane((int)c, 63);
+        cmax = max(cmax, (unsigned int)__builtin_amdgcn_readlane((int)c, 47));
+        cmax = max(cmax, (unsigned int)__builtin_amdgcn_readlane((int)c, 31));
+        cmax = max(cmax, (unsigned int)__builtin_amdgcn_readlane((int)c, 15));
+        const unsigned int mask7 = short_records(G) ? 0xFFFFu : ~0u;          // uniform
+        switch ((cmax + 1u) >> 1) {
+            case 0: break;
+            case 1: lookup_halves<1>(part_base, R, mask7, nullpair, X); break;
+            case 2: lookup_halves<2>(part_base, R, mask7, nullpair, X); break;
+            case 3: lookup_halves<3>(part_base, R, mask7, nullpair, X); break;
+            case 4: lookup_halves<4>(part_base, R, mask7, nullpair, X); break;
+            case 5: lookup_halves<5>(part_base, R, mask7, nullpair, X); break;
+            case 6: lookup_halves<6>(part_base, R, mask7, nullpair, X); break;
+            case 7: lookup_halves<7>(part_base, R, mask7, nullpair, X); break;
+            case 8: lookup_halves<8>(part_base, R, mask7, nullpair, X); break;
+            case 9: lookup_halves<9>(part_base, R, mask7, nullpair, X); break;
+            case 10: lookup_halves<10>(part_base, R, mask7, nullpair, X); break;
+            case 11: lookup_halves<11>(part_base, R, mask7, nullpair, X); break;
+            case 12: lookup_halves<12>(part_base, R, mask7, nullpair, X); break;
+            case 13: lookup_halves<13>(part_base, R, mask7, nullpair, X); break;
+            case 14: lookup_halves<14>(part_base, R, mask7, nullpair, X); break;
+            case 15: lookup_halves<15>(part_base, R, mask7, nullpair, X); break;
+            default: lookup_halves<16>(part_base, R, mask7, nullpair, X); break;
         }
         unsigned int wt = __popc(X[0]) + __popc(X[1]) + __popc(X[2]) + __popc(X[3]);
         wt += __builtin_amdgcn_update_dpp(0u, wt, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
         wt += __builtin_amdgcn_update_dpp(0u, wt, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
-        if (part == 0) pw[pos] = (unsigned short)(flagged || !valid ? REC_FLAG : (stray ? REC_STRAY | ((slot0 >> 8) & 63u) : wt));
+        // (a super-tile's last tiles may lie past the batch: their records read as zeros and nothing is stored for them)
+        if (part == 0 && pos < positions)
+            pw[pos] = (unsigned short)(flagged || !valid ? REC_FLAG : (stray ? REC_STRAY | ((slot0 >> 8) & 63u) : wt));
         // refill the buffers this step has emptied: exactly one store, one record load and one (EXTRA: two) identity loads
         // per step, in this order -- the wait counts above depend on it
         asm volatile("" ::: "memory");
         G = take();
         issue_record(R, G);
-        issue_ident(I, E, rec_pos(Gp2), quad_bcast<0>(Rp2.x));
+        issue_ident(I, E, rec_pos(Gp2), record_header(Rp2));
     };
 #pragma unroll 1
     while (G0 < ngroups) {                                          // a wavefront's tickets ascend
@@ -1305,8 +1365,9 @@ static int launch_gather(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u
     ga.stray_col[1] = stray.col[1];
     ga.clk = clk_dev;
     ga.reverse = ctx->opt[GF2_OPT_GATHER_REVERSE] == 0 ? 0 : 1;
+    ga.cross = ctx->opt[GF2_OPT_GATHER_CROSS] == 0 ? 0 : 1;
     int64_t shares = ctx->num_cus / ck->nslabs512;
-    const int64_t max_shares = gf2_cdiv(gf2_cdiv(count, 16), GAT_WAVES);
+    const int64_t max_shares = gf2_cdiv(gf2_cdiv(count, 16), GAT_WAVES);   // (a few steps more with `cross`: they read zeros)
     if (shares > max_shares) shares = max_shares;
     if (shares < 1) shares = 1;
     const dim3 ggrid((unsigned)(shares * ck->nslabs512));
