@@ -86,7 +86,8 @@ int gf2_ctx_sync(gf2_ctx* ctx);
 #define GF2_F_DIAG_MC_TIMES        (1u << 13)  /* gf2_mc_run: print the host's phases to stderr                         */
 #define GF2_F_MC_ROWS              (1u << 14)  /* gf2_mc_run: packed rows from the sampler, records by the compact kernel */
 #define GF2_F_COMBINE_FOLDED       (1u << 15)  /* slab pipeline: the combine step of a pass inside the next pass' compact kernel */
-#define GF2_F_ALL                  ((1u << 16) - 1u)   /* every defined flag; gf2_ctx_set_flags refuses other bits              */
+#define GF2_F_RREF_NO_LOOKAHEAD    (1u << 16)  /* gf2_rref* on more than 8192 rows: the next pair's panels after, not under, the trailing pass */
+#define GF2_F_ALL                  ((1u << 17) - 1u)   /* every defined flag; gf2_ctx_set_flags refuses other bits              */
 int gf2_ctx_set_flags(gf2_ctx* ctx, uint32_t flags);
 int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
 /* Tunables of a context (value < 0 restores the default). */
@@ -189,6 +190,13 @@ int gf2_syndrome_table(gf2_ctx* ctx, const uint64_t* h_rows, int64_t r, int64_t 
  * (positions c_1 < ... < c_w have rank C(c_1, 1) + ... + C(c_w, w)) -- or all ones; the caller unranks.  t_out, entries_out and
  * max_weight as above. */
 int gf2_syndrome_table_wide(gf2_ctx* ctx, const uint64_t* h_rows, int64_t r, int64_t n, int64_t max_weight,
+                            uint64_t* table_out, int64_t* t_out, int64_t* entries_out);
+
+/* The same search for 128 < n <= 8192 (still r <= 24: the table has 2^r slots; beyond that the Python host enumerates the classes
+ * and only the syndromes come from the device).  h_rows: r packed rows of ld words.  Errors are enumerated as position lists
+ * and keyed by the XOR of their columns' keys; a class is enumerated only if it can fit the table (C(n, w) <= 2^r), which
+ * keeps w <= 8 for every n > 128.  Table slots, t_out, entries_out and max_weight as in gf2_syndrome_table_wide. */
+int gf2_syndrome_table_cols(gf2_ctx* ctx, const uint64_t* h_rows, int64_t r, int64_t n, int64_t ld, int64_t max_weight,
                             uint64_t* table_out, int64_t* t_out, int64_t* entries_out);
 
 /* css_code.transform_stabilisers (css_code.py:737-781) [SURVEY.md 8f item 3].  mat: k rows of ld words holding the k x 2n

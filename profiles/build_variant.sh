@@ -1,0 +1,13 @@
+#!/bin/bash
+# Builds a variant of libgf2hip.so into scratch_ab/<name>.so for same-box A/B runs (scratch_ab/ is git-ignored but travels to the GPU box):
+#   bash profiles/build_variant.sh <name> [<git rev whose gf2_slabs.hip to take> | -] [extra hipcc flags, e.g. -DGAT_EXP_NOLOOKUP]
+set -e
+name=$1; rev=${2:--}; shift; shift || true
+root=$(cd $(dirname $0)/.. && pwd)
+work=/tmp/variant_$name
+rm -rf $work && mkdir -p $work/quantum_css_codes_amd $work/include
+cp -r $root/quantum_css_codes_amd/csrc $work/quantum_css_codes_amd/ && rm -rf $work/quantum_css_codes_amd/csrc/build
+cp $root/include/gf2hip.h $work/include/
+if [ "$rev" != "-" ]; then git -C $root show $rev:quantum_css_codes_amd/csrc/gf2_slabs.hip > $work/quantum_css_codes_amd/csrc/gf2_slabs.hip; fi
+make -C $work/quantum_css_codes_amd/csrc ROOT=$work FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=default -I$work/include -Wall -Wno-unused-function $*" 2>&1 | grep -E "rror|check_isa:" || true
+mkdir -p $root/scratch_ab && cp $work/quantum_css_codes_amd/libgf2hip.so $root/scratch_ab/$name.so && ls -la $root/scratch_ab/$name.so

@@ -22,7 +22,7 @@ K_SYNDROME, K_HIST, K_SAMPLER, K_ELIM = 0, 1, 2, 3
 # routing flags of a context (GF2_F_* of include/gf2hip.h) and its tunables (GF2_OPT_*)
 (F_SPARSE_GATHER, F_SPARSE_SLABS, F_NO_REDO, F_GATHER_GENERIC, F_MC_UNFUSED, F_MC_DENSE, F_MC_FUSED, F_MC_PIPELINE,
  F_RREF_SEQUENTIAL, F_RREF_NO_SMALL, F_NORMALIZE_SEQUENTIAL, F_SAMPLER_GENERIC, F_DIAG_CLOCKS,
- F_DIAG_MC_TIMES, F_MC_ROWS, F_COMBINE_FOLDED) = (1 << k for k in range(16))
+ F_DIAG_MC_TIMES, F_MC_ROWS, F_COMBINE_FOLDED, F_RREF_NO_LOOKAHEAD) = (1 << k for k in range(17))
 (OPT_SLAB_PASS_LOG2, OPT_COMBINE_BLOCKS, OPT_GATHER_REVERSE, OPT_REDO_BLOCKS_PER_CU, OPT_MC_CHUNK_LOG2, OPT_COMBINE_THREADS,
  OPT_GATHER_CROSS) = range(7)
 
@@ -80,6 +80,7 @@ SIGNATURES = {
     "gf2_conjugate_gates": [_p, _p, _c_i64, _c_i64, _c_i64, _p, _c_i64, ctypes.POINTER(_c_i64)],
     "gf2_syndrome_table": [_p, _p, _c_i64, _c_i64, _c_i64, _p, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)],
     "gf2_syndrome_table_wide": [_p, _p, _c_i64, _c_i64, _c_i64, _p, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)],
+    "gf2_syndrome_table_cols": [_p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _p, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)],
     "gf2_check_create": [_p, _p, _c_i64, _c_i64, _c_i64, _pp],
     "gf2_check_destroy": [_p, _p],
     "gf2_syndrome_batch": [_p, _p, _c_i64, _c_i64, _c_i64, _p, _c_i64, _c_i64, ctypes.c_int, _p, _c_i64],
@@ -498,6 +499,19 @@ class Context(object):
         dense = np.empty(1 << r, dtype="<u8")
         t, entries = _c_i64(), _c_i64()
         check(lib().gf2_syndrome_table_wide(self.handle, _ptr(rows) if r else None, r, n,
+                                            -1 if max_weight is None else max_weight, _ptr(dense), ctypes.byref(t),
+                                            ctypes.byref(entries)))
+        return int(t.value), dense
+
+    TABLE_COLS_MAX_N = 8192
+
+    def syndrome_table_cols(self, packed, r, n, max_weight=None):
+        """The same for 128 < n <= 8192 (errors as position lists on the device): dense[key] = (weight << 32) | rank, or
+        TABLE_EMPTY; unrank with unrank_supports."""
+        rows = np.ascontiguousarray(packed, dtype="<u8") if r else np.zeros((1, max(1, words_for(n))), dtype="<u8")
+        dense = np.empty(1 << r, dtype="<u8")
+        t, entries = _c_i64(), _c_i64()
+        check(lib().gf2_syndrome_table_cols(self.handle, _ptr(rows) if r else None, r, n, rows.shape[1],
                                             -1 if max_weight is None else max_weight, _ptr(dense), ctypes.byref(t),
                                             ctypes.byref(entries)))
         return int(t.value), dense

@@ -302,52 +302,95 @@ int gf2_membw_probe_dev(gf2_ctx* ctx, const void* src_dev, void* dst_dev, size_t
 
 // ---- host-side packing ------------------------------------------------------------------------------
 
-#define GF2_PACK_BODY(T)                                                                     \
-    if ((!src || !dst) && m > 0 && n > 0) GF2_FAIL(GF2_E_ARG, "pack: null buffer");          \
-    if (m < 0 || n < 0 || ld < gf2_words(n) || src_stride < n) GF2_FAIL(GF2_E_ARG, "pack: bad shape"); \
-    for (int64_t i = 0; i < m; ++i) {                                                        \
-        const T* row = src + i * src_stride;                                                 \
-        uint64_t* out = dst + i * ld;                                                        \
-        for (int64_t w = 0; w < ld; ++w) {                                                   \
-            uint64_t acc = 0;                                                                \
-            int64_t base = w * 64;                                                           \
-            int64_t lim = n - base < 64 ? n - base : 64;                                     \
-            for (int64_t b = 0; b < lim; ++b) acc |= (uint64_t)(row[base + b] & 1) << b;     \
-            out[w] = acc;                                                                    \
-        }                                                                                    \
-    }                                                                                        \
+// Rows are independent: large arrays are cut into row ranges, one host thread each (a 2048 x 4096 int64 array is 64 MiB, more
+// than one core streams in the time the elimination itself takes; gf2_rref on it spent 6 of its 7 ms here on one thread).
+}   // extern "C"
+
+#include <thread>
+#include <vector>
+
+template <typename F>
+static void host_rows_parallel(int64_t rows, int64_t bytes_per_row, F body) {
+    const int64_t total = rows * bytes_per_row;
+    static const int64_t cap = []() {                                   // GF2_HOST_THREADS, read once (default: up to 16)
+        const char* env = getenv("GF2_HOST_THREADS");
+        const long v = env ? strtol(env, nullptr, 10) : 0;
+        return (int64_t)(v >= 1 && v <= 256 ? v : 16);
+    }();
+    const unsigned int hw = std::thread::hardware_concurrency();
+    int64_t threads = hw ? ((int64_t)hw > cap ? cap : (int64_t)hw) : 1;
+    if (threads > total >> 20) threads = total >> 20;                   // at least 1 MiB per thread
+    if (threads > rows) threads = rows;
+    if (threads <= 1) {
+        body((int64_t)0, rows);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const int64_t per = (rows + threads - 1) / threads;
+    for (int64_t t = 1; t < threads; ++t) {
+        const int64_t lo = t * per, hi = lo + per < rows ? lo + per : rows;
+        if (lo < hi) pool.emplace_back([=]() { body(lo, hi); });
+    }
+    body((int64_t)0, per < rows ? per : rows);
+    for (auto& th : pool) th.join();
+}
+
+template <typename T>
+static int pack_rows_host(const T* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld) {
+    if ((!src || !dst) && m > 0 && n > 0) GF2_FAIL(GF2_E_ARG, "pack: null buffer");
+    if (m < 0 || n < 0 || ld < gf2_words(n) || src_stride < n) GF2_FAIL(GF2_E_ARG, "pack: bad shape");
+    host_rows_parallel(m, n * (int64_t)sizeof(T), [=](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const T* row = src + i * src_stride;
+            uint64_t* out = dst + i * ld;
+            for (int64_t w = 0; w < ld; ++w) {
+                uint64_t acc = 0;
+                const int64_t base = w * 64;
+                const int64_t lim = n - base < 64 ? n - base : 64;
+                for (int64_t b = 0; b < lim; ++b) acc |= (uint64_t)(row[base + b] & 1) << b;
+                out[w] = acc;
+            }
+        }
+    });
     return GF2_OK;
+}
+
+template <typename T>
+static int unpack_rows_host(const uint64_t* src, int64_t m, int64_t n, int64_t ld, T* dst, int64_t dst_stride) {
+    if ((!src || !dst) && m > 0 && n > 0) GF2_FAIL(GF2_E_ARG, "unpack: null buffer");
+    if (m < 0 || n < 0 || ld < gf2_words(n) || dst_stride < n) GF2_FAIL(GF2_E_ARG, "unpack: bad shape");
+    host_rows_parallel(m, n * (int64_t)sizeof(T), [=](int64_t lo, int64_t hi) {
+        for (int64_t i = lo; i < hi; ++i) {
+            const uint64_t* row = src + i * ld;
+            T* out = dst + i * dst_stride;
+            const int64_t full = n >> 6;
+            for (int64_t w = 0; w < full; ++w) {                  /* whole words: a fixed-length loop the compiler vectorises */
+                const uint64_t v = row[w];
+                T* o = out + w * 64;
+                for (int b = 0; b < 64; ++b) o[b] = (T)((v >> b) & 1);
+            }
+            for (int64_t j = full * 64; j < n; ++j) out[j] = (T)((row[j >> 6] >> (j & 63)) & 1);
+        }
+    });
+    return GF2_OK;
+}
+
+extern "C" {
 
 int gf2_pack_rows_u8(const uint8_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld) {
-    GF2_PACK_BODY(uint8_t)
+    return pack_rows_host<uint8_t>(src, m, n, src_stride, dst, ld);
 }
 
 int gf2_pack_rows_i64(const int64_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld) {
-    GF2_PACK_BODY(int64_t)
+    return pack_rows_host<int64_t>(src, m, n, src_stride, dst, ld);
 }
 
-#define GF2_UNPACK_BODY(T)                                                                   \
-    if ((!src || !dst) && m > 0 && n > 0) GF2_FAIL(GF2_E_ARG, "unpack: null buffer");        \
-    if (m < 0 || n < 0 || ld < gf2_words(n) || dst_stride < n) GF2_FAIL(GF2_E_ARG, "unpack: bad shape"); \
-    for (int64_t i = 0; i < m; ++i) {                                                        \
-        const uint64_t* row = src + i * ld;                                                  \
-        T* out = dst + i * dst_stride;                                                       \
-        const int64_t full = n >> 6;                                                         \
-        for (int64_t w = 0; w < full; ++w) {                  /* whole words: a fixed-length loop the compiler vectorises */ \
-            const uint64_t v = row[w];                                                       \
-            T* o = out + w * 64;                                                             \
-            for (int b = 0; b < 64; ++b) o[b] = (T)((v >> b) & 1);                           \
-        }                                                                                    \
-        for (int64_t j = full * 64; j < n; ++j) out[j] = (T)((row[j >> 6] >> (j & 63)) & 1); \
-    }                                                                                        \
-    return GF2_OK;
-
 int gf2_unpack_rows_u8(const uint64_t* src, int64_t m, int64_t n, int64_t ld, uint8_t* dst, int64_t dst_stride) {
-    GF2_UNPACK_BODY(uint8_t)
+    return unpack_rows_host<uint8_t>(src, m, n, ld, dst, dst_stride);
 }
 
 int gf2_unpack_rows_i64(const uint64_t* src, int64_t m, int64_t n, int64_t ld, int64_t* dst, int64_t dst_stride) {
-    GF2_UNPACK_BODY(int64_t)
+    return unpack_rows_host<int64_t>(src, m, n, ld, dst, dst_stride);
 }
 
 }  // extern "C"

@@ -546,25 +546,33 @@ __global__ __launch_bounds__(256) void panel_column_kernel(const u64* __restrict
 
 // After the streamed panel kernel, one launch for its two leftovers: (1) the coefficients of every row the panel kernel has not
 // settled itself (slot -2) take the last round's probe-row table applied to the row's word, one row per lane on as many
-// workgroups as there are rows for; (2) the last 64 workgroups copy the panel's pivot rows (64 rows of ld words) to the snapshot.
+// workgroups as there are rows for (`do_coeff`); (2) the last 64 workgroups copy the panel's pivot rows (64 rows of ld words,
+// words [w_lo, w_hi) but [hole_lo, hole_hi)) to the snapshot.  With look-ahead (launch_rref_blocked) the copy comes in two
+// launches: the chunk that holds the pair's own columns at once, the rest when the previous pair's trailing pass has finished;
+// by then the state's `t` is the other panel's, so the copy goes by tg[member].
 __global__ __launch_bounds__(1024) void panel_finish_kernel(const u64* __restrict__ base, int64_t m, int64_t ld,
                                                             const RrefState* __restrict__ states, const u64* __restrict__ wpan_base,
                                                             const u64* __restrict__ cco_base, const int32_t* __restrict__ slot_base,
                                                             const u64* __restrict__ tabs_base, u64* __restrict__ d_base,
-                                                            const int32_t* __restrict__ prow_base, u64* __restrict__ snap_base) {
+                                                            const int32_t* __restrict__ prow_base, u64* __restrict__ snap_base,
+                                                            int member, int do_coeff, int64_t w_lo, int64_t w_hi, int64_t hole_lo,
+                                                            int64_t hole_hi) {
     __shared__ u64 TC[2048];
     const int64_t mat = blockIdx.y;
     const RrefState st = states[mat];
-    if (st.t == 0) return;
+    const int t = st.tg[member];
+    if (t == 0) return;
     const int coeff_blocks = (int)gridDim.x - 64;
     if ((int)blockIdx.x >= coeff_blocks) {
         const int p = (int)blockIdx.x - coeff_blocks;
-        if (p >= st.t) return;
+        if (p >= t) return;
         const u64* src = base + (mat * m + prow_base[mat * 64 + p]) * ld;
         u64* dst = snap_base + (mat * 64 + p) * ld;
-        for (int64_t wd = threadIdx.x; wd < ld; wd += blockDim.x) dst[wd] = src[wd];
+        for (int64_t wd = w_lo + threadIdx.x; wd < w_hi; wd += blockDim.x)
+            if (wd < hole_lo || wd >= hole_hi) dst[wd] = src[wd];
         return;
     }
+    if (!do_coeff) return;
     for (int idx = threadIdx.x; idx < 2048; idx += 1024) TC[idx] = st.pending ? tabs_base[mat * 2048 + idx] : 0ull;
     __syncthreads();
     const int64_t row = (int64_t)blockIdx.x * 1024 + threadIdx.x;
@@ -774,12 +782,15 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_pair_kernel(u64* __res
                                                                      int64_t rows_per_wg, const RrefState* __restrict__ states,
                                                                      const u64* __restrict__ da_base, const u64* __restrict__ db_base,
                                                                      const u64* __restrict__ snapa_base, const u64* __restrict__ snapb_base,
-                                                                     const u64* __restrict__ fix_base) {
+                                                                     const u64* __restrict__ fix_base, int chunk_base, int chunk_skip) {
     extern __shared__ __attribute__((aligned(16))) u64 T[];           // [2][16 groups][16 entries][32 words]
     const int64_t mat = blockIdx.z;
     const RrefState st = states[mat];
     const int ta = st.tg[0], tb = st.tg[1];
-    const int64_t cw0 = (int64_t)blockIdx.y * U2_CW;
+    // the launch covers chunks chunk_base .. chunk_base + gridDim.y - 1 but chunk_skip (look-ahead: the chunk of the next pair's
+    // columns goes first, in a launch of its own)
+    if ((int)blockIdx.y + chunk_base == chunk_skip) return;
+    const int64_t cw0 = ((int64_t)blockIdx.y + chunk_base) * U2_CW;
     if ((ta | tb) == 0 || (cw0 * 64 >= st.skip_lo && (cw0 + U2_CW) * 64 <= st.skip_hi)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wc_n = ld - cw0 < U2_CW ? (int)(ld - cw0) : U2_CW;
@@ -1259,8 +1270,10 @@ static int launch_eliminate(gf2_ctx* ctx, int mode, u64* a_dev, int64_t batch, i
 
 extern "C" {
 
-// Blocked path.  Workspace: a copy of the batch for the row gather, pivot-row lists, per-matrix state, used flags,
-// coefficients d, the snapshot of the pivot rows and, for m > 8192, the streamed panel words / coefficients / slots.
+// Blocked path.  Workspace: a copy of the batch for the row gather, pivot-row lists, per-matrix state, used flags, and per SET
+// (two of them: with look-ahead the next pair's panels fill one while the trailing pass of this pair reads the other) the
+// coefficients d and pivot-row snapshots of the pair's two panels, `fix`, the pivot rows' indices and a copy of the state as the
+// pass wants it; for m > 8192 also the streamed panel words / coefficients / slots.
 static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld,
                                int64_t* pivots_dev, int64_t cap, int64_t* rank_dev) {
     const int rpt = (int)gf2_cdiv(m, RB_THREADS);
@@ -1269,26 +1282,38 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
     const size_t sbytes = al((size_t)batch * sizeof(RrefState)), ubytes = al((size_t)batch * m);
     const size_t dbytes = al((size_t)batch * m * 8), nbytes = al((size_t)batch * 64 * ld * 8);
     const bool stream = rpt > 8;
-    const size_t fbytes = al((size_t)batch * 64 * 8);
-    const size_t xbytes = stream ? 2 * dbytes + al((size_t)batch * m * 4) + al((size_t)batch * 64 * 4) + (size_t)batch * 2048 * 8 : 0;
-    GF2_TRY(gf2_ws_reserve(ctx, 1, abytes + pbytes + sbytes + ubytes + 2 * dbytes + 2 * nbytes + fbytes + xbytes));
+    const int nsets = stream ? 2 : 1;
+    const size_t fbytes = al((size_t)batch * 64 * 8), rbytes = al((size_t)batch * 64 * 4);
+    const size_t set_bytes = 2 * dbytes + 2 * nbytes + fbytes + 2 * rbytes + sbytes;
+    const size_t xbytes = stream ? 2 * dbytes + al((size_t)batch * m * 4) + (size_t)batch * 2048 * 8 : 0;
+    GF2_TRY(gf2_ws_reserve(ctx, 1, abytes + pbytes + sbytes + ubytes + nsets * set_bytes + xbytes));
     char* q = (char*)ctx->ws[1];
     u64* tmp = (u64*)q; q += abytes;
     int32_t* pivrow = (int32_t*)q; q += pbytes;
     RrefState* states = (RrefState*)q; q += sbytes;
     unsigned char* used = (unsigned char*)q; q += ubytes;
-    u64* dco2[2];                                                      // per panel of a pair: coefficients d, pivot-row snapshot
-    u64* snap2[2];
-    dco2[0] = (u64*)q; q += dbytes;
-    dco2[1] = (u64*)q; q += dbytes;
-    snap2[0] = (u64*)q; q += nbytes;
-    snap2[1] = (u64*)q; q += nbytes;
-    u64* fix = (u64*)q; q += fbytes;
+    struct PairSet {
+        u64* dco[2];                                                   // per panel of the pair: coefficients d, pivot-row snapshot
+        u64* snap[2];
+        u64* fix;
+        int32_t* panel_rows[2];
+        RrefState* state_copy;                                         // the state after the pair's second panel
+    } sets[2];
+    for (int k = 0; k < nsets; ++k) {
+        PairSet& ps = sets[k];
+        ps.dco[0] = (u64*)q; q += dbytes;
+        ps.dco[1] = (u64*)q; q += dbytes;
+        ps.snap[0] = (u64*)q; q += nbytes;
+        ps.snap[1] = (u64*)q; q += nbytes;
+        ps.fix = (u64*)q; q += fbytes;
+        ps.panel_rows[0] = (int32_t*)q; q += rbytes;
+        ps.panel_rows[1] = (int32_t*)q; q += rbytes;
+        ps.state_copy = (RrefState*)q; q += sbytes;
+    }
     u64* wpan = (u64*)q;
     u64* cco = (u64*)(q + dbytes);
     int32_t* slot_of = (int32_t*)(q + 2 * dbytes);
-    int32_t* panel_rows = (int32_t*)(q + 2 * dbytes + al((size_t)batch * m * 4));
-    u64* tabs = (u64*)(q + 2 * dbytes + al((size_t)batch * m * 4) + al((size_t)batch * 64 * 4));
+    u64* tabs = (u64*)(q + 2 * dbytes + al((size_t)batch * m * 4));
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
     GF2_HIP(hipMemsetAsync(states, 0, sbytes + ubytes, ctx->stream));          // rank = 0, used = 0 ...
     hipLaunchKernelGGL(rref_state_init_kernel, dim3((unsigned)gf2_cdiv(batch, 256)), dim3(256), 0, ctx->stream, states, batch, n);
@@ -1305,49 +1330,139 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
     if (rows_per_wg > 256) rows_per_wg = gf2_cdiv(m, gf2_cdiv(m, rows_per_wg));
     if (rows_per_wg < 128) rows_per_wg = 128;
     if (m * chunks * batch < 256 * (int64_t)ctx->num_cus) rows_per_wg = 128;
-    const dim3 ugrid((unsigned)gf2_cdiv(m, rows_per_wg), (unsigned)chunks, (unsigned)batch);
+    // The trailing pass of a pair over chunks [c_lo, c_hi) but `skip`, reading set `ps`.
+    auto launch_pass = [&](const PairSet& ps, const RrefState* st, int64_t c_lo, int64_t c_hi, int64_t skip, int64_t rows_wg,
+                           hipStream_t on) {
+        if (c_hi <= c_lo || (c_hi - c_lo == 1 && skip == c_lo)) return;
+        const dim3 grid((unsigned)gf2_cdiv(m, rows_wg), (unsigned)(c_hi - c_lo), (unsigned)batch);
+        hipLaunchKernelGGL(rref_update_pair_kernel, grid, dim3(RB_THREADS), 128 * 1024, on, a_dev, m, ld, rows_wg, st,
+                           (const u64*)ps.dco[0], (const u64*)ps.dco[1], (const u64*)ps.snap[0], (const u64*)ps.snap[1],
+                           (const u64*)ps.fix, (int)c_lo, (int)skip);
+    };
+    // Every row may have its pivot once m columns have been seen, and a random matrix is done right there: from then on the
+    // ranks are read back now and then (a stream synchronisation, but it saves the launches of the panels that would find
+    // nothing left to do -- half of them for a 2048 x 4096 matrix).
+    auto all_done = [&](int64_t pw, bool* done) -> int {
+        *done = false;
+        if (!((pw + 1) * 64 >= m && pw + 1 < panels && ((pw + 1) * 64 - m) % 512 < 128)) return GF2_OK;
+        std::vector<RrefState> now((size_t)batch);
+        GF2_HIP(hipMemcpyAsync(now.data(), states, (size_t)batch * sizeof(RrefState), hipMemcpyDeviceToHost, ctx->stream));
+        GF2_TRY(gf2_stream_wait(ctx->stream));
+        *done = true;
+        for (const auto& st : now) *done = *done && st.rank >= m;
+        return GF2_OK;
+    };
     // Panels go in PAIRS with one trailing pass of the matrix per pair (rref_update_pair_kernel): the second panel brings its
     // own column up to date on the way in and leaves the correction of its pivot rows to the table build of that pass.
-    for (int64_t pw = 0; pw < panels; ++pw) {
-        const int member = (int)(pw & 1);
-        u64* dco = dco2[member];
-        u64* snap = snap2[member];
+    if (!stream) {
+        const PairSet& ps = sets[0];
+        for (int64_t pw = 0; pw < panels; ++pw) {
+            const int member = (int)(pw & 1);
 #define GF2_RP_LAUNCH(RPT)                                                                                              \
     hipLaunchKernelGGL((rref_panel_kernel<RPT>), dim3((unsigned)batch), dim3(RB_THREADS), 0, ctx->stream, a_dev, m, n, ld, \
-                       pw, pivots_dev, cap, pivrow, states, used, dco, snap, member, (const u64*)dco2[0], (const u64*)snap2[0], fix)
-        if (stream) {
-            hipLaunchKernelGGL(panel_column_kernel, dim3((unsigned)gf2_cdiv(m, 256), (unsigned)batch), dim3(256), 0, ctx->stream,
-                               (const u64*)a_dev, m, ld, pw, wpan, cco, slot_of, member, (const RrefState*)states,
-                               (const u64*)dco2[0], (const u64*)snap2[0]);
-            hipLaunchKernelGGL(rref_panel_stream_kernel, dim3((unsigned)batch), dim3(RB_THREADS), 0, ctx->stream, a_dev, m, n,
-                               ld, pw, pivots_dev, cap, pivrow, states, used, dco, panel_rows, wpan, cco, slot_of, tabs, member,
-                               (const u64*)dco2[0], fix);
-            hipLaunchKernelGGL(panel_finish_kernel, dim3((unsigned)gf2_cdiv(m, 1024) + 64, (unsigned)batch), dim3(1024), 0, ctx->stream,
-                               (const u64*)a_dev, m, ld, (const RrefState*)states, (const u64*)wpan, (const u64*)cco,
-                               (const int32_t*)slot_of, (const u64*)tabs, dco, (const int32_t*)panel_rows, snap);
-        } else if (rpt <= 1)
-            GF2_RP_LAUNCH(1);
-        else if (rpt <= 2)
-            GF2_RP_LAUNCH(2);
-        else if (rpt <= 4)
-            GF2_RP_LAUNCH(4);
-        else
-            GF2_RP_LAUNCH(8);
+                       pw, pivots_dev, cap, pivrow, states, used, ps.dco[member], ps.snap[member], member, (const u64*)ps.dco[0], \
+                       (const u64*)ps.snap[0], ps.fix)
+            if (rpt <= 1)
+                GF2_RP_LAUNCH(1);
+            else if (rpt <= 2)
+                GF2_RP_LAUNCH(2);
+            else if (rpt <= 4)
+                GF2_RP_LAUNCH(4);
+            else
+                GF2_RP_LAUNCH(8);
 #undef GF2_RP_LAUNCH
-        if (member == 0 && pw + 1 < panels) continue;                 // the pair's second panel first
-        hipLaunchKernelGGL(rref_update_pair_kernel, ugrid, dim3(RB_THREADS), 128 * 1024, ctx->stream, a_dev, m, ld, rows_per_wg,
-                           (const RrefState*)states, (const u64*)dco2[0], (const u64*)dco2[1], (const u64*)snap2[0],
-                           (const u64*)snap2[1], (const u64*)fix);
-        // Every row may have its pivot once m columns have been seen, and a random matrix is done right there: from then on the
-        // ranks are read back now and then (a stream synchronisation, but it saves the launches of the panels that would find
-        // nothing left to do -- half of them for a 2048 x 4096 matrix).
-        if ((pw + 1) * 64 >= m && pw + 1 < panels && ((pw + 1) * 64 - m) % 512 < 128) {
-            std::vector<RrefState> now((size_t)batch);
-            GF2_HIP(hipMemcpyAsync(now.data(), states, (size_t)batch * sizeof(RrefState), hipMemcpyDeviceToHost, ctx->stream));
-            GF2_TRY(gf2_stream_wait(ctx->stream));
-            bool done = true;
-            for (const auto& st : now) done = done && st.rank >= m;
+            if (member == 0 && pw + 1 < panels) continue;             // the pair's second panel first
+            launch_pass(ps, states, 0, chunks, -1, rows_per_wg, ctx->stream);
+            bool done;
+            GF2_TRY(all_done(pw, &done));
             if (done) break;
+        }
+    } else {
+        // m > 8192: the panel step is three kernels (column, the one-workgroup factorisation, finish), 30 us per panel with 255 CUs
+        // idle during the middle one -- as long as a trailing pass when a single matrix is being reduced.  LOOK-AHEAD: the next
+        // pair's panels run on a side stream UNDER this pair's pass.  They need their two columns up to date, so the pass does
+        // the chunk that holds them first, in a small launch of its own (workgroups of 128 rows); and they need one CU that no
+        // pass workgroup owns (128 KiB of LDS each), so the rest of the pass goes in two launches, the first of which leaves a
+        // few CUs free.  What the panels leave for later is the snapshot of their pivot rows outside that chunk, which has to
+        // see the finished pass.  The pass reads a COPY of the state taken after its pair's second panel (the look-ahead panels
+        // write the state), and the two pairs in flight use two sets of coefficients, snapshots and pivot-row indices.
+        hipStream_t s1 = ctx->stream, s2 = ctx->side[0];
+        hipEvent_t e_first = ctx->side_ev[0], e_rest = ctx->side_ev[1], e_panels = ctx->side_ev[2];
+        // the three kernels of panel pw (member of its pair) into set ps; snapshot words [w_lo, w_hi) now
+        auto launch_panel = [&](const PairSet& ps, int64_t pw, int member, int64_t w_lo, int64_t w_hi, hipStream_t on) {
+            hipLaunchKernelGGL(panel_column_kernel, dim3((unsigned)gf2_cdiv(m, 256), (unsigned)batch), dim3(256), 0, on,
+                               (const u64*)a_dev, m, ld, pw, wpan, cco, slot_of, member, (const RrefState*)states,
+                               (const u64*)ps.dco[0], (const u64*)ps.snap[0]);
+            hipLaunchKernelGGL(rref_panel_stream_kernel, dim3((unsigned)batch), dim3(RB_THREADS), 0, on, a_dev, m, n, ld, pw,
+                               pivots_dev, cap, pivrow, states, used, ps.dco[member], ps.panel_rows[member], wpan, cco, slot_of, tabs,
+                               member, (const u64*)ps.dco[0], ps.fix);
+            hipLaunchKernelGGL(panel_finish_kernel, dim3((unsigned)gf2_cdiv(m, 1024) + 64, (unsigned)batch), dim3(1024), 0, on,
+                               (const u64*)a_dev, m, ld, (const RrefState*)states, (const u64*)wpan, (const u64*)cco,
+                               (const int32_t*)slot_of, (const u64*)tabs, ps.dco[member], (const int32_t*)ps.panel_rows[member],
+                               ps.snap[member], member, 1, w_lo, w_hi, (int64_t)0, (int64_t)0);
+        };
+        auto launch_snapshot_rest = [&](const PairSet& ps, int member, int64_t hole_lo, int64_t hole_hi, hipStream_t on) {
+            hipLaunchKernelGGL(panel_finish_kernel, dim3(64, (unsigned)batch), dim3(1024), 0, on, (const u64*)a_dev, m, ld,
+                               (const RrefState*)states, (const u64*)wpan, (const u64*)cco, (const int32_t*)slot_of, (const u64*)tabs,
+                               ps.dco[member], (const int32_t*)ps.panel_rows[member], ps.snap[member], member, 0, (int64_t)0, ld,
+                               hole_lo, hole_hi);
+        };
+        const int64_t npairs = gf2_cdiv(panels, 2);
+        // The rest of the pass goes in two launches of about half the remaining chunks each, with as many row blocks as keep
+        // either launch a few workgroups short of the number of CUs: the one-workgroup panel kernel (39 KiB of LDS, 96 registers)
+        // does not fit beside a pass workgroup, and a launch of exactly 256 workgroups that finds one CU taken runs twice as long.
+        const int64_t half = gf2_cdiv(chunks - 1, 2);
+        int64_t blocks_la = half > 0 ? ((int64_t)ctx->num_cus - 8) / (half * batch) : 0;
+        if (blocks_la > gf2_cdiv(m, 128)) blocks_la = gf2_cdiv(m, 128);
+        const bool ahead = !gf2_flag(ctx, GF2_F_RREF_NO_LOOKAHEAD) && chunks >= 8 && blocks_la >= 1;
+        const int64_t rows_la = ahead ? gf2_cdiv(m, blocks_la) : rows_per_wg;
+        // pair 0: nothing to overlap with
+        launch_panel(sets[0], 0, 0, 0, ld, s1);
+        if (panels > 1) launch_panel(sets[0], 1, 1, 0, ld, s1);
+        GF2_HIP(hipMemcpyAsync(sets[0].state_copy, states, (size_t)batch * sizeof(RrefState), hipMemcpyDeviceToDevice, s1));
+        for (int64_t p = 0; p < npairs; ++p) {
+            const PairSet& cur = sets[p & 1];
+            const PairSet& nxt = sets[(p + 1) & 1];
+            const int64_t pw_last = 2 * p + 1 < panels ? 2 * p + 1 : 2 * p;       // this pair's last panel
+            const bool more = p + 1 < npairs;
+            if (!more) {
+                launch_pass(cur, cur.state_copy, 0, chunks, -1, rows_per_wg, s1);
+                break;
+            }
+            const int64_t pa = 2 * (p + 1), pb = pa + 1 < panels ? pa + 1 : -1;   // the next pair's panels
+            const int64_t cnext = pa / U2_CW;                                     // both in one chunk (pa is even)
+            if (ahead) {
+                launch_pass(cur, cur.state_copy, cnext, cnext + 1, -1, 128, s1);
+                GF2_HIP(hipEventRecord(e_first, s1));
+                GF2_HIP(hipStreamWaitEvent(s2, e_first, 0));
+                launch_panel(nxt, pa, 0, cnext * U2_CW, (cnext + 1) * U2_CW < ld ? (cnext + 1) * U2_CW : ld, s2);
+                if (pb >= 0) launch_panel(nxt, pb, 1, cnext * U2_CW, (cnext + 1) * U2_CW < ld ? (cnext + 1) * U2_CW : ld, s2);
+                // the rest of the pass (see above): chunks [0, h1) and [h1, chunks), both without cnext
+                const int64_t h1 = cnext < half ? half + 1 : half;
+                launch_pass(cur, cur.state_copy, 0, h1, cnext, rows_la, s1);
+                launch_pass(cur, cur.state_copy, h1, chunks, cnext, rows_la, s1);
+                GF2_HIP(hipEventRecord(e_rest, s1));
+                GF2_HIP(hipStreamWaitEvent(s2, e_rest, 0));
+                launch_snapshot_rest(nxt, 0, cnext * U2_CW, (cnext + 1) * U2_CW, s2);
+                if (pb >= 0) launch_snapshot_rest(nxt, 1, cnext * U2_CW, (cnext + 1) * U2_CW, s2);
+                GF2_HIP(hipMemcpyAsync(nxt.state_copy, states, (size_t)batch * sizeof(RrefState), hipMemcpyDeviceToDevice, s2));
+                GF2_HIP(hipEventRecord(e_panels, s2));
+                GF2_HIP(hipStreamWaitEvent(s1, e_panels, 0));
+            } else {
+                launch_pass(cur, cur.state_copy, 0, chunks, -1, rows_per_wg, s1);
+                launch_panel(nxt, pa, 0, 0, ld, s1);
+                if (pb >= 0) launch_panel(nxt, pb, 1, 0, ld, s1);
+                GF2_HIP(hipMemcpyAsync(nxt.state_copy, states, (size_t)batch * sizeof(RrefState), hipMemcpyDeviceToDevice, s1));
+            }
+            // (the look-ahead panels have run when the ranks are read: the read-back waits for s1, which has waited for them)
+            bool done;
+            GF2_TRY(all_done(pb >= 0 ? pb : pa, &done));
+            if (done) {
+                // the next pair's panels found the last pivots (or nothing): their pass is still due
+                launch_pass(nxt, nxt.state_copy, 0, chunks, -1, rows_per_wg, s1);
+                break;
+            }
+            (void)pw_last;
         }
     }
     GF2_HIP(hipGetLastError());
@@ -1480,7 +1595,8 @@ int gf2_normalize_dev(gf2_ctx* ctx, uint64_t* h_dev, int64_t r, int64_t n, int64
 #undef GF2_NP_LAUNCH
             // the RREF's trailing pass with this panel as the first of a pair that has no second (diagonal rows rebuilt from zero)
             hipLaunchKernelGGL(rref_update_pair_kernel, ugrid, dim3(RB_THREADS), 128 * 1024, ctx->stream, (u64*)h_dev, r, ld, rows_per_wg,
-                               (const RrefState*)st, (const u64*)dco, (const u64*)dco, (const u64*)snap, (const u64*)snap, (const u64*)dco);
+                               (const RrefState*)st, (const u64*)dco, (const u64*)dco, (const u64*)snap, (const u64*)snap, (const u64*)dco,
+                               0, -1);
             hipLaunchKernelGGL(eliminate_kernel<ELIM_NORMALIZE>, dim3(1), dim3(ELIM_THREADS), 0, ctx->stream, (u64*)h_dev, r, n, ld,
                                offset, (int64_t*)nullptr, (int64_t)0, (int64_t*)nullptr, swaps_dev, nswaps_dev, status_dev, st);
             GF2_HIP(hipGetLastError());

@@ -318,7 +318,7 @@ def syndrome_table(parity_check, max_weight=None):
     return it along with a lookup table from syndromes (as bin_matrix.vec_to_int keys) to error vectors
     of weight at most t (css_code.py:715-735).
 
-    Codes of at most 128 bits and 24 checks are searched entirely on the device (gf2_table.hip).  Otherwise each
+    Codes of at most 8192 bits and 24 checks are searched entirely on the device (gf2_table.hip).  Otherwise each
     weight class is enumerated in bin_matrix.weight_w_vectors order, in chunks, and its syndromes are computed on the GPU; a class containing a syndrome already seen (in an earlier class or earlier in the
     same class) ends the search and is discarded as a whole, exactly as the reference's loop does.  Keys are
     formed and compared as machine words when r <= 63 (the reference's own keys are only meaningful there,
@@ -341,9 +341,13 @@ def syndrome_table(parity_check, max_weight=None):
         order = np.lexsort((~rev, np.bitwise_count(words)))
         errs = _native.unpack_rows(words[order].reshape(-1, 1), n, dtype=np.uint8).astype('int')
         return t, dict(zip(keys[order].tolist(), errs))
-    if ctx.TABLE_MAX_N < n <= ctx.TABLE_WIDE_MAX_N and r <= ctx.TABLE_MAX_R:
-        # two-word errors (n up to 127): the device table holds (weight, rank in the class)
-        t, dense = ctx.syndrome_table_wide(packed_h, r, n, max_weight)
+    if ctx.TABLE_MAX_N < n <= ctx.TABLE_COLS_MAX_N and r <= ctx.TABLE_MAX_R:
+        # two-word errors (n up to 127) or, beyond 128 bits, errors as position lists: the device table
+        # holds (weight, rank in the class)
+        if n <= ctx.TABLE_WIDE_MAX_N:
+            t, dense = ctx.syndrome_table_wide(packed_h, r, n, max_weight)
+        else:
+            t, dense = ctx.syndrome_table_cols(packed_h, r, n, max_weight)
         keys = np.nonzero(dense != ctx.TABLE_EMPTY)[0]
         weight = (dense[keys] >> np.uint64(32)).astype(np.int64)
         rank = dense[keys] & np.uint64(0xFFFFFFFF)
