@@ -87,7 +87,8 @@ int gf2_ctx_sync(gf2_ctx* ctx);
 #define GF2_F_MC_ROWS              (1u << 14)  /* gf2_mc_run: packed rows from the sampler, records by the compact kernel */
 #define GF2_F_COMBINE_FOLDED       (1u << 15)  /* slab pipeline: the combine step of a pass inside the next pass' compact kernel */
 #define GF2_F_RREF_NO_LOOKAHEAD    (1u << 16)  /* gf2_rref* on more than 8192 rows: the next pair's panels after, not under, the trailing pass */
-#define GF2_F_ALL                  ((1u << 17) - 1u)   /* every defined flag; gf2_ctx_set_flags refuses other bits              */
+#define GF2_F_RREF_LOOKAHEAD       (1u << 17)  /* ... under it whatever the size (default: from 128 MiB of matrix on)              */
+#define GF2_F_ALL                  ((1u << 18) - 1u)   /* every defined flag; gf2_ctx_set_flags refuses other bits              */
 int gf2_ctx_set_flags(gf2_ctx* ctx, uint32_t flags);
 int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
 /* Tunables of a context (value < 0 restores the default). */
@@ -97,7 +98,7 @@ int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
 #define GF2_OPT_REDO_BLOCKS_PER_CU 3 /* slab pipeline: workgroups per CU of the redo kernel, 1..64 (default 8)                 */
 #define GF2_OPT_MC_CHUNK_LOG2   4   /* gf2_mc_run at n <= 4096, sparse rates: 2^k samples per chunk, 16 <= k <= 22 (default 22; 21 with GF2_F_MC_ROWS) */
 #define GF2_OPT_COMBINE_THREADS 5   /* slab pipeline: threads per workgroup of the combine kernel, 64 / 128 / 256 / 512 / 1024 (default 1024) */
-#define GF2_OPT_GATHER_CROSS    6   /* slab pipeline: 1 (default) = a gather step takes ranks 4k..4k+3 of four sorted tiles, 0 = a quartile of one */
+#define GF2_OPT_GATHER_CROSS    6   /* slab pipeline: 1 = a gather step takes ranks 4k..4k+3 of four sorted tiles, 0 (default) = a quartile of one */
 #define GF2_OPT_COUNT           7
 int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value);
 

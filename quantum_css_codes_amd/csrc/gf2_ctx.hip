@@ -68,6 +68,11 @@ __global__ __launch_bounds__(512) void membw_probe_kernel(const probe_vec* __res
 static int create_streams_and_events(gf2_ctx* ctx) {
     GF2_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     for (int k = 0; k < 2; ++k) GF2_HIP(hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking));
+    {
+        int least = 0, greatest = 0;                               // (numerically lower = higher priority)
+        GF2_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        GF2_HIP(hipStreamCreateWithPriority(&ctx->hi, hipStreamNonBlocking, greatest));
+    }
     for (int k = 0; k < 7; ++k) GF2_HIP(hipEventCreateWithFlags(&ctx->side_ev[k], hipEventDisableTiming));
     GF2_HIP(hipEventCreate(&ctx->t0));
     GF2_HIP(hipEventCreate(&ctx->t1));
@@ -89,6 +94,7 @@ static void destroy_streams_and_events(gf2_ctx* ctx) {
         if (ctx->side_ev[k]) (void)hipEventDestroy(ctx->side_ev[k]);
     for (int k = 0; k < 2; ++k)
         if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);
+    if (ctx->hi) (void)hipStreamDestroy(ctx->hi);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 }
 
@@ -178,6 +184,7 @@ int gf2_ctx_destroy(gf2_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (int k = 0; k < 2; ++k) (void)hipStreamSynchronize(ctx->side[k]);
+    (void)hipStreamSynchronize(ctx->hi);
     for (int k = 0; k < 4; ++k)
         if (ctx->ws[k]) (void)hipFree(ctx->ws[k]);
     if (ctx->seg_cdf_dev) (void)hipFree(ctx->seg_cdf_dev);
@@ -406,6 +413,7 @@ int gf2_ws_reserve(gf2_ctx* ctx, int slot, size_t bytes) {
     if (ctx->ws_bytes[slot] >= bytes) return GF2_OK;
     GF2_HIP(hipStreamSynchronize(ctx->stream));
     for (int k = 0; k < 2; ++k) GF2_HIP(hipStreamSynchronize(ctx->side[k]));
+    GF2_HIP(hipStreamSynchronize(ctx->hi));
     if (ctx->ws[slot]) GF2_HIP(hipFree(ctx->ws[slot]));
     ctx->ws[slot] = nullptr;
     ctx->ws_bytes[slot] = 0;

@@ -582,6 +582,23 @@ __global__ __launch_bounds__(1024) void panel_finish_kernel(const u64* __restric
     d_base[mat * m + row] = d;
 }
 
+// Look-ahead: what the two panels of a pair could not copy while the previous pair's trailing pass was running -- their pivot
+// rows outside the chunk [hole_lo, hole_hi) that was up to date already.  Workgroups 0 .. 63: first panel, 64 .. 127: second.
+__global__ __launch_bounds__(1024) void panel_snapshot_rest_kernel(const u64* __restrict__ base, int64_t m, int64_t ld,
+                                                                   const RrefState* __restrict__ states,
+                                                                   const int32_t* __restrict__ prow_a, const int32_t* __restrict__ prow_b,
+                                                                   u64* __restrict__ snap_a, u64* __restrict__ snap_b, int64_t hole_lo,
+                                                                   int64_t hole_hi) {
+    const int64_t mat = blockIdx.y;
+    const int member = (int)blockIdx.x >> 6, p = (int)blockIdx.x & 63;
+    if (p >= states[mat].tg[member]) return;
+    const int32_t* prow = member ? prow_b : prow_a;
+    const u64* src = base + (mat * m + prow[mat * 64 + p]) * ld;
+    u64* dst = (member ? snap_b : snap_a) + (mat * 64 + p) * ld;
+    for (int64_t wd = threadIdx.x; wd < ld; wd += blockDim.x)
+        if (wd < hole_lo || wd >= hole_hi) dst[wd] = src[wd];
+}
+
 // The same panel step for matrices with more than 8192 rows: rows are streamed instead of held in registers.  The
 // current panel word and coefficient of every row live in global scratch (wpan, cco); the window is filled through an
 // LDS counter (any unused rows with a bit in an unresolved column will do -- the RREF does not depend on the choice).
@@ -1379,20 +1396,26 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
         }
     } else {
         // m > 8192: the panel step is three kernels (column, the one-workgroup factorisation, finish), 30 us per panel with 255 CUs
-        // idle during the middle one -- as long as a trailing pass when a single matrix is being reduced.  LOOK-AHEAD: the next
-        // pair's panels run on a side stream UNDER this pair's pass.  They need their two columns up to date, so the pass does
-        // the chunk that holds them first, in a small launch of its own (workgroups of 128 rows); and they need one CU that no
-        // pass workgroup owns (128 KiB of LDS each), so the rest of the pass goes in two launches, the first of which leaves a
-        // few CUs free.  What the panels leave for later is the snapshot of their pivot rows outside that chunk, which has to
-        // see the finished pass.  The pass reads a COPY of the state taken after its pair's second panel (the look-ahead panels
-        // write the state), and the two pairs in flight use two sets of coefficients, snapshots and pivot-row indices.
-        hipStream_t s1 = ctx->stream, s2 = ctx->side[0];
-        hipEvent_t e_first = ctx->side_ev[0], e_rest = ctx->side_ev[1], e_panels = ctx->side_ev[2];
-        // the three kernels of panel pw (member of its pair) into set ps; snapshot words [w_lo, w_hi) now
-        auto launch_panel = [&](const PairSet& ps, int64_t pw, int member, int64_t w_lo, int64_t w_hi, hipStream_t on) {
+        // idle during the middle one -- two thirds of a trailing pass when a single matrix is being reduced.  LOOK-AHEAD: the next
+        // pair's panels run on a high-priority side stream UNDER this pair's pass:
+        //   main  | pass, chunk c only (128-row workgroups)  . . wait . . | pass, every other chunk (one launch)      | rest of the
+        //   side  |                     wait . . . . . . . . | column A' | panel A', finish A', column B', panel B', finish B' | snapshots
+        // c is the chunk of 32 words that holds the next pair's two columns: the panels need those up to date, nothing else of the
+        // matrix.  The one-workgroup panel kernel (39 KiB of LDS, 96 registers) cannot share a CU with a pass workgroup (128 KiB),
+        // so the big launch starts when panel A' is about to (behind its column kernel), and without chunk c it is 16 workgroups
+        // short of two rounds of the chip: panel B' finds a CU too.  What is left for after the pass is the snapshot of the new
+        // pivot rows outside chunk c, which has to see the finished pass.  The pass reads a COPY of the state taken after its
+        // pair's second panel (the look-ahead panels write the state), and the two pairs in flight use two sets of coefficients,
+        // snapshots and pivot-row indices.
+        hipStream_t s1 = ctx->stream, s2 = ctx->hi;
+        hipEvent_t e_first = ctx->side_ev[0], e_column = ctx->side_ev[1], e_panels = ctx->side_ev[2];
+        auto launch_column = [&](const PairSet& ps, int64_t pw, int member, hipStream_t on) {
             hipLaunchKernelGGL(panel_column_kernel, dim3((unsigned)gf2_cdiv(m, 256), (unsigned)batch), dim3(256), 0, on,
                                (const u64*)a_dev, m, ld, pw, wpan, cco, slot_of, member, (const RrefState*)states,
                                (const u64*)ps.dco[0], (const u64*)ps.snap[0]);
+        };
+        // the factorisation and finish kernels of panel pw (member of its pair) into set ps; snapshot words [w_lo, w_hi) now
+        auto launch_panel = [&](const PairSet& ps, int64_t pw, int member, int64_t w_lo, int64_t w_hi, hipStream_t on) {
             hipLaunchKernelGGL(rref_panel_stream_kernel, dim3((unsigned)batch), dim3(RB_THREADS), 0, on, a_dev, m, n, ld, pw,
                                pivots_dev, cap, pivrow, states, used, ps.dco[member], ps.panel_rows[member], wpan, cco, slot_of, tabs,
                                member, (const u64*)ps.dco[0], ps.fix);
@@ -1401,57 +1424,56 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
                                (const int32_t*)slot_of, (const u64*)tabs, ps.dco[member], (const int32_t*)ps.panel_rows[member],
                                ps.snap[member], member, 1, w_lo, w_hi, (int64_t)0, (int64_t)0);
         };
-        auto launch_snapshot_rest = [&](const PairSet& ps, int member, int64_t hole_lo, int64_t hole_hi, hipStream_t on) {
-            hipLaunchKernelGGL(panel_finish_kernel, dim3(64, (unsigned)batch), dim3(1024), 0, on, (const u64*)a_dev, m, ld,
-                               (const RrefState*)states, (const u64*)wpan, (const u64*)cco, (const int32_t*)slot_of, (const u64*)tabs,
-                               ps.dco[member], (const int32_t*)ps.panel_rows[member], ps.snap[member], member, 0, (int64_t)0, ld,
-                               hole_lo, hole_hi);
-        };
         const int64_t npairs = gf2_cdiv(panels, 2);
-        // The rest of the pass goes in two launches of about half the remaining chunks each, with as many row blocks as keep
-        // either launch a few workgroups short of the number of CUs: the one-workgroup panel kernel (39 KiB of LDS, 96 registers)
-        // does not fit beside a pass workgroup, and a launch of exactly 256 workgroups that finds one CU taken runs twice as long.
-        const int64_t half = gf2_cdiv(chunks - 1, 2);
-        int64_t blocks_la = half > 0 ? ((int64_t)ctx->num_cus - 8) / (half * batch) : 0;
-        if (blocks_la > gf2_cdiv(m, 128)) blocks_la = gf2_cdiv(m, 128);
-        const bool ahead = !gf2_flag(ctx, GF2_F_RREF_NO_LOOKAHEAD) && chunks >= 8 && blocks_la >= 1;
-        const int64_t rows_la = ahead ? gf2_cdiv(m, blocks_la) : rows_per_wg;
+        // (it pays when a pass outlasts the two panels: 43.1 -> 38.1 ms for one 32768 x 65536 matrix, but 11.9 -> 14.4 ms for
+        // 16384 x 32768, whose passes take 30 us and whose panels 64: from 128 MiB of matrix on -- profiles/r03_rref_lookahead.log)
+        const bool ahead = !gf2_flag(ctx, GF2_F_RREF_NO_LOOKAHEAD) && chunks >= 2 && s2 != nullptr &&
+                           ((chunks >= 8 && m * ld * batch >= (1ll << 24)) || gf2_flag(ctx, GF2_F_RREF_LOOKAHEAD));
         // pair 0: nothing to overlap with
+        launch_column(sets[0], 0, 0, s1);
         launch_panel(sets[0], 0, 0, 0, ld, s1);
-        if (panels > 1) launch_panel(sets[0], 1, 1, 0, ld, s1);
+        if (panels > 1) {
+            launch_column(sets[0], 1, 1, s1);
+            launch_panel(sets[0], 1, 1, 0, ld, s1);
+        }
         GF2_HIP(hipMemcpyAsync(sets[0].state_copy, states, (size_t)batch * sizeof(RrefState), hipMemcpyDeviceToDevice, s1));
         for (int64_t p = 0; p < npairs; ++p) {
             const PairSet& cur = sets[p & 1];
             const PairSet& nxt = sets[(p + 1) & 1];
-            const int64_t pw_last = 2 * p + 1 < panels ? 2 * p + 1 : 2 * p;       // this pair's last panel
-            const bool more = p + 1 < npairs;
-            if (!more) {
+            if (p + 1 >= npairs) {
                 launch_pass(cur, cur.state_copy, 0, chunks, -1, rows_per_wg, s1);
                 break;
             }
             const int64_t pa = 2 * (p + 1), pb = pa + 1 < panels ? pa + 1 : -1;   // the next pair's panels
             const int64_t cnext = pa / U2_CW;                                     // both in one chunk (pa is even)
+            const int64_t w_lo = cnext * U2_CW, w_hi = (cnext + 1) * U2_CW < ld ? (cnext + 1) * U2_CW : ld;
             if (ahead) {
                 launch_pass(cur, cur.state_copy, cnext, cnext + 1, -1, 128, s1);
                 GF2_HIP(hipEventRecord(e_first, s1));
                 GF2_HIP(hipStreamWaitEvent(s2, e_first, 0));
-                launch_panel(nxt, pa, 0, cnext * U2_CW, (cnext + 1) * U2_CW < ld ? (cnext + 1) * U2_CW : ld, s2);
-                if (pb >= 0) launch_panel(nxt, pb, 1, cnext * U2_CW, (cnext + 1) * U2_CW < ld ? (cnext + 1) * U2_CW : ld, s2);
-                // the rest of the pass (see above): chunks [0, h1) and [h1, chunks), both without cnext
-                const int64_t h1 = cnext < half ? half + 1 : half;
-                launch_pass(cur, cur.state_copy, 0, h1, cnext, rows_la, s1);
-                launch_pass(cur, cur.state_copy, h1, chunks, cnext, rows_la, s1);
-                GF2_HIP(hipEventRecord(e_rest, s1));
-                GF2_HIP(hipStreamWaitEvent(s2, e_rest, 0));
-                launch_snapshot_rest(nxt, 0, cnext * U2_CW, (cnext + 1) * U2_CW, s2);
-                if (pb >= 0) launch_snapshot_rest(nxt, 1, cnext * U2_CW, (cnext + 1) * U2_CW, s2);
+                launch_column(nxt, pa, 0, s2);
+                GF2_HIP(hipEventRecord(e_column, s2));
+                launch_panel(nxt, pa, 0, w_lo, w_hi, s2);
+                if (pb >= 0) {
+                    launch_column(nxt, pb, 1, s2);
+                    launch_panel(nxt, pb, 1, w_lo, w_hi, s2);
+                }
                 GF2_HIP(hipMemcpyAsync(nxt.state_copy, states, (size_t)batch * sizeof(RrefState), hipMemcpyDeviceToDevice, s2));
                 GF2_HIP(hipEventRecord(e_panels, s2));
+                GF2_HIP(hipStreamWaitEvent(s1, e_column, 0));
+                launch_pass(cur, cur.state_copy, 0, chunks, cnext, rows_per_wg, s1);
                 GF2_HIP(hipStreamWaitEvent(s1, e_panels, 0));
+                hipLaunchKernelGGL(panel_snapshot_rest_kernel, dim3(128, (unsigned)batch), dim3(1024), 0, s1, (const u64*)a_dev, m, ld,
+                                   (const RrefState*)states, (const int32_t*)nxt.panel_rows[0], (const int32_t*)nxt.panel_rows[1],
+                                   nxt.snap[0], nxt.snap[1], w_lo, w_hi);
             } else {
                 launch_pass(cur, cur.state_copy, 0, chunks, -1, rows_per_wg, s1);
+                launch_column(nxt, pa, 0, s1);
                 launch_panel(nxt, pa, 0, 0, ld, s1);
-                if (pb >= 0) launch_panel(nxt, pb, 1, 0, ld, s1);
+                if (pb >= 0) {
+                    launch_column(nxt, pb, 1, s1);
+                    launch_panel(nxt, pb, 1, 0, ld, s1);
+                }
                 GF2_HIP(hipMemcpyAsync(nxt.state_copy, states, (size_t)batch * sizeof(RrefState), hipMemcpyDeviceToDevice, s1));
             }
             // (the look-ahead panels have run when the ranks are read: the read-back waits for s1, which has waited for them)
@@ -1462,7 +1484,6 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
                 launch_pass(nxt, nxt.state_copy, 0, chunks, -1, rows_per_wg, s1);
                 break;
             }
-            (void)pw_last;
         }
     }
     GF2_HIP(hipGetLastError());

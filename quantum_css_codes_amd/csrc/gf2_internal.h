@@ -42,6 +42,7 @@ struct gf2_ctx {
     int num_cus;
     hipStream_t stream;
     hipStream_t side[2];          // side streams of the pipelined Monte-Carlo (gf2_mc_run): one per Pauli component
+    hipStream_t hi;               // highest-priority stream: the look-ahead panels of the streamed RREF (gf2_elim.hip)
     hipEvent_t side_ev[7];        // sampled[2], done_z[2], done_x[2], start
     hipEvent_t t0, t1;            // gf2_timer_*
     // per-kernel-family profiling: ring of event pairs resolved lazily

@@ -1048,9 +1048,10 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
 
     // A step looks up as many slot pairs as its longest record has.  The tiles are sorted by count, so the 16 records of a step
     // should sit close together in that order: a quartile of one tile spans a quarter of the tile's spread, the four records of
-    // ranks 4k .. 4k + 3 taken from FOUR consecutive tiles span a sixteenth (`cross`; 17.4 instead of 18.3 lookups per record at
-    // the benchmark's rate before the pairs, 15.4 with them and without the header's lookup).  Group g of a super-tile of four
-    // tiles: k = g mod 16; a step's records are 32-byte ones for k < 8.
+    // ranks 4k .. 4k + 3 taken from FOUR consecutive tiles span a sixteenth (`cross`, GF2_OPT_GATHER_CROSS; 16.4 -> 15.4 lookups
+    // per record at the benchmark's rate).  Group g of a super-tile of four tiles: k = g mod 16; a step's records are 32-byte
+    // ones for k < 8.  Measured (profiles/r03_*): the lookups it saves are paid back by its four short runs of records and
+    // partial weights per step -- 2 % slower on one stream, equal on two -- so it is off by default.
     const unsigned int ntiles = (unsigned int)((a.batch + 63) >> 6);
     const unsigned int ngroups = a.cross ? ((ntiles + 3u) >> 2) << 4 : ntiles << 2;
     const unsigned int stride = (unsigned int)shares * GAT_WAVES;
@@ -1386,7 +1387,7 @@ static int launch_gather(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u
     ga.stray_col[1] = stray.col[1];
     ga.clk = clk_dev;
     ga.reverse = ctx->opt[GF2_OPT_GATHER_REVERSE] == 0 ? 0 : 1;
-    ga.cross = ctx->opt[GF2_OPT_GATHER_CROSS] == 0 ? 0 : 1;
+    ga.cross = ctx->opt[GF2_OPT_GATHER_CROSS] == 1 ? 1 : 0;
     int64_t shares = ctx->num_cus / ck->nslabs512;
     const int64_t max_shares = gf2_cdiv(gf2_cdiv(count, 16), GAT_WAVES);   // (a few steps more with `cross`: they read zeros)
     if (shares > max_shares) shares = max_shares;

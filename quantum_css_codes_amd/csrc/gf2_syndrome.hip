@@ -77,8 +77,7 @@ __global__ void build_tables_kernel(const uint64_t* __restrict__ h, int64_t r, i
 
 #define SYN_THREADS 768                             // 12 wavefronts; two workgroups per CU -> 6 waves/SIMD, 80 VGPRs
 #define SYN_WAVES (SYN_THREADS / 64)
-#define SYN_TPW 5                                   // tiles (of 64 samples) per wave
-#define SYN_BLOCK_TILES (SYN_WAVES * SYN_TPW)       // 60 tiles = 3840 samples per workgroup
+#define SYN_TPW_MIN 5                               // tiles (of 64 samples) per wave: at least 60 tiles = 3840 samples per workgroup
 #define SYN_CHUNK_PAIRS 19                          // 19 pairs x 4 KiB = 76 KiB of LDS per staging, 2 workgroups/CU
 #define SYN_UNROLL_PAIRS 16                         // pairs whose table offsets fit the 16-bit DS immediate
 
@@ -159,7 +158,7 @@ struct PairUnroll<0> {
 __global__ __launch_bounds__(SYN_THREADS, 6) void syndrome_tiled_kernel(
     const u64* __restrict__ tables, const int32_t* __restrict__ pair_list, const int32_t* __restrict__ npairs,
     int64_t max_pairs, int64_t slabs, int64_t r, int64_t ident_off, const uint64_t* __restrict__ e, int64_t batch,
-    int64_t ldt, uint64_t* __restrict__ s, int64_t sstride, int64_t chunks) {
+    int64_t ldt, uint64_t* __restrict__ s, int64_t sstride, int64_t chunks, int tpw) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tab[];
     const int64_t b = blockIdx.x;
     const int64_t xcd = b & 7, q = b >> 3;
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(SYN_THREADS, 6) void syndrome_tiled_kernel(
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: tile addresses stay in SGPRs
     const int64_t tiles = (batch + 63) >> 6;
-    const int64_t tile0 = chunk * SYN_BLOCK_TILES + wave;
+    const int64_t tile0 = chunk * (int64_t)(SYN_WAVES * tpw) + wave;
     const int np_total = npairs[slab];
     const int32_t* pairs = pair_list + slab * max_pairs;
     unsigned int mask78 = 0x78u;
@@ -193,7 +192,7 @@ __global__ __launch_bounds__(SYN_THREADS, 6) void syndrome_tiled_kernel(
         }
         __syncthreads();
 #pragma unroll 1
-        for (int k = 0; k < SYN_TPW; ++k) {
+        for (int k = 0; k < tpw; ++k) {
             const int64_t tile = tile0 + (int64_t)k * SYN_WAVES;
             if (tile >= tiles) break;
             const uint64_t* tbase = e + tile * 64 * ldt;
@@ -575,7 +574,14 @@ int gf2_retile_dev(gf2_ctx* ctx, const uint64_t* e_dev, int64_t batch, int64_t l
 static int launch_tiled(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_tiled, int64_t batch, uint64_t* s_dev,
                         int64_t sstride) {
     const int64_t tiles = gf2_cdiv(batch, 64);
-    const int64_t chunks = gf2_cdiv(tiles, SYN_BLOCK_TILES);
+    // Every workgroup stages its slab's tables (64 - 76 KiB) before it touches a sample: with 3840 samples per workgroup a launch
+    // of 2^20 samples read 594 MB of tables for 537 MB of errors (round 2's "1.86 x algorithmic" traffic was mostly this).  Large
+    // batches therefore get as many tiles per wavefront as leave about four workgroups per CU over the launch (two are resident).
+    int64_t chunks_target = gf2_cdiv(4 * (int64_t)ctx->num_cus, ck->slabs > 0 ? ck->slabs : 1);
+    chunks_target = gf2_cdiv(chunks_target, 8) * 8;
+    int64_t tpw = gf2_cdiv(tiles, chunks_target * SYN_WAVES);
+    if (tpw < SYN_TPW_MIN) tpw = SYN_TPW_MIN;
+    const int64_t chunks = gf2_cdiv(tiles, SYN_WAVES * tpw);
     const int64_t chunks8 = gf2_cdiv(chunks, 8) * 8;
     const int64_t blocks = chunks8 * ck->slabs;
     if (blocks > 0x7fffffffLL) GF2_FAIL(GF2_E_ARG, "gf2_syndrome_dev: batch too large for one launch");
@@ -589,7 +595,7 @@ static int launch_tiled(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_til
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_SYNDROME));
     hipLaunchKernelGGL(syndrome_tiled_kernel, dim3((unsigned)blocks), dim3(SYN_THREADS), shmem, ctx->stream,
                        (const u64*)ck->tables_dev, ck->pair_list_dev, ck->npairs_dev, ck->max_pairs, ck->slabs, ck->r,
-                       ck->ident_off, e_tiled, batch, ck->ldt, s_dev, sstride, chunks);
+                       ck->ident_off, e_tiled, batch, ck->ldt, s_dev, sstride, chunks, (int)tpw);
     GF2_TRY(gf2_prof_end(ctx));
     GF2_HIP(hipGetLastError());
     return GF2_OK;

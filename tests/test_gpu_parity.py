@@ -767,7 +767,7 @@ def test_rref_more_than_8192_rows_streaming_panel_kernel(ctx):
 
 @pytest.mark.parametrize("case", ["dependent rows, odd number of panels", "full rank, done half way"])
 def test_rref_streamed_panels_with_look_ahead(case, ctx, route):
-    # more than 8192 rows and at least 8 column chunks of 32 words: the next pair's panels run on a side stream under the trailing
+    # more than 8192 rows and several column chunks of 32 words: the next pair's panels run on a side stream under the trailing
     # pass of this pair (launch_rref_blocked); same matrix, pivots and rank as the oracle and as the run without look-ahead
     rng = np.random.default_rng(8400)
     if case.startswith("dependent"):
@@ -785,7 +785,9 @@ def test_rref_streamed_panels_with_look_ahead(case, ctx, route):
     packed = _native.pack_rows(a)
     want, want_piv, want_rank = c_oracle.rref(packed.copy(), m, n)
     ahead = packed.copy()
+    route.force("GF2_RREF_LOOKAHEAD")            # (by default only from 128 MiB of matrix on, where it pays)
     pivots, rank = ctx.rref(ahead, m, n)
+    route.release("GF2_RREF_LOOKAHEAD")
     assert rank == want_rank and list(pivots) == list(want_piv)
     assert np.array_equal(ahead, want)
     route.force("GF2_RREF_NO_LOOKAHEAD")
@@ -793,6 +795,42 @@ def test_rref_streamed_panels_with_look_ahead(case, ctx, route):
     pivots2, rank2 = ctx.rref(plain, m, n)
     route.release("GF2_RREF_NO_LOOKAHEAD")
     assert rank2 == want_rank and list(pivots2) == list(want_piv) and np.array_equal(plain, want)
+
+
+def test_rref_256_mib_matrix_with_and_without_look_ahead(ctx, route):
+    # bench.py's 32768 x 65536 matrix: too large for the CPU oracle, so the size-independent properties -- the run with look-ahead
+    # (the default at this size) and the run without it return the same bytes, the rank is full, the pivot columns ascend, the
+    # pivot columns of the result form an identity, and rows of the input lie in the row space of the result (spot-checked
+    # through the syndrome kernel: R's nullspace annihilates the input rows)
+    m, n = 32768, 65536
+    ld = n // 64
+    rng = np.random.default_rng(4096)
+    a = (rng.integers(0, 2**63, (m, ld), dtype=np.int64).view(np.uint64) << np.uint64(1)) | \
+        rng.integers(0, 2, (m, ld), dtype=np.int64).view(np.uint64)
+    outs = []
+    for flag in (None, "GF2_RREF_NO_LOOKAHEAD"):
+        if flag:
+            route.force(flag)
+        buf = ctx.alloc(a.nbytes).upload(a)
+        piv, rk = ctx.alloc(m * 8).zero(), ctx.alloc(8)
+        _native.check(_native.lib().gf2_rref_batch_dev(ctx.handle, buf.ptr, 1, m, n, ld, piv.ptr, rk.ptr))
+        outs.append((buf.download((m, ld), "<u8"), piv.download((m,), np.int64), int(rk.download((1,), np.int64)[0])))
+        for b in (buf, piv, rk):
+            b.free()
+        if flag:
+            route.release(flag)
+    (red, piv, rank), (red2, piv2, rank2) = outs
+    assert rank == rank2 == m and np.array_equal(piv, piv2) and np.array_equal(red, red2)
+    assert np.all(np.diff(piv) > 0)
+    # column piv[i] of the result is e_i (checked on a spread of pivots: one word column each)
+    for i in range(0, m, 997):
+        col = (red[:, piv[i] >> 6] >> np.uint64(piv[i] & 63)) & np.uint64(1)
+        assert int(col.sum()) == 1 and int(col[i]) == 1
+    # a row of the input is the XOR of the result's rows selected by its bits in the pivot columns
+    for i in (0, 12345, m - 1):
+        bits = (a[i][piv >> 6] >> (piv & 63).astype(np.uint64)) & np.uint64(1)
+        combo = np.bitwise_xor.reduce(red[bits.astype(bool)], axis=0)
+        assert np.array_equal(combo, a[i])
 
 
 def test_host_syndrome_batch_routes_sparse_and_dense(ctx):
@@ -1011,6 +1049,13 @@ def test_syndrome_slab_pipeline(case, ctx, route):
     hist = ctx.alloc((r + 1) * 8).zero()
     ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist, r + 1)
     assert np.array_equal(hist.download((r + 1,), np.uint64), want)
+    # ... and with a gather step's 16 records taken from four sorted tiles instead of a quartile of one (GF2_OPT_GATHER_CROSS)
+    ctx.set_option(_native.OPT_GATHER_CROSS, 1)
+    try:
+        ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist, r + 1)
+    finally:
+        ctx.set_option(_native.OPT_GATHER_CROSS, None)
+    assert np.array_equal(hist.download((r + 1,), np.uint64), want * np.uint64(2))
     route.release("GF2_SPARSE_SLABS")
     route.force("GF2_SPARSE_GATHER")
     hist2 = ctx.alloc((r + 1) * 8).zero()
