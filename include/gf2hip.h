@@ -133,6 +133,10 @@ int gf2_membw_probe_dev(gf2_ctx* ctx, const void* src_dev, void* dst_dev, size_t
  * np.mod(.,2), bin_matrix.py:34, css_code.py:39-40).  Strides are in elements. */
 int gf2_pack_rows_u8(const uint8_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld);
 int gf2_pack_rows_i64(const int64_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld);
+/* The same with CSSCode's input test (css_code.py:39-44, "parity check matrix must be binary") made on the way: *other_out = 1
+ * when some entry is neither 0 nor 1 (the packed rows are still entries & 1). */
+int gf2_pack_rows_binary_u8(const uint8_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld, int* other_out);
+int gf2_pack_rows_binary_i64(const int64_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld, int* other_out);
 int gf2_unpack_rows_u8(const uint64_t* src, int64_t m, int64_t n, int64_t ld, uint8_t* dst, int64_t dst_stride);
 int gf2_unpack_rows_i64(const uint64_t* src, int64_t m, int64_t n, int64_t ld, int64_t* dst, int64_t dst_stride);
 

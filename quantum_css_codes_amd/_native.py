@@ -66,6 +66,8 @@ SIGNATURES = {
     "gf2_membw_probe_dev": [_p, _p, _p, ctypes.c_size_t, _p],
     "gf2_pack_rows_u8": [_p, _c_i64, _c_i64, _c_i64, _p, _c_i64],
     "gf2_pack_rows_i64": [_p, _c_i64, _c_i64, _c_i64, _p, _c_i64],
+    "gf2_pack_rows_binary_u8": [_p, _c_i64, _c_i64, _c_i64, _p, _c_i64, ctypes.POINTER(ctypes.c_int)],
+    "gf2_pack_rows_binary_i64": [_p, _c_i64, _c_i64, _c_i64, _p, _c_i64, ctypes.POINTER(ctypes.c_int)],
     "gf2_unpack_rows_u8": [_p, _c_i64, _c_i64, _c_i64, _p, _c_i64],
     "gf2_unpack_rows_i64": [_p, _c_i64, _c_i64, _c_i64, _p, _c_i64],
     "gf2_rref": [_p, _p, _c_i64, _c_i64, _c_i64, _p, _p],
@@ -168,6 +170,23 @@ def pack_rows(mat, ld=None):
     padded = np.zeros((m, width * 64), dtype=np.uint8)
     padded[:, :n] = bits
     return np.ascontiguousarray(np.packbits(padded, axis=1, bitorder="little").view("<u8").reshape(m, width))
+
+
+def pack_rows_binary(mat):
+    """(packed rows, every entry is 0 or 1) -- the test of css_code.py:39-44 made while packing: for C-contiguous int64 / uint8
+    arrays one threaded pass in C; otherwise the reference's own expression."""
+    mat = np.asarray(mat)
+    if mat.ndim != 2:
+        raise ValueError("expected a 2-D array")
+    m, n = mat.shape
+    if m and n and mat.flags.c_contiguous and mat.dtype in (np.int64, np.uint8):
+        out = np.zeros((m, max(1, words_for(n))), dtype="<u8")
+        other = ctypes.c_int(0)
+        fn = lib().gf2_pack_rows_binary_i64 if mat.dtype == np.int64 else lib().gf2_pack_rows_binary_u8
+        check(fn(_ptr(mat), m, n, n, _ptr(out), out.shape[1], ctypes.byref(other)))
+        return out, other.value == 0
+    reduced = np.mod(np.array(mat, dtype='int'), 2)
+    return pack_rows(reduced), bool(np.array_equal(reduced, mat))
 
 
 def unpack_rows(words, n, dtype="int"):

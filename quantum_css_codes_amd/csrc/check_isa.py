@@ -15,7 +15,8 @@ so two things must hold in the generated code, and a compiler upgrade or an inno
      Checked by replaying every kernel's instructions in text order against a FIFO of outstanding operations: `vmcnt(N)`
      retires all but the youngest N; any other access to a register of an operation still in the FIFO is an error (see replay).
 
-Usage: check_isa.py <file.s> (the output of hipcc -S --cuda-device-only gf2_slabs.hip).  Exit code 1 on a violation.
+Usage: check_isa.py <file.s> (the output of hipcc -S --cuda-device-only gf2_slabs.hip), or check_isa.py --elim <gf2_elim.s> for the
+panel kernels of gf2_elim.hip (see check_elim).  Exit code 1 on a violation.
 """
 import re
 import sys
@@ -149,6 +150,37 @@ def check_counts(name, stream, spec, errors):
                 errors.add("%s line %d: %d row loads follow `%s`, a sub-pass refills exactly %d" % (name, no, n, w, rounds))
 
 
+def check_elim(path):
+    """gf2_elim.s: window_round writes a lane of two registers through `s_mov_b32 m0, ...; v_writelane_b32 ..., m0` in inline
+    assembly with m0 on the clobber list (this clang has no v_writelane builtin and warns that clobbering a reserved register "may
+    lead to undefined behaviour").  That is safe as long as the COMPILER never keeps anything in m0 in these kernels: checked here --
+    no instruction outside the inline-assembly blocks mentions m0 -- together with: no scratch (spill) traffic in the panel kernels
+    (rref_panel_kernel<8>, whose eight rows per lane do not fit 128 registers, is the one known exception and is reported)."""
+    errors, notes = set(), []
+    found = kernels_in(path)
+    seen = 0
+    for name, stream in found.items():
+        panel = any(k in name for k in ("rref_panel_kernel", "rref_panel_stream_kernel", "norm_panel_kernel"))
+        seen += 1 if panel else 0
+        outside = [(no, text) for no, text, in_asm in stream if not in_asm and re.search(r"\bm0\b", text)]
+        for no, text in outside:
+            errors.add("%s line %d: `%s` uses m0 outside the inline assembly that owns it" % (name, no, text))
+        spills = sum(1 for _, text, _ in stream if text.startswith("scratch_"))
+        if spills and panel:
+            if "rref_panel_kernelILi8E" in name:
+                notes.append("%s: %d scratch operations (eight rows per lane: known)" % (name, spills))
+            else:
+                errors.add("%s: %d scratch (spill) operations in a panel kernel" % (name, spills))
+    if seen < 6:
+        errors.add("only %d panel kernels were found in %s" % (seen, path))
+    for e in sorted(errors):
+        print("check_isa: " + e)
+    for n in notes:
+        print("check_isa: note: " + n)
+    print("check_isa: %d panel kernels, %d problems" % (seen, len(errors)))
+    return 1 if errors else 0
+
+
 def main(path):
     errors = set()
     found = kernels_in(path)
@@ -169,4 +201,6 @@ def main(path):
 
 
 if __name__ == "__main__":
+    if sys.argv[1] == "--elim":
+        sys.exit(check_elim(sys.argv[2]))
     sys.exit(main(sys.argv[1]))

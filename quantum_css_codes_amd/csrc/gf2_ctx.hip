@@ -313,6 +313,7 @@ int gf2_membw_probe_dev(gf2_ctx* ctx, const void* src_dev, void* dst_dev, size_t
 // than one core streams in the time the elimination itself takes; gf2_rref on it spent 6 of its 7 ms here on one thread).
 }   // extern "C"
 
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -342,11 +343,16 @@ static void host_rows_parallel(int64_t rows, int64_t bytes_per_row, F body) {
     for (auto& th : pool) th.join();
 }
 
+// `other_out` (may be null): set to 1 when some entry is not 0 or 1 -- css_code.py:39-44's "must be binary" test, made on the way
+// through the array instead of in three further passes over it.
 template <typename T>
-static int pack_rows_host(const T* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld) {
+static int pack_rows_host(const T* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld, int* other_out = nullptr) {
     if ((!src || !dst) && m > 0 && n > 0) GF2_FAIL(GF2_E_ARG, "pack: null buffer");
     if (m < 0 || n < 0 || ld < gf2_words(n) || src_stride < n) GF2_FAIL(GF2_E_ARG, "pack: bad shape");
+    std::atomic<int> other(0);
+    std::atomic<int>* const other_p = &other;
     host_rows_parallel(m, n * (int64_t)sizeof(T), [=](int64_t lo, int64_t hi) {
+        T seen = 0;
         for (int64_t i = lo; i < hi; ++i) {
             const T* row = src + i * src_stride;
             uint64_t* out = dst + i * ld;
@@ -354,11 +360,16 @@ static int pack_rows_host(const T* src, int64_t m, int64_t n, int64_t src_stride
                 uint64_t acc = 0;
                 const int64_t base = w * 64;
                 const int64_t lim = n - base < 64 ? n - base : 64;
-                for (int64_t b = 0; b < lim; ++b) acc |= (uint64_t)(row[base + b] & 1) << b;
+                for (int64_t b = 0; b < lim; ++b) {
+                    acc |= (uint64_t)(row[base + b] & 1) << b;
+                    seen |= row[base + b];
+                }
                 out[w] = acc;
             }
         }
+        if (seen & ~(T)1) other_p->store(1);
     });
+    if (other_out) *other_out = other.load();
     return GF2_OK;
 }
 
@@ -390,6 +401,16 @@ int gf2_pack_rows_u8(const uint8_t* src, int64_t m, int64_t n, int64_t src_strid
 
 int gf2_pack_rows_i64(const int64_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld) {
     return pack_rows_host<int64_t>(src, m, n, src_stride, dst, ld);
+}
+
+int gf2_pack_rows_binary_u8(const uint8_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld, int* other_out) {
+    if (!other_out) GF2_FAIL(GF2_E_ARG, "pack: null output");
+    return pack_rows_host<uint8_t>(src, m, n, src_stride, dst, ld, other_out);
+}
+
+int gf2_pack_rows_binary_i64(const int64_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld, int* other_out) {
+    if (!other_out) GF2_FAIL(GF2_E_ARG, "pack: null output");
+    return pack_rows_host<int64_t>(src, m, n, src_stride, dst, ld, other_out);
 }
 
 int gf2_unpack_rows_u8(const uint64_t* src, int64_t m, int64_t n, int64_t ld, uint8_t* dst, int64_t dst_stride) {

@@ -60,27 +60,31 @@ class CSSCode(QECC):
         if n_1 != n_2:
             raise ValueError("C_1 and C_2 must have the same code word length")
 
-        h_1 = np.mod(np.array(parity_check_c1, dtype='int'), 2)
-        h_2 = np.mod(np.array(parity_check_c2, dtype='int'), 2)
-        if not np.array_equal(h_1, parity_check_c1):
+        # css_code.py:39-44: entries must be 0 or 1 (tested while the rows are packed: one pass over each 64 MiB array at n = 4096
+        # instead of copy + np.mod + np.array_equal); from here to the end of the normalisations the matrices stay packed
+        p_1, binary = _native.pack_rows_binary(parity_check_c1)
+        if not binary:
             raise ValueError("C_1 parity check matrix must be binary")
-        if not np.array_equal(h_2, parity_check_c2):
+        p_2, binary = _native.pack_rows_binary(parity_check_c2)
+        if not binary:
             raise ValueError("C_2 parity check matrix must be binary")
 
         ctx = _native.default_context()
         # css_code.py:47-49 -- H1 . H2^T must vanish over GF(2)
-        product = ctx.matmul_abt(_native.pack_rows(h_1), r_1, _native.pack_rows(h_2), r_2, n_1)
+        product = ctx.matmul_abt(p_1, r_1, p_2, r_2, n_1)
         if np.any(product):
             raise ValueError("C_2 dual code must be a subspace of C_1")
 
         # css_code.py:51-61 -- standard forms H1 = [I A1 A2], H2 = [D I E]; each normalisation's qubit
         # swaps are applied to the other matrix as well.
-        h_1, qubit_swaps = normalize_parity_check(h_1, offset=0)
-        for indices in qubit_swaps:
-            swap_columns(h_2, indices)
-        h_2, qubit_swaps = normalize_parity_check(h_2, offset=r_1)
-        for indices in qubit_swaps:
-            swap_columns(h_1, indices)
+        for i, j in _normalize_packed(ctx, p_1, r_1, n_1, 0):
+            if r_2 and i != j:
+                ctx.swap_columns(p_2, r_2, n_1, i, j)
+        for i, j in _normalize_packed(ctx, p_2, r_2, n_1, r_1):
+            if r_1 and i != j:
+                ctx.swap_columns(p_1, r_1, n_1, i, j)
+        h_1 = _native.unpack_rows(p_1[:r_1], n_1, dtype='int')
+        h_2 = _native.unpack_rows(p_2[:r_2], n_1, dtype='int')
 
         self._n = n_1
         self._k = n_1 - r_1 - r_2
@@ -88,8 +92,8 @@ class CSSCode(QECC):
         self.r_2 = r_2
         self.parity_check_c1 = h_1
         self.parity_check_c2 = h_2
-        t_1, self._c1_syndromes = syndrome_table(h_1, max_weight=max_table_weight)
-        t_2, self._c2_syndromes = syndrome_table(h_2, max_weight=max_table_weight)
+        t_1, self._c1_syndromes = syndrome_table(h_1, max_weight=max_table_weight, _packed=p_1[:r_1])
+        t_2, self._c2_syndromes = syndrome_table(h_2, max_weight=max_table_weight, _packed=p_2[:r_2])
         self._t = min(t_1, t_2)
         self._transversal_gates = self._determine_transversal_gates(h_1, h_2)
         self._checks = None
@@ -312,7 +316,7 @@ def syndrome_batch(parity_check, errors):
     return _native.unpack_rows(out, r, dtype='int')
 
 
-def syndrome_table(parity_check, max_weight=None):
+def syndrome_table(parity_check, max_weight=None, _packed=None):
     """
     Given a parity check matrix of a binary linear code, determine the unique decoding threshold t and
     return it along with a lookup table from syndromes (as bin_matrix.vec_to_int keys) to error vectors
@@ -328,7 +332,7 @@ def syndrome_table(parity_check, max_weight=None):
     parity_check = np.asarray(parity_check)
     r, n = parity_check.shape
     ctx = _native.default_context()
-    packed_h = _native.pack_rows(parity_check)
+    packed_h = _native.pack_rows(parity_check) if _packed is None else np.ascontiguousarray(_packed)     # (the constructor has them)
     if 0 < n <= ctx.TABLE_MAX_N and r <= ctx.TABLE_MAX_R:
         # whole search on the device (gf2_syndrome_table): one kernel per weight class, first collision ends it
         t, dense = ctx.syndrome_table(packed_h, r, n, max_weight)
@@ -380,12 +384,17 @@ def syndrome_table(parity_check, max_weight=None):
             if count == 0:
                 break
             supports = np.array(batch, dtype=np.int64).reshape(count, w)
-            errors = np.zeros((count, n), dtype=np.uint8)
+            # the error vectors as the table hands them out (dtype 'int'; np.zeros maps untouched pages lazily) and, packed
+            # straight from the supports, as the syndrome kernel reads them
+            errors = np.zeros((count, n), dtype='int')
+            packed_e = np.zeros((count, max(1, _native.words_for(n))), dtype=np.uint64)
             if w:
-                errors[np.arange(count)[:, None], supports] = 1
+                rows = np.arange(count)[:, None]
+                errors[rows, supports] = 1
+                np.bitwise_or.at(packed_e, (np.broadcast_to(rows, supports.shape), supports >> 6),
+                                 np.uint64(1) << (supports & 63).astype(np.uint64))
             if r:
-                syn = _native.unpack_rows(_syndromes_of(ctx, chk, packed_h, r, n, _native.pack_rows(errors), count), r,
-                                          dtype=np.uint8)
+                syn = _native.unpack_rows(_syndromes_of(ctx, chk, packed_h, r, n, packed_e, count), r, dtype=np.uint8)
             else:
                 syn = np.zeros((count, 0), dtype=np.uint8)
             if weights is not None or r == 0:
@@ -407,8 +416,8 @@ def syndrome_table(parity_check, max_weight=None):
                 layer_seen_big |= fresh
                 layer_keys.extend(keys)
             layer_errs.append(errors)
-        errs = np.concatenate(layer_errs) if layer_errs else np.zeros((0, n), dtype=np.uint8)
-        table.update(zip(layer_keys, errs.astype('int')))
+        errs = (layer_errs[0] if len(layer_errs) == 1 else np.concatenate(layer_errs)) if layer_errs else np.zeros((0, n), dtype='int')
+        table.update(zip(layer_keys, errs))
         if weights is not None:
             seen = np.union1d(seen, layer_seen)
     return n, table
@@ -537,6 +546,22 @@ def pauli_term_for_row(x_check, z_check):
     return "*".join(factors) if factors else "I"
 
 
+def _normalize_packed(ctx, packed, r, n, offset):
+    """gf2_normalize on packed rows, in place; returns the swaps; the reference's two exceptions (css_code.py:811-812, 825-826)."""
+    if n < offset + r:
+        raise ValueError("not enough columns")
+    if r == 0:
+        return []
+    try:
+        return ctx.normalize(packed, r, n, offset)
+    except _native.GF2Error as err:
+        if err.code == _native.GF2_E_DEPENDENT:
+            raise InvalidCodeError("rows are not independent") from None
+        if err.code == _native.GF2_E_COLUMNS:
+            raise ValueError("not enough columns") from None
+        raise
+
+
 def normalize_parity_check(h, offset):
     """
     Put h into the form with an identity block in columns offset..offset+r-1 (css_code.py:809-836),
@@ -552,15 +577,11 @@ def normalize_parity_check(h, offset):
     if r == 0:
         return np.mod(h, 2), []
     packed = _native.pack_rows(h)
-    try:
-        swaps = _native.default_context().normalize(packed, r, n, offset)
-    except _native.GF2Error as err:
-        if err.code == _native.GF2_E_DEPENDENT:
-            raise InvalidCodeError("rows are not independent") from None
-        if err.code == _native.GF2_E_COLUMNS:
-            raise ValueError("not enough columns") from None
-        raise
-    _native.unpack_rows_into(packed, h)                       # h is reduced from here on, so np.mod(h, 2) is a plain copy
+    swaps = _normalize_packed(_native.default_context(), packed, r, n, offset)
+    _native.unpack_rows_into(packed, h)                       # h is reduced from here on: np.mod(h, 2) is the same matrix again,
+    # unpacked a second time (on several host threads: a 64 MiB h.copy() on one takes three times as long)
+    if isinstance(h, np.ndarray) and h.dtype in (np.int64, np.uint8):
+        return _native.unpack_rows(packed, n, dtype=h.dtype), swaps
     return h.copy(), swaps
 
 
