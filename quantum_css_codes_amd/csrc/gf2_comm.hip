@@ -6,8 +6,8 @@
 // bound: the xGMI links' bandwidth does not matter at this size, one ncclAllReduce on the context's stream does.
 //
 // librccl is loaded on first use (dlopen), so that the library itself does not depend on it: a process that never creates a
-// communicator never loads it, and a process that has imported torch gets the copy torch has loaded already (same soname, one
-// HIP runtime underneath).  Two ways in:
+// communicator never loads it.  The copy that is loaded is the one that sits beside the HIP runtime this library is bound to (see
+// rccl_load: a process that imported torch first runs on torch's pair, any other on ROCm's).  Two ways in:
 //   gf2_comm_create      one process per GPU (the bench's ranks): rank 0 makes an id (gf2_comm_unique_id), every rank receives it
 //                        out of band (the launcher's rendezvous store) and joins with its context;
 //   gf2_comm_create_all  one process, G contexts on G devices (ncclCommInitAll): no id to pass around.
@@ -38,11 +38,32 @@ RcclApi g_rccl = {};
 
 int rccl_load() {
     if (g_rccl.handle) return GF2_OK;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    // The RCCL that belongs to the HIP runtime THIS library runs on.  A process may hold two HIP runtimes -- ROCm's and the copy a
+    // PyTorch wheel ships next to its own librccl -- and which of them libgf2hip is bound to depends on what was loaded first; a
+    // communicator from the other runtime's RCCL cannot use this library's streams ("unhandled cuda error" from ncclCommInitAll).
+    // So: look beside the libamdhip64 that hipGetDeviceCount resolves to, by full path, before the plain names.
     void* h = nullptr;
-    for (const char* name : names) {
-        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (h) break;
+    Dl_info info;
+    if (dladdr((void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+        const char* slash = strrchr(info.dli_fname, '/');
+        if (slash) {
+            const size_t dir_len = (size_t)(slash - info.dli_fname) + 1;
+            for (const char* leaf : {"librccl.so.1", "librccl.so"}) {
+                char path[4096];
+                if (dir_len + strlen(leaf) + 1 > sizeof(path)) continue;
+                memcpy(path, info.dli_fname, dir_len);
+                strcpy(path + dir_len, leaf);
+                h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+                if (h) break;
+            }
+        }
+    }
+    if (!h) {
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* name : names) {
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+        }
     }
     if (!h) GF2_FAIL(GF2_E_RCCL, "librccl.so.1 cannot be loaded: %s", dlerror());
     RcclApi api = {};
