@@ -238,16 +238,24 @@ def timed(ctx, path, steps, warmup):
     return gpu_ms, syn_ms / 1e3 / max(1, syn_n), syn_n, hist_ms
 
 
+def pmc_traffic(kernel):
+    """(HBM-side bytes per 2^20-sample call of one component, where they come from): the committed rocprofv3 --pmc passes
+    (profiles/traffic.json names the script and the commit they were taken at); not measured by this run."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, None
+    tj = json.load(open(tpath))
+    return tj.get(kernel + "_bytes_per_launch"), "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, at " \
+        "commit %s (profiles/r03_evidence.sh)" % tj.get("captured_at_commit", "?")
+
+
 def roofline(path, mean_launch_s, launches):
     alg_bytes = path.batch * path.alg_bytes_per_sample
     achieved = alg_bytes / mean_launch_s / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and path.batch % (1 << 20) == 0:     # PMC bytes of a 2^20-sample call (profiles/traffic.json)
-        per = json.load(open(tpath)).get(path.kernel + "_bytes_per_launch")
-        traffic = per * (path.batch >> 20) if per else None
+    per, source = pmc_traffic(path.kernel)
+    traffic = per * (path.batch >> 20) if per and path.batch % (1 << 20) == 0 else None
     return {"bound": "hbm", "kernel": path.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source, "algorithmic_bytes_per_launch": alg_bytes,
             "mean_launch_ms": mean_launch_s * 1e3, "launches": launches}
 
 
@@ -257,13 +265,11 @@ def roofline_of_steps(path, gpu_s, steps, per_call_s, calls):
     step = both components; the per-call durations on each stream (overlapped, hence longer than alone) are kept beside it."""
     alg_bytes = 2 * path.batch * path.alg_bytes_per_sample
     achieved = alg_bytes / (gpu_s / steps) / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and path.batch % (1 << 20) == 0:     # PMC bytes of a 2^20-sample call (profiles/traffic.json)
-        one = json.load(open(tpath)).get(path.kernel + "_bytes_per_launch")
-        traffic = 2 * one * (path.batch >> 20) if one else None
+    one, source = pmc_traffic(path.kernel)
+    traffic = 2 * one * (path.batch >> 20) if one and path.batch % (1 << 20) == 0 else None
     return {"bound": "hbm", "kernel": path.kernel + " x2: H1.e_z and H2.e_x on two HIP streams, one launch = one step",
             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": source,
             "algorithmic_bytes_per_launch": alg_bytes, "mean_launch_ms": gpu_s / steps * 1e3, "launches": steps,
             "mean_call_ms_on_its_stream": per_call_s * 1e3, "calls": calls}
 
