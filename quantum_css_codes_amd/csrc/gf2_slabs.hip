@@ -1098,8 +1098,8 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         }
     };
 
-    u32x4 R0, R1, R2, R3, I0, I1;
-    unsigned int E0 = 0, E1 = 0;
+    u32x4 R0, R1, R2, R3, I0, I1, I2, I3;
+    unsigned int E0 = 0, E1 = 0, E2 = 0, E3 = 0;
     // ticket t = step t / 16 of the fixed split's wavefront t mod 16: group share * 16 + t mod 16 + (t / 16) * stride
 #ifdef GAT_EXP_NOTAKE
     unsigned int fixed_t = (unsigned int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1131,15 +1131,20 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(R0), "+v"(R1), "+v"(R2), "+v"(R3)::"memory");
     issue_ident(I0, E0, rec_pos(G0), record_header(R0));
     issue_ident(I1, E1, rec_pos(G1), record_header(R1));
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(I0), "+v"(I1), "+v"(E0), "+v"(E1)::"memory");
+    issue_ident(I2, E2, rec_pos(G2), record_header(R2));
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(I0), "+v"(I1), "+v"(I2), "+v"(E0), "+v"(E1), "+v"(E2)::"memory");
 
-    // One step: R, I, E = record and identity words of this step (requested four and two steps ago), Rp2 = record of the
-    // step after next.  Requests younger than the ones needed here: last step's store, record and identity loads.
-    auto step = [&](u32x4& R, u32x4& I, unsigned int& E, u32x4& Rp2, unsigned int& G, unsigned int Gp2) {
-        if (EXTRA)
-            asm volatile("s_waitcnt vmcnt(4)" : "+v"(R), "+v"(I), "+v"(E), "+v"(Rp2)::"memory");
-        else
-            asm volatile("s_waitcnt vmcnt(3)" : "+v"(R), "+v"(I), "+v"(E), "+v"(Rp2)::"memory");
+    // One step: R, I, E = record and identity words of this step -- the record was requested four steps ago, the identity words
+    // THREE (round 2: two; a memory round trip under load is about as long as a step, and with one step of lead the wavefront
+    // sat in its wait: with the identity loads served from L2 the kernel ran 10 % faster, profiles/r03_gather_what_if.log).
+    // Their address needs the header of the record of step i + 3, requested one step ago, so the step's ONE counted wait sits
+    // at its end, between the request for the record of step i + 4 and the request for the identity words of step i + 3: all
+    // but the last three operations (the identity words of step i + 2, this step's store, the record just requested) are
+    // complete behind it -- record i + 3, and everything the next step reads.
+    // (Rn, In, En: the next step's registers, valid behind the wait like Rp3 -- and only those are named in it: a register
+    // whose load is still in flight must not appear as an operand, or the compiler may touch it.)
+    auto step = [&](u32x4& R, u32x4& I, unsigned int& E, u32x4& Rn, u32x4& In, unsigned int& En, u32x4& Rp3, u32x4& Ip3,
+                    unsigned int& Ep3, unsigned int& G, unsigned int Gp3) {
         const unsigned int pos = rec_pos(G);
         const unsigned int slot0 = record_header(R);                // count, tile-local sample, flags
         // finished by the compact kernel: REC_OVER sorts first (count 0); a REC_DONE record sits where its count put it, at
@@ -1207,17 +1212,21 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         asm volatile("" ::: "memory");
         G = take();
         issue_record(R, G);
-        issue_ident(I, E, rec_pos(Gp2), record_header(Rp2));
+        if (EXTRA)
+            asm volatile("s_waitcnt vmcnt(4)" : "+v"(Rn), "+v"(In), "+v"(En), "+v"(Rp3)::"memory");
+        else
+            asm volatile("s_waitcnt vmcnt(3)" : "+v"(Rn), "+v"(In), "+v"(En), "+v"(Rp3)::"memory");
+        issue_ident(Ip3, Ep3, rec_pos(Gp3), record_header(Rp3));
     };
 #pragma unroll 1
     while (G0 < ngroups) {                                          // a wavefront's tickets ascend
-        step(R0, I0, E0, R2, G0, G2);
+        step(R0, I0, E0, R1, I1, E1, R3, I3, E3, G0, G3);
         if (G1 >= ngroups) break;
-        step(R1, I1, E1, R3, G1, G3);
+        step(R1, I1, E1, R2, I2, E2, R0, I0, E0, G1, G0);
         if (G2 >= ngroups) break;
-        step(R2, I0, E0, R0, G2, G0);
+        step(R2, I2, E2, R3, I3, E3, R1, I1, E1, G2, G1);
         if (G3 >= ngroups) break;
-        step(R3, I1, E1, R1, G3, G1);
+        step(R3, I3, E3, R0, I0, E0, R2, I2, E2, G3, G2);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (a.clk && lane == 0) atomicMax(&a.clk[3], (u64)wall_clock64());
