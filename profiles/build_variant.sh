@@ -8,6 +8,9 @@ work=/tmp/variant_$name
 rm -rf $work && mkdir -p $work/quantum_css_codes_amd $work/include
 cp -r $root/quantum_css_codes_amd/csrc $work/quantum_css_codes_amd/ && rm -rf $work/quantum_css_codes_amd/csrc/build
 cp $root/include/gf2hip.h $work/include/
-if [ "$rev" != "-" ]; then git -C $root show $rev:quantum_css_codes_amd/csrc/gf2_slabs.hip > $work/quantum_css_codes_amd/csrc/gf2_slabs.hip; fi
+if [ "$rev" != "-" ]; then      # (check_isa.py knows the kernels by name: it goes with the source it checks)
+  git -C $root show $rev:quantum_css_codes_amd/csrc/gf2_slabs.hip > $work/quantum_css_codes_amd/csrc/gf2_slabs.hip
+  git -C $root show $rev:quantum_css_codes_amd/csrc/check_isa.py > $work/quantum_css_codes_amd/csrc/check_isa.py
+fi
 make -C $work/quantum_css_codes_amd/csrc ROOT=$work FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=default -I$work/include -Wall -Wno-unused-function $*" 2>&1 | grep -E "rror|check_isa:" || true
 mkdir -p $root/scratch_ab && cp $work/quantum_css_codes_amd/libgf2hip.so $root/scratch_ab/$name.so && ls -la $root/scratch_ab/$name.so

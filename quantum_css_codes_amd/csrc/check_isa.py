@@ -2,7 +2,7 @@
 """
 Build-time guard for the hand-scheduled kernels of gf2_slabs.hip (run by `make`, see Makefile: build/slabs_isa.ok).
 
-slab_compact_kernel<T> and slab_gather_fast_kernel<EXTRA> issue their loads through inline assembly and wait with hand-counted
+slab_compact_kernel<T> and slab_gather_fast_kernel<EXTRA, CROSS> issue their loads through inline assembly and wait with hand-counted
 `s_waitcnt vmcnt(N)`.  The compiler neither sees those loads nor knows that their destination registers are still being filled,
 so two things must hold in the generated code, and a compiler upgrade or an innocent edit can break either:
 
@@ -22,12 +22,15 @@ import re
 import sys
 
 KERNELS = {
-    "slab_gather_fast_kernelILb0E": {"step_vmem": 3, "wait": 3},
-    "slab_gather_fast_kernelILb1E": {"step_vmem": 4, "wait": 4},
-    "slab_compact_kernelILi4E": {"rounds": 4},
-    "slab_compact_kernelILi5E": {"rounds": 5},
-    "slab_compact_kernelILi6E": {"rounds": 6},
-    "slab_compact_kernelILi8E": {"rounds": 8},
+    "slab_gather_fast_kernelILb0ELb0E": {"step_vmem": 3, "wait": 3},
+    "slab_gather_fast_kernelILb0ELb1E": {"step_vmem": 3, "wait": 3},
+    "slab_gather_fast_kernelILb1ELb0E": {"step_vmem": 4, "wait": 4},
+    "slab_gather_fast_kernelILb1ELb1E": {"step_vmem": 4, "wait": 4},
+    "slab_compact_kernelILi4ELb0E": {"rounds": 4},
+    "slab_compact_kernelILi4ELb1E": {"rounds": 4},
+    "slab_compact_kernelILi5ELb0E": {"rounds": 5},
+    "slab_compact_kernelILi6ELb0E": {"rounds": 6},
+    "slab_compact_kernelILi8ELb0E": {"rounds": 8},
 }
 VMEM = re.compile(r"^(global|buffer|scratch|flat)_(load|store|atomic)")
 REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")

@@ -221,7 +221,9 @@ __device__ __forceinline__ void wait_pairs(u64 (&w)[T]) {
     for (int t = 0; t < T; ++t) asm volatile("" : "+v"(w[t]));
 }
 
-template <int T>
+// FULL: every (sample, word) pair of a sub-pass is live and every scanned word consists of non-identity columns only (H = [I | A]
+// and [A' | I | c] at n = 4096): no mask is applied (and none kept in registers).
+template <int T, bool FULL>
 __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void slab_compact_kernel(CompactArgs a) {
     __shared__ CompactWaveLds lds_all[CMP_WAVES];
     __shared__ unsigned int wlist[64];
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void sl
         u64 w[T];
         if (s0 + (sub + 1) * CMP_SUB <= a.batch) {                  // uniform
 #pragma unroll
-            for (int t = 0; t < T; ++t) w[t] = wbuf[t] & pm.mask[t];
+            for (int t = 0; t < T; ++t) w[t] = FULL ? wbuf[t] : wbuf[t] & pm.mask[t];
         } else {
 #pragma unroll
             for (int t = 0; t < T; ++t) w[t] = s0 + sub * CMP_SUB + (pm.jw[t] >> 6) < a.batch ? wbuf[t] & pm.mask[t] : 0ull;
@@ -972,7 +974,9 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
 // (vector memory operations complete in order, so "all but the last N").
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-template <bool EXTRA>                              // EXTRA: ident_off is not a multiple of 32, a fifth dword per row part
+// EXTRA: ident_off is not a multiple of 32, a fifth dword per row part; CROSS: GatherArgs::cross (a template parameter: the
+// step's address arithmetic is scalar code on its critical path)
+template <bool EXTRA, bool CROSS>
 __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(GatherArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];            // the only LDS: the table starts at LDS address 0
     const int lane = threadIdx.x & 63;
@@ -1053,7 +1057,7 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
     // ones for k < 8.  Measured (profiles/r03_*): the lookups it saves are paid back by its four short runs of records and
     // partial weights per step -- 2 % slower on one stream, equal on two -- so it is off by default.
     const unsigned int ntiles = (unsigned int)((a.batch + 63) >> 6);
-    const unsigned int ngroups = a.cross ? ((ntiles + 3u) >> 2) << 4 : ntiles << 2;
+    const unsigned int ngroups = CROSS ? ((ntiles + 3u) >> 2) << 4 : ntiles << 2;
     const unsigned int stride = (unsigned int)shares * GAT_WAVES;
     const unsigned int lane_rec = lane >> 2;
     const unsigned int part16 = (unsigned int)part * 16u;
@@ -1062,15 +1066,15 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
     // reverse: group g stands for group ngroups - 1 - g (groups past the end stay past the end: their records read as zeros)
     const unsigned int last_group = a.reverse ? ngroups - 1u : 0u;
     // the record quarter of this lane in its group: 32-byte records in the lower half of a tile, 64-byte ones above
-    const unsigned int lane_tile = a.cross ? (lane_rec >> 2) : 0u, lane_sub = a.cross ? (lane_rec & 3u) : lane_rec;
+    const unsigned int lane_tile = CROSS ? (lane_rec >> 2) : 0u, lane_sub = CROSS ? (lane_rec & 3u) : lane_rec;
     const unsigned int short_lane = lane_tile * TILE_REC_BYTES + lane_sub * 32u + ((unsigned int)part & 1u) * 16u;
     const unsigned int long_lane = lane_tile * TILE_REC_BYTES + lane_sub * 64u + part16;
-    const unsigned int pos_lane = a.cross ? lane_tile * 64u + lane_sub : lane_rec;
+    const unsigned int pos_lane = CROSS ? lane_tile * 64u + lane_sub : lane_rec;
     auto the_group = [&](unsigned int g) { return a.reverse && g < ngroups ? last_group - g : g; };
     auto issue_record = [&](u32x4& R, unsigned int g) {
         const unsigned int group = the_group(g);
         unsigned int off;
-        if (a.cross) {
+        if (CROSS) {
             const unsigned int k = group & 15u;
             off = (group >> 4) * (4u * TILE_REC_BYTES) + (k < 8 ? k * 128u + short_lane : 1024u + (k - 8u) * 256u + long_lane);
 #ifdef GAT_EXP_NOREC
@@ -1109,19 +1113,26 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         return (unsigned int)share * GAT_WAVES + (t & (GAT_WAVES - 1)) + (t / GAT_WAVES) * stride;
     };
 #else
+    // Tickets are taken FOUR at a time (one LDS atomic and its round trip per four steps instead of one per step; round 3): a
+    // wavefront's four steps are then the four quartile groups of one tile, short records and long.
+    unsigned int ticket_base = 0, ticket_used = 4;
     auto take = [&]() {
-        unsigned int t = 0;
-        if (lane == 0) t = atomicAdd(next_step, 1u);
-        t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+        if (ticket_used == 4) {                                     // uniform
+            unsigned int t = 0;
+            if (lane == 0) t = atomicAdd(next_step, 4u);
+            ticket_base = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+            ticket_used = 0;
+        }
+        const unsigned int t = ticket_base + ticket_used++;
         return (unsigned int)share * GAT_WAVES + (t & (GAT_WAVES - 1)) + (t / GAT_WAVES) * stride;
     };
 #endif
     // position of this lane's record (tile * 64 + rank in the sorted tile)
     auto rec_pos = [&](unsigned int g) {
         const unsigned int group = the_group(g);
-        return (a.cross ? ((group >> 4) << 8) + ((group & 15u) << 2) : group << 4) + pos_lane;
+        return (CROSS ? ((group >> 4) << 8) + ((group & 15u) << 2) : group << 4) + pos_lane;
     };
-    auto short_records = [&](unsigned int g) { return a.cross ? (the_group(g) & 15u) < 8u : (the_group(g) & 3u) < 2u; };
+    auto short_records = [&](unsigned int g) { return CROSS ? (the_group(g) & 15u) < 8u : (the_group(g) & 3u) < 2u; };
     const unsigned int nullpair = null_ent | (null_ent << 16);
     unsigned int G0 = take(), G1 = take(), G2 = take(), G3 = take();
     issue_record(R0, G0);
@@ -1365,9 +1376,13 @@ static int slab_lds_optin(gf2_ctx* ctx) {
     if (!ctx->lds_optin[2]) {
         GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
-        GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_fast_kernel<false>),
+        GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_fast_kernel<false, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
-        GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_fast_kernel<true>),
+        GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_fast_kernel<true, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
+        GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_fast_kernel<false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
+        GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_fast_kernel<true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
         ctx->lds_optin[2] = true;
     }
@@ -1402,10 +1417,15 @@ static int launch_gather(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u
     if (shares > max_shares) shares = max_shares;
     if (shares < 1) shares = 1;
     const dim3 ggrid((unsigned)(shares * ck->nslabs512));
-    if (fast && (ck->ident_off & 31) != 0)
-        hipLaunchKernelGGL(slab_gather_fast_kernel<true>, ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+    const bool extra = (ck->ident_off & 31) != 0;
+    if (fast && extra && ga.cross)
+        hipLaunchKernelGGL((slab_gather_fast_kernel<true, true>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+    else if (fast && extra)
+        hipLaunchKernelGGL((slab_gather_fast_kernel<true, false>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+    else if (fast && ga.cross)
+        hipLaunchKernelGGL((slab_gather_fast_kernel<false, true>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
     else if (fast)
-        hipLaunchKernelGGL(slab_gather_fast_kernel<false>, ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+        hipLaunchKernelGGL((slab_gather_fast_kernel<false, false>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
     else
         hipLaunchKernelGGL(slab_gather_kernel, ggrid, dim3(GAT_THREADS), lds_bytes, stream, ga);
     GF2_HIP(hipGetLastError());
@@ -1517,14 +1537,24 @@ static int launch_compact(gf2_ctx* ctx, const SlabCall& c, int64_t first, hipStr
     const int per_cu = rounds <= 4 ? 5 : (rounds <= 5 ? 4 : 3);
     if (cblocks > (int64_t)ctx->num_cus * per_cu) cblocks = (int64_t)ctx->num_cus * per_cu;
     const dim3 cgrid((unsigned)cblocks), cblock(CMP_THREADS);
-    if (rounds <= 4)
-        hipLaunchKernelGGL(slab_compact_kernel<4>, cgrid, cblock, 0, stream, ca);
+    // all pairs live and all scanned words whole: no masks (the benchmark's two checks)
+    bool full = CMP_SUB * non_identity_words(ck, c.stray.skip_words) == 64 * 4 && gf2_words(ck->n) * 64 == ck->n;
+    for (int64_t wd = 0; full && wd < gf2_words(ck->n); ++wd) {
+        const int64_t lo = wd * 64, hi = lo + 64;
+        const bool inside = ck->ident_off >= 0 && lo >= ck->ident_off && hi <= ck->ident_off + ck->r;
+        const bool outside = ck->ident_off < 0 || hi <= ck->ident_off || lo >= ck->ident_off + ck->r;
+        full = inside || outside || ((c.stray.skip_words >> wd) & 1ull);
+    }
+    if (rounds <= 4 && full)
+        hipLaunchKernelGGL((slab_compact_kernel<4, true>), cgrid, cblock, 0, stream, ca);
+    else if (rounds <= 4)
+        hipLaunchKernelGGL((slab_compact_kernel<4, false>), cgrid, cblock, 0, stream, ca);
     else if (rounds <= 5)
-        hipLaunchKernelGGL(slab_compact_kernel<5>, cgrid, cblock, 0, stream, ca);
+        hipLaunchKernelGGL((slab_compact_kernel<5, false>), cgrid, cblock, 0, stream, ca);
     else if (rounds <= 6)
-        hipLaunchKernelGGL(slab_compact_kernel<6>, cgrid, cblock, 0, stream, ca);
+        hipLaunchKernelGGL((slab_compact_kernel<6, false>), cgrid, cblock, 0, stream, ca);
     else
-        hipLaunchKernelGGL(slab_compact_kernel<8>, cgrid, cblock, 0, stream, ca);
+        hipLaunchKernelGGL((slab_compact_kernel<8, false>), cgrid, cblock, 0, stream, ca);
     GF2_HIP(hipGetLastError());
     return GF2_OK;
 }
