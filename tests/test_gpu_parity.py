@@ -1511,13 +1511,17 @@ def test_bench_under_torchrun_two_ranks_share_the_gpu(tmp_path):
 def test_context_options_are_validated(ctx):
     for option, bad in ((_native.OPT_SLAB_PASS_LOG2, 11), (_native.OPT_SLAB_PASS_LOG2, 23), (_native.OPT_COMBINE_BLOCKS, 0),
                         (_native.OPT_MC_CHUNK_LOG2, 15), (_native.OPT_MC_CHUNK_LOG2, 23), (_native.OPT_COMBINE_THREADS, 96),
-                        (99, 1)):
+                        (_native.OPT_REDO_BLOCKS_PER_CU, 0), (_native.OPT_REDO_BLOCKS_PER_CU, 65), (_native.OPT_GATHER_REVERSE, 2),
+                        (_native.OPT_GATHER_CROSS, 2), (99, 1)):
         with pytest.raises(_native.GF2Error):
             ctx.set_option(option, bad)
     for option, good in ((_native.OPT_SLAB_PASS_LOG2, 20), (_native.OPT_MC_CHUNK_LOG2, 20), (_native.OPT_COMBINE_THREADS, 256),
-                         (_native.OPT_COMBINE_BLOCKS, 64)):
+                         (_native.OPT_COMBINE_BLOCKS, 64), (_native.OPT_REDO_BLOCKS_PER_CU, 16), (_native.OPT_GATHER_REVERSE, 0),
+                         (_native.OPT_GATHER_CROSS, 1)):
         ctx.set_option(option, good)
         ctx.set_option(option, None)                                        # back to the default
+    with pytest.raises(_native.GF2Error):
+        ctx.set_flags(1 << 30)                                              # not a defined flag
     before = ctx.get_flags()
     with ctx.flags(_native.F_MC_ROWS | _native.F_COMBINE_FOLDED):
         assert ctx.get_flags() == before | _native.F_MC_ROWS | _native.F_COMBINE_FOLDED
