@@ -92,7 +92,7 @@ int gf2_ctx_sync(gf2_ctx* ctx);
 int gf2_ctx_set_flags(gf2_ctx* ctx, uint32_t flags);
 int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
 /* Tunables of a context (value < 0 restores the default). */
-#define GF2_OPT_SLAB_PASS_LOG2  0   /* slab pipeline: 2^k samples per pass through the workspace, 12 <= k <= 22 (default 21) */
+#define GF2_OPT_SLAB_PASS_LOG2  0   /* slab pipeline: 2^k samples per pass through the workspace, 12 <= k <= 24 (default 22) */
 #define GF2_OPT_COMBINE_BLOCKS  1   /* slab pipeline: workgroups of the combine kernel (default 128 * 1024 / threads)        */
 #define GF2_OPT_GATHER_REVERSE   2   /* slab pipeline: 1 (default) = the gather kernel walks the records last tile first  */
 #define GF2_OPT_REDO_BLOCKS_PER_CU 3 /* slab pipeline: workgroups per CU of the redo kernel, 1..64 (default 8)                 */

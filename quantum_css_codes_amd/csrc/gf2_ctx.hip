@@ -162,8 +162,8 @@ int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out) {
 int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value) {
     if (!ctx || option < 0 || option >= GF2_OPT_COUNT) GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: bad argument");
     if (value >= 0) {
-        if (option == GF2_OPT_SLAB_PASS_LOG2 && (value < 12 || value > 22))
-            GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_SLAB_PASS_LOG2 must be in 12..22");
+        if (option == GF2_OPT_SLAB_PASS_LOG2 && (value < 12 || value > 24))
+            GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_SLAB_PASS_LOG2 must be in 12..24");
         if (option == GF2_OPT_MC_CHUNK_LOG2 && (value < 16 || value > 22))
             GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_MC_CHUNK_LOG2 must be in 16..22");
         if (option == GF2_OPT_COMBINE_THREADS && value != 64 && value != 128 && value != 256 && value != 512 && value != 1024)

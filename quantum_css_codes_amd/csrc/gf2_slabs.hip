@@ -41,8 +41,8 @@
 #define SLAB_ROWS 512
 #define SLAB_MAX_COLS 2400                    // (cols + 1) * 64 bytes of LDS <= 150 KiB
 #define SLAB_MAX_BINS 2304
-#define SLAB_MAX_BATCH (1 << 22)              // most samples per pass through the workspace (32-bit byte offsets of 512-byte rows)
-#define SLAB_DEFAULT_BATCH (1 << 21)
+#define SLAB_MAX_BATCH (1 << 24)              // most samples per pass through the workspace (record positions and buffer offsets are 32-bit)
+#define SLAB_DEFAULT_BATCH (1 << 22)              // (2^21 until round 3: 2^22 is 5 % faster on two streams, 2^23 and 2^24 no more: profiles/r03_sweep_pass.log)
 
 // Records of a tile of 64 samples, sorted by count: the 32 shortest as 32-byte records (15 columns + header), the 32 longest
 // as 64-byte records (31 columns + header) -- 3 KiB per tile instead of 4.  Seven samples in ten list at most 15 columns at the
@@ -203,12 +203,17 @@ __device__ __forceinline__ void load_pairs(const CompactArgs& a, int64_t s_first
         for (int t = 0; t < T; ++t)
             asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(w[t]) : "v"(pm.off[t]), "s"(base) : "memory");
     } else {
+        // rows past the batch are clamped into it (the caller masks); offsets from the sub-pass' first row (itself clamped), so
+        // that they stay small whatever the size of a pass (the lane offset is an unsigned 32-bit addend of the scalar base)
+        const int64_t last = a.batch - 1;
+        const int64_t first = s_first < last ? s_first : last;
+        const u64* base = a.e + first * a.lde;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            int64_t sample = s_first + (pm.jw[t] >> 6);
-            if (sample >= a.batch) sample = a.batch - 1;            // clamped into the batch; the caller masks
-            const unsigned int off = (unsigned int)sample * (unsigned int)a.lde * 8u + (pm.jw[t] & 63u) * 8u;
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(w[t]) : "v"(off), "s"(a.e) : "memory");
+            int64_t sample = s_first + (int64_t)(pm.jw[t] >> 6);
+            if (sample > last) sample = last;
+            const unsigned int off = (unsigned int)(sample - first) * (unsigned int)a.lde * 8u + (pm.jw[t] & 63u) * 8u;
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(w[t]) : "v"(off), "s"(base) : "memory");
         }
     }
 }

@@ -1509,7 +1509,7 @@ def test_bench_under_torchrun_two_ranks_share_the_gpu(tmp_path):
 
 
 def test_context_options_are_validated(ctx):
-    for option, bad in ((_native.OPT_SLAB_PASS_LOG2, 11), (_native.OPT_SLAB_PASS_LOG2, 23), (_native.OPT_COMBINE_BLOCKS, 0),
+    for option, bad in ((_native.OPT_SLAB_PASS_LOG2, 11), (_native.OPT_SLAB_PASS_LOG2, 25), (_native.OPT_COMBINE_BLOCKS, 0),
                         (_native.OPT_MC_CHUNK_LOG2, 15), (_native.OPT_MC_CHUNK_LOG2, 23), (_native.OPT_COMBINE_THREADS, 96),
                         (_native.OPT_REDO_BLOCKS_PER_CU, 0), (_native.OPT_REDO_BLOCKS_PER_CU, 65), (_native.OPT_GATHER_REVERSE, 2),
                         (_native.OPT_GATHER_CROSS, 2), (99, 1)):
