@@ -474,7 +474,12 @@ def main():
     ctx = _native.default_context()
     # the ranks' own RCCL communicator (its id travels over the process group's rendezvous); ranks that share a GPU
     # (--dist-backend gloo) cannot form one and sum on the host
-    comm = rccl_comm(ctx=ctx) if (world > 1 and args.dist_backend == "nccl" and args.allreduce == "gf2") else None
+    comm, comm_note = None, ""
+    if world > 1 and args.dist_backend == "nccl" and args.allreduce == "gf2":
+        try:
+            comm = rccl_comm(ctx=ctx)
+        except Exception as err:                       # every rank fails or none does (ncclCommInitRank is collective)
+            comm_note = " [gf2_comm_create failed: %s]" % str(err)[:120]
     code, h1, h2 = build_code()
     chk1, chk2 = ctx.check_create(h1, R1, N_QUBITS), ctx.check_create(h2, R2, N_QUBITS)
     batch = 1 << args.batch_log2
@@ -594,7 +599,7 @@ def main():
                        "streams": 2 if path.ctx2 is not None else 1,
                        "parallelism": "sample-range shards, 1 histogram all-reduce"
                                       + ("" if world == 1 else " (gf2_hist_allreduce over librccl)" if comm is not None else
-                                         " (torch.distributed, %s)" % args.dist_backend)},
+                                         " (torch.distributed, %s)%s" % (args.dist_backend, comm_note))},
             "roofline": roof,
             "checks": {"histogram_total": int(hist_z.sum()), "expected_total": int(total),
                        "oracle_prefix": "512 samples of this rank's batch through the timed path == oracle/gf2_oracle.c",
