@@ -153,3 +153,16 @@ def test_bench_refuses_a_world_size_that_contradicts_gpus():
     done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
                           stderr=subprocess.PIPE, timeout=120, text=True)
     assert done.returncode != 0 and "WORLD_SIZE=3" in done.stderr
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    # `python bench.py --gpus 2` without a launcher starts its two ranks itself; where they cannot run (no GPU in the CPU container: the
+    # first compute call raises) the launcher must come back with a non-zero code instead of waiting for the other rank
+    if _native.device_count() > 0:
+        pytest.skip("needs a box without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--steps", "1",
+                           "--warmup", "0", "--batch-log2", "15", "--no-cpu-baseline", "--no-secondary", "--no-settle"],
+                          cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+    assert done.returncode != 0
+    assert not [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
