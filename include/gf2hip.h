@@ -99,7 +99,8 @@ int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
 #define GF2_OPT_MC_CHUNK_LOG2   4   /* gf2_mc_run at n <= 4096, sparse rates: 2^k samples per chunk, 16 <= k <= 22 (default 22; 21 with GF2_F_MC_ROWS) */
 #define GF2_OPT_COMBINE_THREADS 5   /* slab pipeline: threads per workgroup of the combine kernel, 64 / 128 / 256 / 512 / 1024 (default 1024) */
 #define GF2_OPT_GATHER_CROSS    6   /* slab pipeline: 1 = a gather step takes ranks 4k..4k+3 of four sorted tiles, 0 (default) = a quartile of one */
-#define GF2_OPT_COUNT           7
+#define GF2_OPT_GATHER_OVER     7   /* slab pipeline: gather workgroups per CU over a launch, 1..8 (default 1)                            */
+#define GF2_OPT_COUNT           8
 int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value);
 
 /* Device memory and stream-ordered copies on the context's stream (copies are synchronous). */

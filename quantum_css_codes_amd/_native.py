@@ -24,7 +24,7 @@ K_SYNDROME, K_HIST, K_SAMPLER, K_ELIM = 0, 1, 2, 3
  F_RREF_SEQUENTIAL, F_RREF_NO_SMALL, F_NORMALIZE_SEQUENTIAL, F_SAMPLER_GENERIC, F_DIAG_CLOCKS,
  F_DIAG_MC_TIMES, F_MC_ROWS, F_COMBINE_FOLDED, F_RREF_NO_LOOKAHEAD, F_RREF_LOOKAHEAD) = (1 << k for k in range(18))
 (OPT_SLAB_PASS_LOG2, OPT_COMBINE_BLOCKS, OPT_GATHER_REVERSE, OPT_REDO_BLOCKS_PER_CU, OPT_MC_CHUNK_LOG2, OPT_COMBINE_THREADS,
- OPT_GATHER_CROSS) = range(7)
+ OPT_GATHER_CROSS, OPT_GATHER_OVER) = range(8)
 
 
 class GF2Error(RuntimeError):

@@ -1417,7 +1417,10 @@ static int launch_gather(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u
     ga.clk = clk_dev;
     ga.reverse = ctx->opt[GF2_OPT_GATHER_REVERSE] == 0 ? 0 : 1;
     ga.cross = ctx->opt[GF2_OPT_GATHER_CROSS] == 1 ? 1 : 0;
-    int64_t shares = ctx->num_cus / ck->nslabs512;
+    // GF2_OPT_GATHER_OVER workgroups per CU over the launch (default 1): more of them let a CU that is done early take another
+    // share, at the price of one more copy of the slab's table into LDS each
+    const int64_t over = ctx->opt[GF2_OPT_GATHER_OVER] > 0 ? ctx->opt[GF2_OPT_GATHER_OVER] : 1;
+    int64_t shares = ctx->num_cus / ck->nslabs512 * over;
     const int64_t max_shares = gf2_cdiv(gf2_cdiv(count, 16), GAT_WAVES);   // (a few steps more with `cross`: they read zeros)
     if (shares > max_shares) shares = max_shares;
     if (shares < 1) shares = 1;
