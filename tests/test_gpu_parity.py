@@ -797,6 +797,25 @@ def test_rref_streamed_panels_with_look_ahead(case, ctx, route):
     assert rank2 == want_rank and list(pivots2) == list(want_piv) and np.array_equal(plain, want)
 
 
+def test_rref_look_ahead_on_a_batch_of_two_tall_matrices(ctx, route):
+    # the look-ahead's state copies, coefficient sets and snapshots are per matrix: two different 8300-row matrices in one call
+    m, n, batch = 8300, 8200, 2
+    rng = np.random.default_rng(2)
+    mats = rng.integers(0, 2, (batch, m, n), dtype=np.uint8)
+    mats[1, :, 700:764] = 0                      # the second one has a panel without pivots where the first has 64
+    mats[1, 17] = mats[1, 3]
+    packed = np.stack([_native.pack_rows(mats[b]) for b in range(batch)])
+    want = [c_oracle.rref(packed[b].copy(), m, n) for b in range(batch)]
+    route.force("GF2_RREF_LOOKAHEAD")
+    got = packed.copy()
+    pivots, ranks = ctx.rref_batch(got, batch, m, n)
+    route.release("GF2_RREF_LOOKAHEAD")
+    for b in range(batch):
+        assert int(ranks[b]) == want[b][2]
+        assert list(pivots[b][:ranks[b]]) == list(want[b][1])
+        assert np.array_equal(got[b], want[b][0])
+
+
 def test_rref_256_mib_matrix_with_and_without_look_ahead(ctx, route):
     # bench.py's 32768 x 65536 matrix: too large for the CPU oracle, so the size-independent properties -- the run with look-ahead
     # (the default at this size) and the run without it return the same bytes, the rank is full, the pivot columns ascend, the
