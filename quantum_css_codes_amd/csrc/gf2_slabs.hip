@@ -24,6 +24,8 @@
 // records add 64 bytes written and 64 bytes read per slab and sample.  A lookup is 64 bytes wide per sample, so a
 // group of 16 lanes holds 4 samples on 4 sixteen-bank quarters: 2.1 LDS cycles per group on average with random
 // columns.
+#include <type_traits>
+
 #include "gf2_internal.h"
 #include "gf2_sparse_dev.h"
 #include "gf2_sampler.h"
@@ -564,52 +566,70 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
                 has_id[c] = lo[c] < nb && lo[c] + a.side[c].r > 0;
                 has_rec[c] = lo[c] > 0 || lo[c] + a.side[c].r < nb;
             }
-            // One erroneous qubit into the outputs, without a divergent branch: an identity column is a bit in the image (an LDS
-            // OR of zero otherwise), any other column a 16-bit slot at the end of the lane's record (stored to the lane's sink
-            // otherwise).
-            auto emit = [&](bool on, unsigned int pos, unsigned int kind) {
-                unsigned int id_bit = 0;
+            // The segment's erroneous qubits, MASK = what the segment holds of the two checks as compile-time constants (bit 0 / 1:
+            // identity columns / other columns of component 0, bits 2 / 3: of component 1), so that the walk below has no uniform
+            // branches in it (round 3: a CSS code's segments are "records for one component, identity bits for the other").
+            auto walk = [&](auto mask_constant) {
+                constexpr int MASK = decltype(mask_constant)::value;
+                constexpr bool HID[2] = {(MASK & 1) != 0, (MASK & 4) != 0}, HREC[2] = {(MASK & 2) != 0, (MASK & 8) != 0};
+                // One erroneous qubit into the outputs, without a divergent branch: an identity column is a bit in the image (an
+                // LDS OR of zero otherwise), any other column a 16-bit slot at the end of the lane's record (stored to the lane's
+                // sink otherwise).
+                auto emit = [&](bool on, unsigned int pos, unsigned int kind) {
+                    unsigned int id_bit = 0;
 #pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const RecSide& sd = a.side[c];
-                    const bool mine = on && ((kind >> c) & 1u);
-                    const bool under = (unsigned int)((int)pos - lo[c]) < (unsigned int)sd.r;
-                    if (has_id[c]) {                                           // uniform
-                        if (mine && (!has_rec[c] || under)) id_bit = 1u << (pos & 31u);
+                    for (int c = 0; c < 2; ++c) {
+                        const RecSide& sd = a.side[c];
+                        const bool mine = on && ((kind >> c) & 1u);
+                        const bool under = (unsigned int)((int)pos - lo[c]) < (unsigned int)sd.r;
+                        if (HID[c]) {
+                            if (mine && (!HREC[c] || under)) id_bit = 1u << (pos & 31u);
+                        }
+                        if (HREC[c]) {
+                            const bool is_rec = mine && (!HID[c] || !under);
+                            cnt[c] += is_rec ? 1u : 0u;
+                            const unsigned int ord = (unsigned int)((int)pos + ((int)pos < lo[c] ? base : base - sd.r)) << 4;
+                            unsigned short* const at = (is_rec && cnt[c] < REC_SLOTS)
+                                                           ? reinterpret_cast<unsigned short*>(L.rec[c] + lane * 64 + (cnt[c] - 1u) * 2)
+                                                           : &L.sink[lane];
+                            *at = (unsigned short)ord;
+                        }
                     }
-                    if (has_rec[c]) {                                          // uniform
-                        const bool is_rec = mine && (!has_id[c] || !under);
-                        cnt[c] += is_rec ? 1u : 0u;
-                        const unsigned int ord = (unsigned int)((int)pos + ((int)pos < lo[c] ? base : base - sd.r)) << 4;
-                        unsigned short* const at = (is_rec && cnt[c] < REC_SLOTS)
-                                                       ? reinterpret_cast<unsigned short*>(L.rec[c] + lane * 64 + (cnt[c] - 1u) * 2)
-                                                       : &L.sink[lane];
-                        *at = (unsigned short)ord;
-                    }
+                    if (HID[0] || HID[1]) atomicOr(&L.img[lane * RS_STRIDE + (pos >> 5)], id_bit);
+                };
+                // two erroneous qubits per trip: their draws are independent chains of multiplies, and the second one's atomic is
+                // issued behind the first one's without waiting for it (the LDS serves a wavefront's operations in order)
+                for (int k = 0; __ballot(k < K) != 0; k += 2) {
+                    const bool on0 = k < K, on1 = k + 1 < K;
+                    unsigned int t0, kind0, t1, kind1;
+                    error_draw(d, k, K, nb, a.th.t_1, a.th.t_2, &t0, &kind0);
+                    error_draw(d, k + 1, K, nb, a.th.t_1, a.th.t_2, &t1, &kind1);
+                    if (!on0) t0 = 0;
+                    if (!on1) t1 = 0;
+                    const unsigned int old0 = atomicOr(&my_taken[t0 >> 5], on0 ? 1u << (t0 & 31u) : 0u);
+                    const unsigned int old1 = atomicOr(&my_taken[t1 >> 5], on1 ? 1u << (t1 & 31u) : 0u);
+                    const unsigned int j0 = (unsigned int)(nb - K + k) & 511u, j1 = (j0 + 1u) & 511u;
+                    // Floyd: a position taken already gives way to j (never taken before); the second qubit's candidate may be the
+                    // j the first one has just moved to
+                    const bool hit0 = on0 && ((old0 >> (t0 & 31u)) & 1u);
+                    const bool hit1 = on1 && (((old1 >> (t1 & 31u)) & 1u) || (hit0 && t1 == j0));
+                    const unsigned int pos0 = hit0 ? j0 : t0, pos1 = hit1 ? j1 : t1;
+                    atomicOr(&my_taken[j0 >> 5], hit0 ? 1u << (j0 & 31u) : 0u);
+                    atomicOr(&my_taken[j1 >> 5], hit1 ? 1u << (j1 & 31u) : 0u);
+                    emit(on0, pos0, kind0);
+                    emit(on1, pos1, kind1);
                 }
-                if (has_id[0] || has_id[1]) atomicOr(&L.img[lane * RS_STRIDE + (pos >> 5)], id_bit);
             };
-            // two erroneous qubits per trip: their draws are independent chains of multiplies, and the second one's atomic is
-            // issued behind the first one's without waiting for it (the LDS serves a wavefront's operations in order)
-            for (int k = 0; __ballot(k < K) != 0; k += 2) {
-                const bool on0 = k < K, on1 = k + 1 < K;
-                unsigned int t0, kind0, t1, kind1;
-                error_draw(d, k, K, nb, a.th.t_1, a.th.t_2, &t0, &kind0);
-                error_draw(d, k + 1, K, nb, a.th.t_1, a.th.t_2, &t1, &kind1);
-                if (!on0) t0 = 0;
-                if (!on1) t1 = 0;
-                const unsigned int old0 = atomicOr(&my_taken[t0 >> 5], on0 ? 1u << (t0 & 31u) : 0u);
-                const unsigned int old1 = atomicOr(&my_taken[t1 >> 5], on1 ? 1u << (t1 & 31u) : 0u);
-                const unsigned int j0 = (unsigned int)(nb - K + k) & 511u, j1 = (j0 + 1u) & 511u;
-                // Floyd: a position taken already gives way to j (never taken before); the second qubit's candidate may be the
-                // j the first one has just moved to
-                const bool hit0 = on0 && ((old0 >> (t0 & 31u)) & 1u);
-                const bool hit1 = on1 && (((old1 >> (t1 & 31u)) & 1u) || (hit0 && t1 == j0));
-                const unsigned int pos0 = hit0 ? j0 : t0, pos1 = hit1 ? j1 : t1;
-                atomicOr(&my_taken[j0 >> 5], hit0 ? 1u << (j0 & 31u) : 0u);
-                atomicOr(&my_taken[j1 >> 5], hit1 ? 1u << (j1 & 31u) : 0u);
-                emit(on0, pos0, kind0);
-                emit(on1, pos1, kind1);
+            switch ((has_id[0] ? 1 : 0) | (has_rec[0] ? 2 : 0) | (has_id[1] ? 4 : 0) | (has_rec[1] ? 8 : 0)) {        // uniform
+                case 6: walk(std::integral_constant<int, 6>{}); break;       // records for component 0, identity bits for 1
+                case 9: walk(std::integral_constant<int, 9>{}); break;       // the other way round
+                case 10: walk(std::integral_constant<int, 10>{}); break;     // records for both
+                case 5: walk(std::integral_constant<int, 5>{}); break;       // identity bits for both
+                case 7: walk(std::integral_constant<int, 7>{}); break;
+                case 11: walk(std::integral_constant<int, 11>{}); break;
+                case 13: walk(std::integral_constant<int, 13>{}); break;
+                case 14: walk(std::integral_constant<int, 14>{}); break;
+                default: walk(std::integral_constant<int, 15>{}); break;
             }
             __builtin_amdgcn_wave_barrier();
             // the segment's identity words out: four lanes per sample, 16 bytes each, sixteen samples per store instruction
