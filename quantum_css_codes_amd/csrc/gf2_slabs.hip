@@ -599,11 +599,23 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
                 };
                 // two erroneous qubits per trip: their draws are independent chains of multiplies, and the second one's atomic is
                 // issued behind the first one's without waiting for it (the LDS serves a wavefront's operations in order)
-                for (int k = 0; __ballot(k < K) != 0; k += 2) {
+                // (error_draw of gf2_sampler.h with its argument d + G (k + 1) carried along -- two additions per trip instead of
+                // two 64-bit multiplies -- and the kind thresholds, which are 2^32 at most, compared as 32-bit numbers)
+                u64 x0 = d + GF2_GOLDEN, x1 = x0 + GF2_GOLDEN;
+                const unsigned int t1_lo = (unsigned int)a.th.t_1, t2_lo = (unsigned int)a.th.t_2;
+                const bool t1_top = (a.th.t_1 >> 32) != 0, t2_top = (a.th.t_2 >> 32) != 0;       // threshold = 2^32: every c is below it
+                auto draw = [&](u64 x, int k, unsigned int* t_out, unsigned int* kind) {
+                    const u64 v = mix64(x);
+                    const unsigned int j = (unsigned int)(nb - K + k);
+                    *t_out = __umulhi((unsigned int)(v >> 32), j + 1u);
+                    const unsigned int c = (unsigned int)v;
+                    *kind = ((t2_top || c < t2_lo) ? 1u : 0u) | ((!t1_top && c >= t1_lo) ? 2u : 0u);
+                };
+                for (int k = 0; __ballot(k < K) != 0; k += 2, x0 += 2 * GF2_GOLDEN, x1 += 2 * GF2_GOLDEN) {
                     const bool on0 = k < K, on1 = k + 1 < K;
                     unsigned int t0, kind0, t1, kind1;
-                    error_draw(d, k, K, nb, a.th.t_1, a.th.t_2, &t0, &kind0);
-                    error_draw(d, k + 1, K, nb, a.th.t_1, a.th.t_2, &t1, &kind1);
+                    draw(x0, k, &t0, &kind0);
+                    draw(x1, k + 1, &t1, &kind1);
                     if (!on0) t0 = 0;
                     if (!on1) t1 = 0;
                     const unsigned int old0 = atomicOr(&my_taken[t0 >> 5], on0 ? 1u << (t0 & 31u) : 0u);
