@@ -111,7 +111,7 @@ def cpu_baseline(code, seconds_target=20.0, sample=2048):
 class Path(object):
     """Resident buffers and the step function of one implementation of the hot path."""
 
-    def __init__(self, ctx, algo, chk1, chk2, batch, first, ctx2=None, stagger=0):
+    def __init__(self, ctx, algo, chk1, chk2, batch, first, ctx2=None):
         from quantum_css_codes_amd import _native
         self.ctx, self.algo, self.batch = ctx, algo, batch
         # second context = second HIP stream (own workspace): the sparse path issues H1.e_z on ctx and H2.e_x on ctx2, so
@@ -134,18 +134,9 @@ class Path(object):
             self.alg_bytes_per_sample = N_QUBITS / 8.0                   # SURVEY.md 8d read-only variant, per component
             side = self.ctx2 if self.ctx2 is not None else ctx
 
-            head = min(batch, stagger) if (stagger and self.ctx2 is not None and stagger < batch) else 0
-            ex_head = self.ex.view(0, head * lde * 8) if head else None
-            ex_rest = self.ex.view(head * lde * 8, (batch - head) * lde * 8) if head else None
-
             def step():
                 ctx.syndrome_sparse_dev(chk1, self.ez, batch, lde, None, 0, self.hz, R1 + 1)
-                if head:
-                    # --stagger: H2's step as a short call and the rest, so that its passes sit half a pass off H1's
-                    side.syndrome_sparse_dev(chk2, ex_head, head, lde, None, 0, self.hx, R2 + 1)
-                    side.syndrome_sparse_dev(chk2, ex_rest, batch - head, lde, None, 0, self.hx, R2 + 1)
-                else:
-                    side.syndrome_sparse_dev(chk2, self.ex, batch, lde, None, 0, self.hx, R2 + 1)
+                side.syndrome_sparse_dev(chk2, self.ex, batch, lde, None, 0, self.hx, R2 + 1)
 
             def prefix_hist(count):
                 a, b = ctx.alloc((R1 + 1) * 8).zero(), ctx.alloc((R2 + 1) * 8).zero()
@@ -454,9 +445,6 @@ def main():
     ap.add_argument("--ctx-flags", type=lambda v: int(v, 0), default=0, help="routing flags (GF2_F_*) of both contexts")
     ap.add_argument("--opt", action="append", default=[], metavar="K=V",
                     help="set a context tunable (GF2_OPT_* number = value), e.g. --opt 2=0")
-    ap.add_argument("--stagger-log2", type=int, default=0,
-                    help="experiment: the side stream's step starts with a short call of 2^k samples, so that its passes are offset "
-                         "against the main stream's (0 = off)")
     ap.add_argument("--one-stream", action="store_true",
                     help="issue both components of a step on one HIP stream (default: H2.e_x goes to a second context)")
     args = ap.parse_args()
@@ -506,7 +494,7 @@ def main():
         for kv in args.opt:
             if c is not None:
                 c.set_option(int(kv.split("=")[0]), int(kv.split("=")[1]))
-    path = Path(ctx, args.algo, chk1, chk2, batch, first, ctx2, stagger=(1 << args.stagger_log2) if args.stagger_log2 else 0)
+    path = Path(ctx, args.algo, chk1, chk2, batch, first, ctx2)
     if rank == 0:
         path.check_against_oracle(h1, h2, first)        # correctness of what is about to be timed
 
