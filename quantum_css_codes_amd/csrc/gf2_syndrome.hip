@@ -103,18 +103,21 @@ __device__ __forceinline__ unsigned int byte_and(unsigned int x, unsigned int ma
     return out;
 }
 
+__device__ __forceinline__ u64 xor3_u64(u64 a, u64 b, u64 c) {
+    const unsigned int lo = __builtin_amdgcn_bitop3_b32((unsigned int)a, (unsigned int)b, (unsigned int)c, 0x96);
+    const unsigned int hi = __builtin_amdgcn_bitop3_b32((unsigned int)(a >> 32), (unsigned int)(b >> 32), (unsigned int)(c >> 32), 0x96);
+    return ((u64)hi << 32) | lo;
+}
+
 // 8 table reads for the 8 nibbles of one dword; BASE = byte offset of the dword's first group.
 template <int BASE>
 __device__ __forceinline__ u64 lookup_dword(const unsigned int d, u64 a, unsigned int mask78) {
     const unsigned int lo = d << 3, hi = d >> 1;                // nibble*8 sits in bits 3..6 of each byte
-    a ^= lds_entry<BASE + 0 * 128>(byte_and<0>(lo, mask78));
-    a ^= lds_entry<BASE + 1 * 128>(byte_and<0>(hi, mask78));
-    a ^= lds_entry<BASE + 2 * 128>(byte_and<1>(lo, mask78));
-    a ^= lds_entry<BASE + 3 * 128>(byte_and<1>(hi, mask78));
-    a ^= lds_entry<BASE + 4 * 128>(byte_and<2>(lo, mask78));
-    a ^= lds_entry<BASE + 5 * 128>(byte_and<2>(hi, mask78));
-    a ^= lds_entry<BASE + 6 * 128>(byte_and<3>(lo, mask78));
-    a ^= lds_entry<BASE + 7 * 128>(byte_and<3>(hi, mask78));
+    // two entries per v_bitop3_b32 (0x96: three-way XOR) and half of the accumulator: one instead of two XORs per lookup
+    a = xor3_u64(a, lds_entry<BASE + 0 * 128>(byte_and<0>(lo, mask78)), lds_entry<BASE + 1 * 128>(byte_and<0>(hi, mask78)));
+    a = xor3_u64(a, lds_entry<BASE + 2 * 128>(byte_and<1>(lo, mask78)), lds_entry<BASE + 3 * 128>(byte_and<1>(hi, mask78)));
+    a = xor3_u64(a, lds_entry<BASE + 4 * 128>(byte_and<2>(lo, mask78)), lds_entry<BASE + 5 * 128>(byte_and<2>(hi, mask78)));
+    a = xor3_u64(a, lds_entry<BASE + 6 * 128>(byte_and<3>(lo, mask78)), lds_entry<BASE + 7 * 128>(byte_and<3>(hi, mask78)));
     return a;
 }
 
