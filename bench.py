@@ -422,6 +422,53 @@ def launch_ranks(gpus):
     return worst
 
 
+def guarded_comm(ctx, nbins, seconds=120.0):
+    """libgf2hip's communicator over all ranks, proven by one all-reduce, or (None, why): the N > 1 line must come out even on
+    a node where the library's librccl cannot set itself up beside torch's.  The id exchange runs here (a collective of the
+    process group); ncclCommInitRank and the first all-reduce run in a helper thread with a time limit, and the ranks then
+    agree (MIN over the process group) whether ALL of them got through -- otherwise all of them sum through
+    torch.distributed instead and a helper thread that is still stuck is left behind (it is a daemon thread)."""
+    import threading
+    import torch
+    import torch.distributed as dist
+    from quantum_css_codes_amd import _native
+    rank, world = dist.get_rank(), dist.get_world_size()
+    ident = [None]
+    if rank == 0:
+        try:
+            ident[0] = _native.Comm.unique_id()
+        except _native.GF2Error as err:                # librccl does not load: every rank hears of it
+            ident[0] = str(err)[:120]
+    dist.broadcast_object_list(ident, src=0)
+    if not isinstance(ident[0], bytes):
+        return None, " [gf2_comm_unique_id: %s]" % ident[0]
+    box = {}
+
+    def work():
+        try:
+            comm = _native.Comm(ctx, ident[0], world, rank)
+            probe = ctx.alloc(nbins * 8).upload(np.full(nbins, 1, dtype=np.uint64))
+            comm.allreduce(probe, nbins)
+            got = probe.download((nbins,), np.uint64)
+            probe.free()
+            if not (got == world).all():
+                raise RuntimeError("gf2_hist_allreduce: wrong sum")
+            box["comm"] = comm
+        except Exception as err:                       # noqa: BLE001 -- whatever it is, the fallback runs
+            box["why"] = str(err)[:120]
+
+    helper = threading.Thread(target=work, daemon=True)
+    helper.start()
+    helper.join(seconds)
+    mine = 1 if "comm" in box else 0
+    flag = torch.tensor([mine], dtype=torch.int32, device=torch.device("cuda", ctx.device))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return box["comm"], ""
+    why = box.get("why", "no answer within %.0f s" % seconds if not mine else "another rank failed")
+    return None, " [gf2_comm_create: %s]" % why
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -470,16 +517,13 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from quantum_css_codes_amd import _native
-    from quantum_css_codes_amd.montecarlo import all_reduce_histograms, rccl_comm
+    from quantum_css_codes_amd.montecarlo import all_reduce_histograms
     ctx = _native.default_context()
     # the ranks' own RCCL communicator (its id travels over the process group's rendezvous); ranks that share a GPU
     # (--dist-backend gloo) cannot form one and sum on the host
     comm, comm_note = None, ""
     if world > 1 and args.dist_backend == "nccl" and args.allreduce == "gf2":
-        try:
-            comm = rccl_comm(ctx=ctx)
-        except Exception as err:                       # every rank fails or none does (ncclCommInitRank is collective)
-            comm_note = " [gf2_comm_create failed: %s]" % str(err)[:120]
+        comm, comm_note = guarded_comm(ctx, R1 + 1 + R2 + 1)
     code, h1, h2 = build_code()
     chk1, chk2 = ctx.check_create(h1, R1, N_QUBITS), ctx.check_create(h2, R2, N_QUBITS)
     batch = 1 << args.batch_log2

@@ -95,6 +95,20 @@ big = np.arange(4097, dtype=np.uint64) * np.uint64(1 << 40)            # 32 KiB,
 assert np.array_equal(montecarlo.all_reduce_histograms([big])[0], big)
 assert np.array_equal(montecarlo.all_reduce_histograms([big], comm=comm)[0], big)
 comm.close()
+# bench.py's way in: the communicator proven by one all-reduce under a time limit, the ranks agreeing on the outcome; and
+# its way out when the library's communicator cannot be had
+import bench
+ctx = _native.default_context()
+comm, note = bench.guarded_comm(ctx, 4097)
+assert comm is not None and note == "", note
+comm.close()
+class Broken(_native.Comm):
+    def __init__(self, *a):
+        raise _native.GF2Error(-7, "ncclCommInitRank refused")
+keep, _native.Comm = _native.Comm, Broken
+comm, note = bench.guarded_comm(ctx, 4097)
+_native.Comm = keep
+assert comm is None and "refused" in note, note
 dist.destroy_process_group()
 maps = open("/proc/self/maps").read()
 assert "librccl" in maps and "libgf2hip.so" in maps
