@@ -498,6 +498,32 @@ def test_monte_carlo_on_the_config4_code_itself(ctx, route):
         b.free()
 
 
+def test_monte_carlo_config4_at_full_size_shards_add_up(ctx):
+    # BASELINE.json configs[4] at its full size: 10^8 samples of the config-4 code, once as one run and once as the eight
+    # contiguous shards the 8-GPU job cuts them into (montecarlo.shard_range), summed as the all-reduce sums them.  Sample i is a
+    # function of (seed, i) alone, so the two must agree bin for bin; every sample lands in exactly one bin of each histogram;
+    # and the first 2^16 samples of shard 5 are the oracle's (the size-independent property + a prefix the oracle can afford).
+    import bench
+    from quantum_css_codes_amd import montecarlo
+    code, h1, h2 = bench.build_code()
+    c1, c2 = ctx.check_create(h1, bench.R1, bench.N_QUBITS), ctx.check_create(h2, bench.R2, bench.N_QUBITS)
+    total, first, p = 10**8, 7 * 10**11 + 3, bench.P_TOTAL / 3
+    whole = ctx.mc_run(c1, c2, bench.SEED, first, total, p, p, p, _native.HIST_WEIGHT)
+    assert int(whole[0].sum()) == total and int(whole[1].sum()) == total
+    sum_z, sum_x = np.zeros(bench.R1 + 1, np.uint64), np.zeros(bench.R2 + 1, np.uint64)
+    for rank in range(8):
+        shard_first, shard_count = montecarlo.shard_range(first, total, rank, 8)
+        hz, hx = ctx.mc_run(c1, c2, bench.SEED, shard_first, shard_count, p, p, p, _native.HIST_WEIGHT)
+        assert int(hz.sum()) == shard_count and int(hx.sum()) == shard_count
+        sum_z += hz
+        sum_x += hx
+    assert np.array_equal(sum_z, whole[0]) and np.array_equal(sum_x, whole[1])
+    shard_first, _ = montecarlo.shard_range(first, total, 5, 8)
+    got = ctx.mc_run(c1, c2, bench.SEED, shard_first, 1 << 16, p, p, p, _native.HIST_WEIGHT)
+    want = c_oracle.mc(h1, bench.R1, h2, bench.R2, bench.N_QUBITS, bench.SEED, shard_first, 1 << 16, p, p, p, 1)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+
+
 # ---- tiled device layout -----------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("shape", [(70, 1), (130, 64), (200, 65), (4096, 300), (4100, 130)])
