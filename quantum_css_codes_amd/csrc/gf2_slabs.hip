@@ -103,22 +103,20 @@ struct CompactArgs {
     unsigned int* redo_list;
 };
 
-// LDS per wavefront.  Non-zero (sample, word) pairs wait in a ring of 128 until 64 of them are there, so every pass over them
-// has all lanes busy; a pass writes the FIRST column of each word and moves words with more columns to the `left` list,
-// which is worked off when it fills up and at the end of the tile.  The 64 records of the tile are 64 contiguous bytes each
-// (slot k of sample j at 64 j + 2 k); a column beyond slot 30 is written to the record's own slot 31, the header's place,
-// which is filled in last.
-#define CMP_RING 128
-#define CMP_LEFT 128
+// LDS per wavefront.  Non-zero (sample, word) pairs wait in a ring until 64 of them are there, so every pass over them has all
+// lanes busy; a pass writes the FIRST column of each word and puts words with more columns back at the ring's tail, with the
+// slot their next column goes to (round 3; before, they went on a list of their own that was worked off by a second routine
+// with a loop over the bits of each lane's word).  The 64 records of the tile are 64 contiguous bytes each (slot k of sample j
+// at 64 j + 2 k); a column beyond slot 30 is written to the record's own slot 31, the header's place, which is filled in last.
+#define CMP_RING 256
+#define CMP_CONT 0x40000u                 // ring_m: the word has been here before, bits 12..17 = the slot of its next column
 struct alignas(16) CompactWaveLds {
-    u64 ring_v[CMP_RING];                 // word
-    unsigned short ring_m[CMP_RING];      // tile-local sample << 6 | word index
-    u64 left_v[CMP_LEFT];                 // columns still to write
-    unsigned int left_m[CMP_LEFT];        // next slot (<= 32) | sample << 6 | column base << 16 (16 bits, see ord16)
+    u64 ring_v[CMP_RING];                 // word (the columns still to write)
+    unsigned int ring_m[CMP_RING];        // word index | tile-local sample << 6 | next slot << 12 | CMP_CONT
     unsigned char rec[4096 + 16];
     unsigned int cnt[64];
 };
-static_assert(CMP_RING * 10 + CMP_LEFT * 12 >= (SPARSE_LIST_CAP + 8) * 4, "the slow routine's list reuses the ring and left regions");
+static_assert(CMP_RING * 12 >= (SPARSE_LIST_CAP + 8) * 4, "the slow routine's list reuses the ring");
 
 // The combine step for the positions this workgroup takes (every 4 * blockDim * gridDim): adds the (up to four) slabs' partial
 // weights of a record position and counts the total in `bins` (LDS, nbins counters, zeroed here), which it then adds to the
@@ -288,29 +286,9 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void sl
         const unsigned int col = (cb >> 4) + bit;
         return ((int)col >= a.ident_off ? col - (unsigned int)a.r : col) << 4;
     };
-    unsigned int lc = 0;                                                // entries of the left list (uniform)
-    auto flush_left = [&]() {
-        wave_lds_sync();
-        for (unsigned int i0 = 0; i0 < lc; i0 += 64) {
-            const unsigned int i = i0 + lane;
-            if (i < lc) {
-                u64 v = L.left_v[i];
-                const unsigned int m = L.left_m[i];
-                unsigned char* const rj = L.rec + (m & 0xFC0u);
-                unsigned char* p = rj + (m & 63u) * 2;
-                const unsigned int cb = m >> 16;
-                while (v) {
-                    const unsigned int bit = (unsigned int)(__ffsll((long long)v) - 1);
-                    v &= v - 1;
-                    *reinterpret_cast<unsigned short*>(p < rj + 62 ? p : rj + 62) = (unsigned short)ord16(cb, bit);
-                    p += 2;
-                }
-            }
-        }
-        lc = 0;
-        wave_lds_sync();
-    };
-    // One pass over `count` <= 64 ring entries starting at `first`: slots are reserved per word with one LDS atomic.
+    unsigned int head = 0, tail = 0;                                    // ring positions (uniform, running)
+    // One pass over `count` <= 64 ring entries starting at `first`: a word that comes for the first time reserves the slots of all
+    // its columns with one LDS atomic, every word writes its lowest column and, if it has more, goes back to the tail.
     auto process = [&](unsigned int first, unsigned int count) {
         bool more = false;
         u64 v = 0;
@@ -319,24 +297,26 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void sl
             const unsigned int at = (first + lane) & (CMP_RING - 1);
             v = L.ring_v[at];
             const unsigned int m = L.ring_m[at];
-            const unsigned int j = m >> 6, col0 = (m & 63u) << 6;
-            const unsigned int slot = atomicAdd(&L.cnt[j], (unsigned int)__popcll(v));
+            const unsigned int j = (m >> 6) & 63u, col0 = (m & 63u) << 6;
+            const bool fresh = (m & CMP_CONT) == 0;
+            const unsigned int reserved = atomicAdd(&L.cnt[j], fresh ? (unsigned int)__popcll(v) : 0u);
+            const unsigned int slot = fresh ? reserved : (m >> 12) & 63u;
             const unsigned int bit = (unsigned int)(__ffsll((long long)v) - 1);
             const unsigned int cb = col_base16(col0, bit);
             unsigned char* const rj = L.rec + j * 64;
             *reinterpret_cast<unsigned short*>(rj + (slot < REC_SLOTS - 1 ? slot * 2 : 62u)) = (unsigned short)ord16(cb, bit);
             v &= v - 1;
             more = v != 0;
-            meta = (slot + 1 < REC_SLOTS - 1 ? slot + 1 : (unsigned int)(REC_SLOTS - 1)) | (j << 6) | (cb << 16);
+            meta = (m & 0xFFFu) | ((slot + 1 < REC_SLOTS - 1 ? slot + 1 : (unsigned int)(REC_SLOTS - 1)) << 12) | CMP_CONT;
         }
         const u64 mact = __ballot(more);
         if (more) {
-            const unsigned int q = lc + __builtin_amdgcn_mbcnt_hi((unsigned int)(mact >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mact, 0u));
-            L.left_v[q] = v;
-            L.left_m[q] = meta;
+            const unsigned int q = (tail + __builtin_amdgcn_mbcnt_hi((unsigned int)(mact >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mact, 0u))) &
+                                   (CMP_RING - 1);
+            L.ring_v[q] = v;
+            L.ring_m[q] = meta;
         }
-        lc += (unsigned int)__popcll(mact);
-        if (lc > CMP_LEFT - 64) flush_left();                           // uniform
+        tail += (unsigned int)__popcll(mact);
     };
 
     const int64_t ntiles = (a.batch + 63) >> 6;
@@ -346,7 +326,6 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void sl
     // operations complete in order, so a sub-pass waits until all but the other buffer's T loads (and, in the first two
     // sub-passes of a tile, the previous tile's four record stores) have completed.
     u64 wa[T], wb[T];
-    unsigned int head = 0, tail = 0;                                    // ring positions (uniform, running)
     int64_t tile = (int64_t)blockIdx.x * CMP_WAVES + wave;
     load_pairs<T>(a, tile * 64, pm, wa);
     load_pairs<T>(a, tile * 64 + CMP_SUB, pm, wb);
@@ -376,10 +355,10 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void sl
                                                                              __builtin_amdgcn_mbcnt_lo((unsigned int)act, 0u))) &
                                          (CMP_RING - 1);
                 L.ring_v[pos] = w[t];
-                L.ring_m[pos] = (unsigned short)(pm.jw[t] + ((unsigned int)(sub * CMP_SUB) << 6));
+                L.ring_m[pos] = pm.jw[t] + ((unsigned int)(sub * CMP_SUB) << 6);
             }
             tail += (unsigned int)__popcll(act);
-            if (tail - head >= 64) {                                    // uniform; at most 63 entries stay behind
+            while (tail - head >= 64) {                                 // uniform; at most 63 entries stay behind (a pass adds fewer than it takes)
                 wave_lds_sync();
                 process(head, 64);
                 head += 64;
@@ -406,10 +385,13 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void sl
             sub_pass(s0, sub, wa, tile + total_waves);
             sub_pass(s0, sub + 1, wb, tile + total_waves);
         }
+        while (tail != head) {                                          // uniform: what is left, and what that leaves
+            wave_lds_sync();
+            const unsigned int count = tail - head < 64 ? tail - head : 64;
+            process(head, count);
+            head += count;
+        }
         wave_lds_sync();
-        if (tail != head) process(head, tail - head);
-        head = tail;
-        flush_left();
 
         // lane = sample from here on
         const unsigned int c = L.cnt[lane];
