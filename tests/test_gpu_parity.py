@@ -116,6 +116,38 @@ def test_rref_panels_that_need_several_rounds(shape, ctx):
             assert list(pivots[b, :want_rank]) == list(want_piv)
 
 
+@pytest.mark.parametrize("shape", [(300, 700, 1), (200, 500, 4), (1100, 2500, 2), (2048, 4096, 3)])
+def test_rref_first_pass_moves_rows_it_has_nothing_to_add_to(shape, ctx):
+    # The blocked RREF's first trailing pass writes every row into the workspace copy (the row gather at the end then writes
+    # straight into the caller's buffer): also where the first PAIR of panels finds no pivot at all (128 empty columns in front:
+    # the pass has nothing to add and must still move the rows), where one matrix of a batch is like that and its neighbour is
+    # not, where a matrix is all zeros, and where the last 32-word chunk of a row is a partial one.
+    m, n, batch = shape
+    rng = np.random.default_rng(m * 3 + n)
+    mats = []
+    for b in range(batch):
+        a = rng.integers(0, 2, (m, n)).astype(np.uint8)
+        if b % 2 == 0:
+            a[:, :130] = 0
+        if b == 3:
+            a[:] = 0
+        if b == 2:
+            a[:, :1000] = 0                               # several pairs without a pivot, then the rest
+        mats.append(a)
+    packed = np.stack([_native.pack_rows(a) for a in mats])
+    if batch == 1:
+        pivots, rank = ctx.rref(packed[0], m, n)
+        want, want_piv, want_rank = c_oracle.rref(c_oracle.pack_rows(mats[0]), m, n)
+        assert rank == want_rank and list(pivots) == list(want_piv)
+        assert np.array_equal(packed[0], want)
+    else:
+        pivots, ranks = ctx.rref_batch(packed, batch, m, n)
+        for b in range(batch):
+            want, want_piv, want_rank = c_oracle.rref(c_oracle.pack_rows(mats[b]), m, n)
+            assert ranks[b] == want_rank and np.array_equal(packed[b], want), b
+            assert list(pivots[b, :want_rank]) == list(want_piv)
+
+
 def test_rref_big512(golden):
     a = np.random.default_rng(1024).integers(0, 2, (512, 1024)).astype(np.int64)
     out = bin_matrix.reduced_row_echelon_form(a)
