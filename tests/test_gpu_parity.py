@@ -148,6 +148,33 @@ def test_rref_first_pass_moves_rows_it_has_nothing_to_add_to(shape, ctx):
             assert list(pivots[b, :want_rank]) == list(want_piv)
 
 
+@pytest.mark.parametrize("shape", [(300, 2500, 3), (2048, 4096, 2), (700, 4100, 5), (1500, 6000, 1), (256, 2112, 9), (2000, 2100, 2)])
+def test_rref_mixed_batches_under_either_look_ahead_flag(shape, ctx, route):
+    # Batches of matrices with at most 2048 rows (panels held in registers), under both look-ahead flags (they only change the
+    # route of matrices with more than 8192 rows; a look-ahead for these batches was built and measured slower):
+    # same reduced forms, pivots and ranks as the oracle's -- dense and sparse matrices in one batch, empty leading columns
+    # (pairs without a pivot), a rank-deficient matrix, a last chunk of 32 words that is partial.
+    m, n, batch = shape
+    rng = np.random.default_rng(m * 11 + n + batch)
+    mats = []
+    for b in range(batch):
+        a = (rng.random((m, n)) < (0.5 if b % 3 != 1 else 0.02)).astype(np.uint8)
+        if b % 4 == 2:
+            a[:, :200] = 0
+        if b % 5 == 3:
+            a[m // 2:] = a[: m - m // 2]                     # every row twice: rank at most m / 2
+        mats.append(a)
+    want = [c_oracle.rref(c_oracle.pack_rows(a), m, n) for a in mats]
+    for flag in ("GF2_RREF_LOOKAHEAD", "GF2_RREF_NO_LOOKAHEAD"):
+        route.force(flag)
+        packed = np.stack([_native.pack_rows(a) for a in mats])
+        pivots, ranks = ctx.rref_batch(packed, batch, m, n)
+        route.release(flag)
+        for b in range(batch):
+            assert ranks[b] == want[b][2] and np.array_equal(packed[b], want[b][0]), (flag, b)
+            assert list(pivots[b, :want[b][2]]) == list(want[b][1]), (flag, b)
+
+
 def test_rref_big512(golden):
     a = np.random.default_rng(1024).integers(0, 2, (512, 1024)).astype(np.int64)
     out = bin_matrix.reduced_row_echelon_form(a)
