@@ -1,0 +1,179 @@
+"""
+Seeded random sweeps of the HIP path against the C oracle (oracle/gf2_oracle.c, pinned by tests/test_oracle_golden.py): shapes
+nobody picked by hand -- row and column counts around the 64-bit word, the 64-column panel, the 128-row window and the 1024-lane
+workgroup, padded leading dimensions, densities from empty to full, batches of unequal matrices.  Bit-exact, as everywhere.
+"""
+import numpy as np
+import pytest
+
+from oracle import c_oracle
+from quantum_css_codes_amd import _native
+
+pytestmark = pytest.mark.gpu
+
+EDGES = (1, 2, 3, 31, 63, 64, 65, 127, 128, 129, 191, 255, 256, 257, 500, 1023, 1024, 1025, 1500, 2047, 2049)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    return _native.default_context()
+
+
+def random_matrix(rng, m, n, density, pad_words=0):
+    a = (rng.random((m, n)) < density).astype(np.uint8)
+    kind = rng.integers(0, 6)
+    if kind == 0 and m > 2:
+        a[rng.integers(0, m)] = a[0] ^ a[m - 1]                       # a dependent row
+    if kind == 1 and n > 3:
+        a[:, rng.integers(0, n)] = 0                                  # a pivot-free column
+    if kind == 2 and n > 70:
+        a[:, : int(rng.integers(1, min(n, 200)))] = 0                 # empty leading columns
+    if kind == 3 and m > 4:
+        a[m // 2:] = a[: m - m // 2]                                  # rank at most m / 2
+    packed = _native.pack_rows(a)
+    if pad_words:                                                     # a leading dimension wider than the matrix needs
+        wide = np.zeros((m, packed.shape[1] + pad_words), dtype="<u8")
+        wide[:, : packed.shape[1]] = packed
+        packed = wide
+    return a, packed
+
+
+def test_fuzz_rref_nullspace_single_matrices(ctx):
+    rng = np.random.default_rng(20260)
+    for case in range(60):
+        m, n = int(rng.choice(EDGES)), int(rng.choice(EDGES))
+        if case % 7 == 0:
+            m, n = int(rng.integers(1, 700)), int(rng.integers(1, 3000))
+        density = float(rng.choice([0.0, 0.01, 0.1, 0.5, 0.9, 1.0]))
+        a, packed = random_matrix(rng, m, n, density, pad_words=int(rng.integers(0, 3)))
+        want, want_piv, want_rank = c_oracle.rref(packed, m, n)
+        null_want = c_oracle.nullspace(packed, m, n)
+        got = packed.copy()
+        pivots, rank = ctx.rref(got, m, n)
+        label = "case %d: %d x %d, density %.2f, ld %d" % (case, m, n, density, packed.shape[1])
+        assert rank == want_rank and list(pivots) == list(want_piv), label
+        assert np.array_equal(got, want), label
+        null_got = ctx.nullspace(packed.copy(), m, n)
+        assert np.array_equal(null_got, null_want), label
+
+
+def test_fuzz_rref_batches(ctx):
+    rng = np.random.default_rng(20261)
+    for case in range(25):
+        m, n = int(rng.choice(EDGES[3:])), int(rng.choice(EDGES[3:]))
+        batch = int(rng.integers(1, 12))
+        mats = [random_matrix(rng, m, n, float(rng.choice([0.02, 0.3, 0.5, 1.0])))[1] for _ in range(batch)]
+        packed = np.stack(mats)
+        want = [c_oracle.rref(mat, m, n) for mat in mats]
+        pivots, ranks = ctx.rref_batch(packed, batch, m, n)
+        for b in range(batch):
+            label = "case %d matrix %d: %d x %d" % (case, b, m, n)
+            assert ranks[b] == want[b][2] and np.array_equal(packed[b], want[b][0]), label
+            assert list(pivots[b, : want[b][2]]) == list(want[b][1]), label
+
+
+def test_fuzz_normalize(ctx):
+    rng = np.random.default_rng(20262)
+    done = 0
+    for case in range(80):
+        r = int(rng.choice(EDGES[:18]))
+        n = r + int(rng.integers(0, 400))
+        offset = int(rng.integers(0, n - r + 1))
+        a, packed = random_matrix(rng, r, n, float(rng.choice([0.2, 0.5, 0.8])))
+        rc, want, want_swaps = c_oracle.normalize(packed, r, n, offset)
+        label = "case %d: %d x %d, offset %d" % (case, r, n, offset)
+        got = packed.copy()
+        if rc != 0:                                                    # the reference raises for this matrix: so must the drop-in
+            with pytest.raises(_native.GF2Error):
+                ctx.normalize(got, r, n, offset)
+            continue
+        swaps = ctx.normalize(got, r, n, offset)
+        assert swaps == want_swaps, label
+        assert np.array_equal(got, want), label
+        done += 1
+    assert done >= 20
+
+
+def test_fuzz_syndromes_host_batches(ctx):
+    rng = np.random.default_rng(20263)
+    for case in range(40):
+        r, n = int(rng.choice(EDGES)), int(rng.choice(EDGES))
+        batch = int(rng.choice([1, 2, 63, 64, 65, 200, 1000]))
+        hm = (rng.random((r, n)) < rng.choice([0.05, 0.5])).astype(np.uint8)
+        if case % 3 == 0 and n >= r:                                   # a standard form: an identity block somewhere
+            off = int(rng.integers(0, n - r + 1))
+            hm[:, off:off + r] = np.identity(r, dtype=np.uint8)
+        em = (rng.random((batch, n)) < rng.choice([0.0, 0.01, 0.3, 1.0])).astype(np.uint8)
+        h, e = _native.pack_rows(hm), _native.pack_rows(em)
+        want = c_oracle.syndrome_batch(h, r, n, e, batch)
+        got = ctx.syndrome_batch(h, r, n, e, batch)
+        assert np.array_equal(got, want), "case %d: check %d x %d, %d errors" % (case, r, n, batch)
+
+
+def test_fuzz_sparse_weight_histograms_three_routes(ctx):
+    # gf2_syndrome_sparse_dev's three implementations on random standard-form checks: the LDS row-slab pipeline (forced: the
+    # batches are small), the wavefront-per-sample column gather, and whatever the library picks by itself; identity block at a
+    # random column (word-aligned, dword-aligned or neither), rates from nothing to records that overflow, ragged batches
+    rng = np.random.default_rng(20264)
+    for case in range(24):
+        r = int(rng.choice([65, 130, 300, 512, 513, 1000, 1536, 2040, 2047, 2048]))
+        extra = int(rng.integers(1, 2400))
+        n = min(r + extra, 4096 if r > 1024 else r + extra)
+        n = max(n, r + 1)
+        align = int(rng.choice([1, 32, 64]))
+        off = int(rng.integers(0, (n - r) // align + 1)) * align
+        batch = int(rng.choice([1, 63, 64, 65, 500, 1300, 3000]))
+        density = float(rng.choice([0.0, 0.002, 0.006, 0.012, 0.03]))
+        hm = rng.integers(0, 2, (r, n)).astype(np.uint8)
+        hm[:, off:off + r] = np.identity(r, dtype=np.uint8)
+        em = (rng.random((batch, n)) < density).astype(np.uint8)
+        if batch > 2:
+            em[int(rng.integers(0, batch))] = 1                        # every column at once
+        h, e = _native.pack_rows(hm), _native.pack_rows(em)
+        chk = ctx.check_create(h, r, n)
+        lde = e.shape[1]
+        e_buf = ctx.alloc(e.nbytes).upload(e)
+        want = c_oracle.histogram(c_oracle.syndrome_batch(h, r, n, e, batch), batch, r, 1, r + 1)
+        label = "case %d: check %d x %d, identity at %d, %d errors at %.3f" % (case, r, n, off, batch, density)
+        for flags in (_native.F_SPARSE_SLABS, _native.F_SPARSE_GATHER, 0):
+            keep = ctx.get_flags()
+            ctx.set_flags(keep | flags)
+            try:
+                hist = ctx.alloc((r + 1) * 8).zero()
+                ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist, r + 1)
+                got = hist.download((r + 1,), np.uint64)
+                hist.free()
+            finally:
+                ctx.set_flags(keep)
+            assert np.array_equal(got, want), label + ", flags %x" % flags
+        e_buf.free()
+
+
+def test_fuzz_monte_carlo_random_codes_and_rates(ctx):
+    # gf2_mc_run on random pairs of standard-form checks (H1 = [I | A], H2 = [A' | I | c] with k leftover columns, or no identity
+    # block at all) against the oracle's sequential statement: whatever route the library picks for the size and the rates --
+    # fused small-code kernel, lane-per-sample kernel, record sampler + slab pipeline, packed rows -- the histograms are the
+    # oracle's, from a sample index far into the stream
+    rng = np.random.default_rng(20265)
+    for case in range(14):
+        n = int(rng.choice([7, 15, 63, 64, 65, 127, 255, 511, 1000, 2048, 3000, 4096]))
+        r1 = max(1, int(n * rng.choice([0.25, 0.4, 0.5])))
+        k = int(rng.choice([0, 1, 2, 5]))
+        r2 = max(1, min(n - r1 - k, n - 1)) if n - r1 - k > 0 else 1
+        h1 = rng.integers(0, 2, (r1, n)).astype(np.uint8)
+        h2 = rng.integers(0, 2, (r2, n)).astype(np.uint8)
+        if case % 4 != 3:
+            h1[:, :r1] = np.identity(r1, dtype=np.uint8)
+            off2 = n - k - r2
+            h2[:, off2:off2 + r2] = np.identity(r2, dtype=np.uint8)
+        p = [float(v) for v in rng.choice([0.0, 0.001, 0.0033, 0.01, 0.05], size=3)]
+        count = int(rng.choice([1, 777, 20000, 70001])) if n > 64 else int(rng.choice([1, 1000, 300000]))
+        first = int(rng.integers(0, 2**40))
+        seed = int(rng.integers(0, 2**63))
+        hp1, hp2 = _native.pack_rows(h1), _native.pack_rows(h2)
+        c1, c2 = ctx.check_create(hp1, r1, n), ctx.check_create(hp2, r2, n)
+        want = c_oracle.mc(hp1, r1, hp2, r2, n, seed, first, count, p[0], p[1], p[2], 1)
+        got = ctx.mc_run(c1, c2, seed, first, count, p[0], p[1], p[2], _native.HIST_WEIGHT)
+        label = "case %d: n %d, r1 %d, r2 %d, k %d, p %s, %d samples from %d" % (case, n, r1, r2, k, p, count, first)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), label
+        assert int(got[0].sum()) == count and int(got[1].sum()) == count, label
