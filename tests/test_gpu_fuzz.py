@@ -177,3 +177,27 @@ def test_fuzz_monte_carlo_random_codes_and_rates(ctx):
         label = "case %d: n %d, r1 %d, r2 %d, k %d, p %s, %d samples from %d" % (case, n, r1, r2, k, p, count, first)
         assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), label
         assert int(got[0].sum()) == count and int(got[1].sum()) == count, label
+
+
+def test_fuzz_syndrome_table_random_checks():
+    # css_code.syndrome_table (the device search behind it: one word, two words, position lists) on random checks of random
+    # widths against the oracle's restatement of css_code.py:715-735: same t, same keys in the same insertion order, same errors
+    from oracle import cpu_ref
+    from quantum_css_codes_amd import css_code
+    rng = np.random.default_rng(20266)
+    for case in range(18):
+        n = int(rng.choice([5, 10, 23, 40, 63, 64, 65, 100, 128, 129, 200, 300]))
+        r = int(rng.integers(3, 13)) if n > 30 else int(rng.integers(2, min(n, 9)))
+        h = rng.integers(0, 2, (r, n))
+        if case % 3 == 0:
+            h[:, :r] = np.identity(r, dtype=int)
+        if case % 5 == 4:
+            h[:, int(rng.integers(0, n))] = 0                          # a weight-1 error with the zero syndrome
+        cap = 2 if n > 64 else (3 if n > 30 else None)
+        t, table = css_code.syndrome_table(h, max_weight=cap)
+        want_t, want = cpu_ref.syndrome_table(h, max_weight=cap)
+        label = "case %d: check %d x %d, cap %s" % (case, r, n, cap)
+        assert t == want_t, label
+        assert list(table.keys()) == [int(k) for k in want.keys()], label
+        for k in list(table.keys())[:: max(1, len(table) // 300)]:
+            assert np.array_equal(table[k], np.asarray(want[k], dtype=int)), label
