@@ -201,3 +201,48 @@ def test_fuzz_syndrome_table_random_checks():
         assert list(table.keys()) == [int(k) for k in want.keys()], label
         for k in list(table.keys())[:: max(1, len(table) // 300)]:
             assert np.array_equal(table[k], np.asarray(want[k], dtype=int)), label
+
+
+def test_fuzz_css_code_constructor_random_dual_pairs():
+    # CSSCode(H1, H2) on random dual pairs of random sizes (H2 = some rows of nullspace(H1), so H1 . H2^T = 0 by construction):
+    # both standard forms, the logical operators, t and k, the stabiliser labels and the gate set as the oracle's restatement of
+    # css_code.py:32-75 makes them; a pair the reference rejects (InvalidCodeError out of normalize_parity_check) must be
+    # rejected here too
+    from oracle import cpu_ref
+    from quantum_css_codes_amd import bin_matrix
+    from quantum_css_codes_amd.css_code import CSSCode
+    from quantum_css_codes_amd.errors import InvalidCodeError
+    rng = np.random.default_rng(20267)
+    built = 0
+    for case in range(30):
+        n = int(rng.choice([6, 9, 16, 31, 40, 64, 65, 100, 130, 200]))
+        r1 = int(rng.integers(1, max(2, n // 2)))
+        h1 = rng.integers(0, 2, (r1, n))
+        if case % 6 != 5:                                              # (every sixth pair keeps whatever rank it has)
+            while bin_matrix.rank(h1) < r1:
+                h1 = rng.integers(0, 2, (r1, n))
+        null = bin_matrix.nullspace(h1)
+        if null.shape[0] < 2:
+            continue
+        # the reference supports one logical qubit: all but one row of the dual's basis (now and then one row fewer, which it rejects)
+        r2 = null.shape[0] - (1 if case % 7 != 6 else 2)
+        rows = rng.choice(null.shape[0], size=r2, replace=False)
+        h2 = null[np.sort(rows)]
+        label = "case %d: n %d, r1 %d, r2 %d" % (case, n, r1, r2)
+        try:
+            want = cpu_ref.CSSCode(h1.copy(), h2.copy(), max_table_weight=1)
+        except Exception as err:                                        # noqa: BLE001 -- whatever the reference's logic raises
+            with pytest.raises((InvalidCodeError, ValueError)):
+                CSSCode(h1.copy(), h2.copy(), max_table_weight=1)
+            assert isinstance(err, (cpu_ref.InvalidCodeError, ValueError)), (label, repr(err))
+            continue
+        code = CSSCode(h1.copy(), h2.copy(), max_table_weight=1)
+        assert np.array_equal(code.parity_check_c1, want.parity_check_c1), label
+        assert np.array_equal(code.parity_check_c2, want.parity_check_c2), label
+        assert (code.n, code.k, code.t) == (want.n, want.k, want.t), label
+        assert np.array_equal(code.z_operator_matrix(), want.z_operator_matrix()), label
+        assert np.array_equal(code.x_operator_matrix(), want.x_operator_matrix()), label
+        assert code.stabilisers() == want.stabiliser_labels(), label
+        assert sorted(code._transversal_gates) == sorted(want._transversal_gates), label
+        built += 1
+    assert built >= 8
