@@ -246,3 +246,43 @@ def test_fuzz_css_code_constructor_random_dual_pairs():
         assert sorted(code._transversal_gates) == sorted(want._transversal_gates), label
         built += 1
     assert built >= 8
+
+
+def test_fuzz_decode_and_tally_random_small_codes():
+    # table decoding and the logical-error tally on random one-logical-qubit CSS codes small enough for
+    # full tables, against the statement built on the reference's dict tables (cpu_ref.decode_and_tally) and, at a larger sample
+    # count, against the C oracle's packed statement
+    from oracle import cpu_ref
+    from quantum_css_codes_amd import bin_matrix
+    from quantum_css_codes_amd.css_code import CSSCode
+    from quantum_css_codes_amd.montecarlo import dense_table, packed_word
+    rng = np.random.default_rng(20268)
+    fields = ('logical_x', 'logical_z', 'logical_any', 'uncorrectable_x', 'uncorrectable_z')
+    done = 0
+    for case in range(40):
+        n = int(rng.choice([5, 7, 9, 11, 13, 15]))
+        r1 = int(rng.integers(1, n - 2))
+        h1 = rng.integers(0, 2, (r1, n))
+        if bin_matrix.rank(h1) < r1:
+            continue
+        null = bin_matrix.nullspace(h1)
+        rows = np.sort(rng.choice(null.shape[0], size=null.shape[0] - 1, replace=False))
+        h2 = null[rows]
+        try:
+            want_code = cpu_ref.CSSCode(h1.copy(), h2.copy())
+        except Exception:                                               # noqa: BLE001 -- pairs the reference rejects are another test's
+            continue
+        code = CSSCode(h1.copy(), h2.copy())
+        p = [float(v) for v in rng.choice([0.01, 0.05, 0.1, 0.2], size=3)]
+        seed, first = int(rng.integers(0, 2**31)), int(rng.integers(0, 2**33))
+        label = "case %d: n %d, r1 %d, r2 %d, t %d, p %s" % (case, n, r1, h2.shape[0], code.t, p)
+        small = code.logical_error_rates(250, *p, seed=seed, first_sample=first)
+        assert [small[f] for f in fields] == cpu_ref.decode_and_tally(want_code, seed, first, 250, *p), label
+        big = code.logical_error_rates(150000, *p, seed=seed, first_sample=first)
+        want = c_oracle.mc_decode(c_oracle.pack_rows(code.parity_check_c1), code.r_1, c_oracle.pack_rows(code.parity_check_c2),
+                                  code.r_2, code.n, dense_table(code._c1_syndromes, code.r_1, code.n),
+                                  dense_table(code._c2_syndromes, code.r_2, code.n), packed_word(code.x_operator_matrix()[0]),
+                                  packed_word(code.z_operator_matrix()[0]), seed, first, 150000, *p)
+        assert [big[f] for f in fields] == [int(v) for v in want], label
+        done += 1
+    assert done >= 6
