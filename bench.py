@@ -24,10 +24,12 @@ the two syndrome-weight histograms.  Two implementations, same results bit for b
                            components of a step go to two contexts = two HIP streams (--one-stream: one).
   --algo dense             Four-Russians table kernel on tiled errors, slab-major syndromes written, then the
                            histogram kernel.  Data-independent.
-Per-GPU work is fixed as N grows ("weak"); ranks never exchange data on the path; the histograms are summed
-once with one all-reduce inside the timed region -- gf2_hist_allreduce: libgf2hip's own RCCL communicator, from the
-device buffer the kernels accumulate into, on the compute context's stream (--allreduce torch: torch.distributed's
-all_reduce on a copy instead).  value = N * K * batch / max-over-ranks time.
+Per-GPU work is fixed as N grows ("weak"; --total-samples T: T samples in all, 1/N of them per rank, "strong" -- T = 10^8 is
+configs[4] to the letter); ranks never exchange data on the path; the histograms are summed once with one all-reduce inside
+the timed region -- torch.distributed's all_reduce (RCCL) by default; --allreduce gf2: gf2_hist_allreduce, libgf2hip's own RCCL
+communicator, from the device buffer the kernels accumulate into, on the compute context's stream, set up under a time limit
+(guarded_comm: a rank whose communicator does not come up leaves, the launcher starts fresh ranks with --allreduce torch).
+value = K * (samples of all ranks per step) / max-over-ranks time.
 
 The JSON line also carries
   roofline      the path against the HBM roofline: algorithmic bytes per launch (n/8 read [+ r/8
@@ -392,80 +394,165 @@ def small_code_numbers(ctx):
     return res
 
 
-def launch_ranks(gpus):
+COMM_TIMEOUT_EXIT = 3          # a rank leaves with this code when its RCCL communicator did not come up in time (guarded_comm)
+
+
+def launch_ranks(gpus, argv=None, deadline_s=3600.0):
     """`python bench.py --gpus N` without a launcher: the N ranks as child processes of this one, which never touches the
     GPU (no re-exec of a process that has: the children are started first thing).  Rank 0 prints the JSON line on the
-    inherited stdout; the exit code is the worst of the ranks'; when one rank fails the others are stopped."""
+    inherited stdout; the exit code is the worst of the ranks'.  Every rank is the leader of a process group of its own:
+    when one rank fails, when this process is told to stop (SIGTERM / SIGINT are forwarded) or when the deadline passes, the
+    others are terminated and, if they have not gone within five seconds -- a rank inside an RCCL or HIP call does not see
+    SIGTERM --, killed, so no rank outlives the launcher holding its GPU.  Ranks that leave with COMM_TIMEOUT_EXIT (the
+    library's own communicator did not come up, --allreduce gf2) are started once more, fresh, with --allreduce torch."""
+    import signal
     import socket
     import subprocess
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    procs = []
-    for r in range(gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    worst, live = 0, list(procs)
-    while live:
-        time.sleep(0.2)
-        for proc in list(live):
-            rc = proc.poll()
-            if rc is None:
-                continue
-            live.remove(proc)
-            if rc != 0:
-                worst = worst or (rc if rc > 0 else 128 - rc)
-                for other in live:
-                    other.terminate()                  # exactly the processes started above
-    return worst
+    argv = list(sys.argv[1:] if argv is None else argv)
+    stop = {"signal": None}
+
+    def on_signal(signum, _frame):
+        stop["signal"] = signum
+
+    previous = {sig: signal.signal(sig, on_signal) for sig in (signal.SIGTERM, signal.SIGINT)}
+
+    def end(procs):
+        for proc in procs:
+            if proc.poll() is None:
+                try:
+                    os.killpg(proc.pid, signal.SIGTERM)
+                except OSError:
+                    pass
+        limit = time.monotonic() + 5.0
+        for proc in procs:
+            try:
+                proc.wait(max(0.0, limit - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                try:
+                    os.killpg(proc.pid, signal.SIGKILL)
+                except OSError:
+                    pass
+                proc.wait()
+
+    def one_round(args):
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        procs = []
+        try:
+            for r in range(gpus):
+                env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), LOCAL_WORLD_SIZE=str(gpus),
+                           MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + args, env=env, start_new_session=True))
+            worst, live, t_end = 0, list(procs), time.monotonic() + deadline_s
+            while live:
+                time.sleep(0.1)
+                if stop["signal"] is not None:
+                    return 128 + int(stop["signal"])
+                if time.monotonic() > t_end:
+                    sys.stderr.write("[bench] ranks still running after %.0f s: stopping them\n" % deadline_s)
+                    return 124
+                for proc in list(live):
+                    rc = proc.poll()
+                    if rc is None:
+                        continue
+                    live.remove(proc)
+                    if rc != 0:
+                        worst = worst or (rc if rc > 0 else 128 - rc)
+                        return worst                       # the others are stopped below
+            return worst
+        finally:
+            end(procs)                                     # exactly the process groups started above
+
+    try:
+        rc = one_round(argv)
+        if rc == COMM_TIMEOUT_EXIT and "gf2" in argv:
+            sys.stderr.write("[bench] a rank's RCCL communicator did not come up: fresh ranks with --allreduce torch\n")
+            sys.stderr.flush()
+            rc = one_round(argv + ["--allreduce", "torch"])
+        return rc
+    finally:
+        for sig, handler in previous.items():
+            signal.signal(sig, handler)
 
 
 def guarded_comm(ctx, nbins, seconds=120.0):
-    """libgf2hip's communicator over all ranks, proven by one all-reduce, or (None, why): the N > 1 line must come out even on
-    a node where the library's librccl cannot set itself up beside torch's.  The id exchange runs here (a collective of the
-    process group); ncclCommInitRank and the first all-reduce run in a helper thread with a time limit, and the ranks then
-    agree (MIN over the process group) whether ALL of them got through -- otherwise all of them sum through
-    torch.distributed instead and a helper thread that is still stuck is left behind (it is a daemon thread)."""
+    """libgf2hip's communicator over all ranks, proven by one all-reduce -- (comm, "") --, or (None, why) when it cannot be had:
+    then every rank sums through torch.distributed instead.  The id exchange runs here (a collective of the process group);
+    ncclCommInitRank and the first all-reduce run in a helper thread with a time limit.  What the ranks made of it they tell
+    each other through the process group's key-value store (host side: no GPU collective while a helper may be stuck in one):
+      every rank got through              -> the communicator;
+      a rank's attempt came back failed   -> (None, why) on every rank; a rank that does hold a communicator closes it;
+      a rank's helper has not come back   -> that thread sits inside RCCL on this context's device, so the context must not
+                                             be used any further: every rank says why on stderr, flushes and leaves through
+                                             os._exit(COMM_TIMEOUT_EXIT) -- an exit, never a re-exec; the stuck thread cannot
+                                             hold the interpreter's teardown.  bench's own launcher then starts fresh ranks with
+                                             --allreduce torch (launch_ranks); under another launcher the run is lost, which is
+                                             why --allreduce gf2 is not the default for N > 1 before an N > 1 run has proven it."""
+    import datetime
     import threading
-    import torch
     import torch.distributed as dist
     from quantum_css_codes_amd import _native
-    rank, world = dist.get_rank(), dist.get_world_size()
+    grouped = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if grouped else (0, 1)
     ident = [None]
     if rank == 0:
         try:
             ident[0] = _native.Comm.unique_id()
         except _native.GF2Error as err:                # librccl does not load: every rank hears of it
             ident[0] = str(err)[:120]
-    dist.broadcast_object_list(ident, src=0)
+    if grouped:
+        dist.broadcast_object_list(ident, src=0)
     if not isinstance(ident[0], bytes):
         return None, " [gf2_comm_unique_id: %s]" % ident[0]
     box = {}
 
     def work():
         try:
+            if os.environ.get("BENCH_FAULT") == "comm_timeout":        # tests/test_rccl.py: a communicator that never comes up
+                time.sleep(3600)
             comm = _native.Comm(ctx, ident[0], world, rank)
+            box["comm"] = comm
             probe = ctx.alloc(nbins * 8).upload(np.full(nbins, 1, dtype=np.uint64))
             comm.allreduce(probe, nbins)
             got = probe.download((nbins,), np.uint64)
             probe.free()
             if not (got == world).all():
                 raise RuntimeError("gf2_hist_allreduce: wrong sum")
-            box["comm"] = comm
+            box["ok"] = True
         except Exception as err:                       # noqa: BLE001 -- whatever it is, the fallback runs
             box["why"] = str(err)[:120]
 
     helper = threading.Thread(target=work, daemon=True)
     helper.start()
     helper.join(seconds)
-    mine = 1 if "comm" in box else 0
-    flag = torch.tensor([mine], dtype=torch.int32, device=torch.device("cuda", ctx.device))
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if int(flag.item()) == 1:
+    mine = "ok" if box.get("ok") else ("err:" + box["why"] if "why" in box else "timeout")
+    verdicts = [mine]
+    if grouped and world > 1:
+        store = dist.distributed_c10d._get_default_store()
+        store.set("gf2_comm/%d" % rank, mine)
+        keys = ["gf2_comm/%d" % r for r in range(world)]
+        try:
+            store.wait(keys, datetime.timedelta(seconds=seconds + 60.0))
+            verdicts = [store.get(k).decode("utf-8", "replace") for k in keys]
+        except Exception as err:                       # noqa: BLE001 -- a rank never answered: treated as stuck
+            verdicts = [mine, "timeout (%s)" % str(err)[:60]]
+    if any(v.startswith("timeout") for v in verdicts):
+        sys.stderr.write("[bench] rank %d: gf2_comm_create / first gf2_hist_allreduce not back within %.0f s on %s: leaving with code "
+                         "%d (the context cannot be used beside a thread that is inside RCCL)\n"
+                         % (rank, seconds, "this rank" if mine == "timeout" else "another rank", COMM_TIMEOUT_EXIT))
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(COMM_TIMEOUT_EXIT)
+    if all(v == "ok" for v in verdicts):
         return box["comm"], ""
-    why = box.get("why", "no answer within %.0f s" % seconds if not mine else "another rank failed")
+    if "comm" in box and not helper.is_alive():
+        try:
+            box["comm"].close()                        # this rank's came up, another's did not
+        except Exception:                              # noqa: BLE001
+            pass
+    why = next(v[4:] for v in verdicts if v.startswith("err:"))
     return None, " [gf2_comm_create: %s]" % why
 
 
@@ -483,9 +570,18 @@ def main():
     ap.add_argument("--dist-backend", choices=("nccl", "gloo"), default="nccl",
                     help="gloo lets several ranks share one GPU to rehearse the multi-process path (histograms are "
                          "then all-reduced on the host); the driver's runs use nccl = RCCL")
-    ap.add_argument("--allreduce", choices=("gf2", "torch"), default="gf2",
-                    help="the histogram all-reduce of N > 1 ranks on the nccl backend: gf2 = gf2_hist_allreduce (libgf2hip's own "
-                         "RCCL communicator, device buffer, the context's stream), torch = torch.distributed.all_reduce")
+    ap.add_argument("--allreduce", choices=("gf2", "torch"), default="torch",
+                    help="the histogram all-reduce of the ranks on the nccl backend: torch = torch.distributed.all_reduce (RCCL through "
+                         "torch; the default until an N > 1 run has proven the other), gf2 = gf2_hist_allreduce (libgf2hip's own RCCL "
+                         "communicator, device buffer, the context's stream; set up under a time limit: guarded_comm)")
+    ap.add_argument("--launch-deadline", type=float, default=3600.0,
+                    help="seconds after which the self-launched ranks (no launcher: WORLD_SIZE unset) are stopped")
+    ap.add_argument("--comm-timeout", type=float, default=120.0, help="seconds --allreduce gf2 waits for its communicator")
+    ap.add_argument("--total-samples", type=int, default=None,
+                    help="strong scaling: this many samples of the global stream in total, rank g of N taking the g-th of N contiguous "
+                         "shards (montecarlo.shard_range) -- 100000000 is BASELINE.json configs[4] to the letter; the line then says "
+                         "\"scaling\": \"strong\" and a step is one pass over the rank's shard.  Default: 2^batch-log2 samples per "
+                         "GPU whatever N (weak scaling)")
     ap.add_argument("--algo", choices=("sparse", "dense"), default="sparse")
     ap.add_argument("--slab-pass-log2", type=int, default=None,
                     help="samples per pass of the slab pipeline through its workspace (GF2_OPT_SLAB_PASS_LOG2)")
@@ -496,8 +592,15 @@ def main():
                     help="issue both components of a step on one HIP stream (default: H2.e_x goes to a second context)")
     args = ap.parse_args()
 
-    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(launch_ranks(args.gpus))
+    # without a launcher this process only supervises: N > 1 ranks, and also the single rank of an explicit --allreduce gf2,
+    # which must be able to leave (guarded_comm) and be started afresh
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.allreduce == "gf2"):
+        sys.exit(launch_ranks(args.gpus, deadline_s=args.launch_deadline))
+    if os.environ.get("BENCH_FAULT") == "hang" and "WORLD_SIZE" in os.environ:
+        # tests/test_rccl.py: a rank that sits in a call that does not see SIGTERM (what a rank inside RCCL looks like to its launcher)
+        import signal
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)
+        time.sleep(3600)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -522,12 +625,20 @@ def main():
     # the ranks' own RCCL communicator (its id travels over the process group's rendezvous); ranks that share a GPU
     # (--dist-backend gloo) cannot form one and sum on the host
     comm, comm_note = None, ""
-    if world > 1 and args.dist_backend == "nccl" and args.allreduce == "gf2":
-        comm, comm_note = guarded_comm(ctx, R1 + 1 + R2 + 1)
+    if args.dist_backend == "nccl" and args.allreduce == "gf2":
+        comm, comm_note = guarded_comm(ctx, R1 + 1 + R2 + 1, args.comm_timeout)
     code, h1, h2 = build_code()
     chk1, chk2 = ctx.check_create(h1, R1, N_QUBITS), ctx.check_create(h2, R2, N_QUBITS)
-    batch = 1 << args.batch_log2
-    first = rank * batch               # this rank's shard of the global sample stream: sample i = f(seed, i)
+    if args.total_samples is None:
+        batch = 1 << args.batch_log2
+        first = rank * batch           # this rank's shard of the global sample stream: sample i = f(seed, i)
+        total_per_step = world * batch
+    else:
+        from quantum_css_codes_amd.montecarlo import shard_range
+        first, batch = shard_range(0, args.total_samples, rank, world)
+        total_per_step = args.total_samples
+        if batch < 512:
+            raise SystemExit("--total-samples %d leaves rank %d with %d samples: at least 512 per rank" % (args.total_samples, rank, batch))
 
     ctx2 = None if args.one_stream else _native.Context(ctx.device)
     for c in (ctx, ctx2):
@@ -598,7 +709,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    total = world * args.steps * batch
+    total = args.steps * total_per_step
     assert int(hist_z.sum()) == total and int(hist_x.sum()) == total
     if not call_events:
         for c in path.contexts():
@@ -635,11 +746,12 @@ def main():
         out = {
             "metric": "syndromes/sec (n=4096 CSS)", "value": total / elapsed, "unit": "syndromes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "settle_steps": settle_steps,
-            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "weak" if args.total_samples is None else "strong",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": "configs[4]: n=4096 CSS Monte-Carlo, random dual code (H1 2048x4096, H2 2047x4096, "
                                    "standard form), depolarising p=0.01, errors resident in HBM",
-                       "algo": args.algo, "samples_per_gpu_per_step": batch, "global_samples_per_step": batch * world,
+                       "algo": args.algo, "samples_per_gpu_per_step": batch, "global_samples_per_step": total_per_step,
                        "streams": 2 if path.ctx2 is not None else 1,
                        "parallelism": "sample-range shards, 1 histogram all-reduce"
                                       + ("" if world == 1 else " (gf2_hist_allreduce over librccl)" if comm is not None else
@@ -673,6 +785,33 @@ def main():
             else:
                 assert np.array_equal(ctx.mc_run(chk1, chk2, SEED, first, batch, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3,
                                                  _native.HIST_WEIGHT)[0], single_z)
+            # BASELINE.json configs[4] to the letter, on this one GPU: 10^8 samples (the first 10^8 of the resident batch), both
+            # components on the two streams of the timed region, histograms included; `--total-samples 100000000 --gpus N` is
+            # the same over N ranks (1/N of it each)
+            literal = None
+            if args.algo == "sparse" and batch >= 10**8:
+                lde = _native.words_for(N_QUBITS)
+                side = path.ctx2 if path.ctx2 is not None else ctx
+                lit_z, lit_x = ctx.alloc((R1 + 1) * 8).zero(), ctx.alloc((R2 + 1) * 8).zero()
+
+                def literal_step():
+                    ctx.syndrome_sparse_dev(chk1, path.ez, 10**8, lde, None, 0, lit_z, R1 + 1)
+                    side.syndrome_sparse_dev(chk2, path.ex, 10**8, lde, None, 0, lit_x, R2 + 1)
+                literal_step()
+                path.sync()
+                lit_z.zero(), lit_x.zero()
+                path.sync()
+                ctx.timer_start()
+                for _ in range(5):
+                    literal_step()
+                if path.ctx2 is not None:
+                    path.ctx2.sync()
+                lit_ms = ctx.timer_stop() / 5
+                assert int(lit_z.download((R1 + 1,), np.uint64).sum()) == 5 * 10**8
+                literal = {"samples": 10**8, "ms": lit_ms, "value": 10**8 / (lit_ms / 1e3), "unit": "syndromes/s",
+                           "frac_hbm_peak": 10**8 * 2 * path.alg_bytes_per_sample / lit_ms / 1e6 / HBM_PEAK_GBS,
+                           "what": "configs[4]'s 10^8 error samples, resident, H1.e_z and H2.e_x + both weight histograms, one GPU"}
+                lit_z.free(), lit_x.free()
             path.free()
             # the other implementations on 2^20 resident samples of the same stream (one stream, per-call rooflines)
             sec = min(batch, 1 << 20)
@@ -727,6 +866,8 @@ def main():
                 other.algo + "_kernel": {"value": 10 * sec / (o_ms / 1e3), "unit": "syndromes/s", "ms_per_step": o_ms / 10,
                                          "roofline": roofline(other, o_launch, o_n), "histogram_ms_per_step": o_hist / 10},
                 "rref": rref_numbers(ctx)}
+            if literal is not None:
+                out["secondary"]["configs4_literal_1e8"] = literal
             out["secondary"]["column_gather_kernel"] = gather
             out["secondary"]["one_stream"] = single
             out["secondary"]["read_write_1536B"] = stored

@@ -11,8 +11,12 @@ for path in sys.argv[1:]:
     with open(path) as fh:
         for rec in csv.DictReader(fh):
             name = re.sub(r"\(.*", "", rec["Kernel_Name"]).replace("void ", "")
-            key = (name, int(rec["Grid_Size_X"]) * int(rec["Grid_Size_Y"]) // max(1, int(rec["Workgroup_Size_X"])),
-                   int(rec["Workgroup_Size_X"]), int(rec["VGPR_Count"]), int(rec["SGPR_Count"]), int(rec["LDS_Block_Size"]))
+            # workgroups = product over the three dimensions of grid size (work-items) / workgroup size
+            wgs = 1
+            for d in "XYZ":
+                wgs *= -(-int(rec.get("Grid_Size_" + d) or 1) // max(1, int(rec.get("Workgroup_Size_" + d) or 1)))
+            key = (name, wgs, int(rec["Workgroup_Size_X"]) * int(rec.get("Workgroup_Size_Y") or 1) * int(rec.get("Workgroup_Size_Z") or 1),
+                   int(rec["VGPR_Count"]), int(rec["SGPR_Count"]), int(rec["LDS_Block_Size"]))
             rows[key].append(int(rec["End_Timestamp"]) - int(rec["Start_Timestamp"]))
 print("| kernel | workgroups | wg size | VGPR | SGPR | LDS B | calls | mean us | min us | max us | total ms |")
 print("|---|---|---|---|---|---|---|---|---|---|---|")

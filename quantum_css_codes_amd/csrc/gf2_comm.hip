@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include <rccl/rccl.h>
 
 #include "gf2_internal.h"
@@ -35,8 +37,10 @@ struct RcclApi {
 };
 
 RcclApi g_rccl = {};
+std::mutex g_rccl_mutex;            // entry points may be called from several host threads (one context each): one of them loads
 
 int rccl_load() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.handle) return GF2_OK;
     // The RCCL that belongs to the HIP runtime THIS library runs on.  A process may hold two HIP runtimes -- ROCm's and the copy a
     // PyTorch wheel ships next to its own librccl -- and which of them libgf2hip is bound to depends on what was loaded first; a
@@ -177,12 +181,22 @@ int gf2_hist_allreduce(gf2_comm* comm, uint64_t* const* hist_dev, int64_t nbins)
     for (int i = 0; i < comm->nlocal; ++i)
         if (!hist_dev[i]) GF2_FAIL(GF2_E_ARG, "gf2_hist_allreduce: null histogram %d", i);
     // one process with several communicators: the calls must sit in one group, or the first would wait for the others
-    if (comm->nlocal > 1) GF2_RCCL(g_rccl.GroupStart());
+    const bool grouped = comm->nlocal > 1;
+    if (grouped) GF2_RCCL(g_rccl.GroupStart());
     for (int i = 0; i < comm->nlocal; ++i) {
-        GF2_TRY(gf2_ctx_activate(comm->ctx[i]));
-        GF2_RCCL(g_rccl.AllReduce(hist_dev[i], hist_dev[i], (size_t)nbins, ncclUint64, ncclSum, comm->comm[i], comm->ctx[i]->stream));
+        // a failure inside the group must not leave it open (every later collective of the process would hang): close it first
+        if (gf2_ctx_activate(comm->ctx[i]) != GF2_OK) {
+            if (grouped) (void)g_rccl.GroupEnd();
+            return GF2_E_HIP;
+        }
+        const ncclResult_t nr =
+            g_rccl.AllReduce(hist_dev[i], hist_dev[i], (size_t)nbins, ncclUint64, ncclSum, comm->comm[i], comm->ctx[i]->stream);
+        if (nr != ncclSuccess) {
+            if (grouped) (void)g_rccl.GroupEnd();
+            GF2_FAIL(GF2_E_RCCL, "ncclAllReduce (communicator %d of %d) failed: %s", i, comm->nlocal, g_rccl.GetErrorString(nr));
+        }
     }
-    if (comm->nlocal > 1) GF2_RCCL(g_rccl.GroupEnd());
+    if (grouped) GF2_RCCL(g_rccl.GroupEnd());
     for (int i = 0; i < comm->nlocal; ++i) {
         GF2_TRY(gf2_ctx_activate(comm->ctx[i]));
         GF2_TRY(gf2_stream_wait(comm->ctx[i]->stream));
@@ -195,6 +209,7 @@ int gf2_comm_destroy(gf2_comm* comm) {
     int rc = GF2_OK;
     for (int i = 0; i < comm->nlocal; ++i) {
         (void)hipSetDevice(comm->ctx[i]->device);
+        (void)hipStreamSynchronize(comm->ctx[i]->stream);          // a collective of this communicator may still be on the stream
         if (comm->comm[i] && g_rccl.CommDestroy(comm->comm[i]) != ncclSuccess) rc = GF2_E_RCCL;
     }
     free(comm);

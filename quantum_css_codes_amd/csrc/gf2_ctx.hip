@@ -7,15 +7,6 @@
 
 #include "gf2_internal.h"
 
-static thread_local char g_error[512] = "";
-
-void gf2_set_error(const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_error, sizeof(g_error), fmt, ap);
-    va_end(ap);
-}
-
 // Waits for a stream.  hipStreamSynchronize blocks on an interrupt after a short poll and was seen to wake up milliseconds
 // late (a 12 ms gf2_mc_run returned after 20 ms every other call): poll hipStreamQuery for the first 50 ms instead, then block.
 int gf2_stream_wait(hipStream_t stream) {
@@ -101,8 +92,6 @@ static void destroy_streams_and_events(gf2_ctx* ctx) {
 extern "C" {
 
 int gf2_version(void) { return GF2_VERSION_NUMBER; }
-
-const char* gf2_last_error(void) { return g_error; }
 
 int gf2_device_count(int* count_out) {
     if (!count_out) GF2_FAIL(GF2_E_ARG, "gf2_device_count: null output");
@@ -309,121 +298,9 @@ int gf2_membw_probe_dev(gf2_ctx* ctx, const void* src_dev, void* dst_dev, size_t
     return GF2_OK;
 }
 
-// ---- host-side packing ------------------------------------------------------------------------------
-
-// Rows are independent: large arrays are cut into row ranges, one host thread each (a 2048 x 4096 int64 array is 64 MiB, more
-// than one core streams in the time the elimination itself takes; gf2_rref on it spent 6 of its 7 ms here on one thread).
+// (host-side packing -- gf2_pack_rows_*, gf2_unpack_rows_* -- and the error message plumbing live in gf2_host.cpp: a plain C++
+// translation unit without HIP, so that the CPU box can build it with -fsanitize=thread / address: `make tsan`, `make asan`)
 }   // extern "C"
-
-#include <atomic>
-#include <thread>
-#include <vector>
-
-template <typename F>
-static void host_rows_parallel(int64_t rows, int64_t bytes_per_row, F body) {
-    const int64_t total = rows * bytes_per_row;
-    static const int64_t cap = []() {                                   // GF2_HOST_THREADS, read once (default: up to 16)
-        const char* env = getenv("GF2_HOST_THREADS");
-        const long v = env ? strtol(env, nullptr, 10) : 0;
-        return (int64_t)(v >= 1 && v <= 256 ? v : 16);
-    }();
-    const unsigned int hw = std::thread::hardware_concurrency();
-    int64_t threads = hw ? ((int64_t)hw > cap ? cap : (int64_t)hw) : 1;
-    if (threads > total >> 20) threads = total >> 20;                   // at least 1 MiB per thread
-    if (threads > rows) threads = rows;
-    if (threads <= 1) {
-        body((int64_t)0, rows);
-        return;
-    }
-    std::vector<std::thread> pool;
-    const int64_t per = (rows + threads - 1) / threads;
-    for (int64_t t = 1; t < threads; ++t) {
-        const int64_t lo = t * per, hi = lo + per < rows ? lo + per : rows;
-        if (lo < hi) pool.emplace_back([=]() { body(lo, hi); });
-    }
-    body((int64_t)0, per < rows ? per : rows);
-    for (auto& th : pool) th.join();
-}
-
-// `other_out` (may be null): set to 1 when some entry is not 0 or 1 -- css_code.py:39-44's "must be binary" test, made on the way
-// through the array instead of in three further passes over it.
-template <typename T>
-static int pack_rows_host(const T* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld, int* other_out = nullptr) {
-    if ((!src || !dst) && m > 0 && n > 0) GF2_FAIL(GF2_E_ARG, "pack: null buffer");
-    if (m < 0 || n < 0 || ld < gf2_words(n) || src_stride < n) GF2_FAIL(GF2_E_ARG, "pack: bad shape");
-    std::atomic<int> other(0);
-    std::atomic<int>* const other_p = &other;
-    host_rows_parallel(m, n * (int64_t)sizeof(T), [=](int64_t lo, int64_t hi) {
-        T seen = 0;
-        for (int64_t i = lo; i < hi; ++i) {
-            const T* row = src + i * src_stride;
-            uint64_t* out = dst + i * ld;
-            for (int64_t w = 0; w < ld; ++w) {
-                uint64_t acc = 0;
-                const int64_t base = w * 64;
-                const int64_t lim = n - base < 64 ? n - base : 64;
-                for (int64_t b = 0; b < lim; ++b) {
-                    acc |= (uint64_t)(row[base + b] & 1) << b;
-                    seen |= row[base + b];
-                }
-                out[w] = acc;
-            }
-        }
-        if (seen & ~(T)1) other_p->store(1);
-    });
-    if (other_out) *other_out = other.load();
-    return GF2_OK;
-}
-
-template <typename T>
-static int unpack_rows_host(const uint64_t* src, int64_t m, int64_t n, int64_t ld, T* dst, int64_t dst_stride) {
-    if ((!src || !dst) && m > 0 && n > 0) GF2_FAIL(GF2_E_ARG, "unpack: null buffer");
-    if (m < 0 || n < 0 || ld < gf2_words(n) || dst_stride < n) GF2_FAIL(GF2_E_ARG, "unpack: bad shape");
-    host_rows_parallel(m, n * (int64_t)sizeof(T), [=](int64_t lo, int64_t hi) {
-        for (int64_t i = lo; i < hi; ++i) {
-            const uint64_t* row = src + i * ld;
-            T* out = dst + i * dst_stride;
-            const int64_t full = n >> 6;
-            for (int64_t w = 0; w < full; ++w) {                  /* whole words: a fixed-length loop the compiler vectorises */
-                const uint64_t v = row[w];
-                T* o = out + w * 64;
-                for (int b = 0; b < 64; ++b) o[b] = (T)((v >> b) & 1);
-            }
-            for (int64_t j = full * 64; j < n; ++j) out[j] = (T)((row[j >> 6] >> (j & 63)) & 1);
-        }
-    });
-    return GF2_OK;
-}
-
-extern "C" {
-
-int gf2_pack_rows_u8(const uint8_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld) {
-    return pack_rows_host<uint8_t>(src, m, n, src_stride, dst, ld);
-}
-
-int gf2_pack_rows_i64(const int64_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld) {
-    return pack_rows_host<int64_t>(src, m, n, src_stride, dst, ld);
-}
-
-int gf2_pack_rows_binary_u8(const uint8_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld, int* other_out) {
-    if (!other_out) GF2_FAIL(GF2_E_ARG, "pack: null output");
-    return pack_rows_host<uint8_t>(src, m, n, src_stride, dst, ld, other_out);
-}
-
-int gf2_pack_rows_binary_i64(const int64_t* src, int64_t m, int64_t n, int64_t src_stride, uint64_t* dst, int64_t ld, int* other_out) {
-    if (!other_out) GF2_FAIL(GF2_E_ARG, "pack: null output");
-    return pack_rows_host<int64_t>(src, m, n, src_stride, dst, ld, other_out);
-}
-
-int gf2_unpack_rows_u8(const uint64_t* src, int64_t m, int64_t n, int64_t ld, uint8_t* dst, int64_t dst_stride) {
-    return unpack_rows_host<uint8_t>(src, m, n, ld, dst, dst_stride);
-}
-
-int gf2_unpack_rows_i64(const uint64_t* src, int64_t m, int64_t n, int64_t ld, int64_t* dst, int64_t dst_stride) {
-    return unpack_rows_host<int64_t>(src, m, n, ld, dst, dst_stride);
-}
-
-}  // extern "C"
 
 // ---- internals --------------------------------------------------------------------------------------
 

@@ -1096,9 +1096,6 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         if (CROSS) {
             const unsigned int k = group & 15u;
             off = (group >> 4) * (4u * TILE_REC_BYTES) + (k < 8 ? k * 128u + short_lane : 1024u + (k - 8u) * 256u + long_lane);
-#ifdef GAT_EXP_NOREC
-            off = ((group >> 4) & 15u) * (4u * TILE_REC_BYTES) + (k < 8 ? k * 128u + short_lane : 1024u + (k - 8u) * 256u + long_lane);
-#endif
         } else {
             const unsigned int q = group & 3u;
             off = (group >> 2) * TILE_REC_BYTES + (q < 2 ? q * 512u + short_lane : (q - 1u) * 1024u + long_lane);
@@ -1106,13 +1103,7 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(R) : "v"(off), "s"(rsrc) : "memory");
     };
     auto issue_ident = [&](u32x4& I, unsigned int& E, unsigned int pos, unsigned int header) {
-#if defined(GAT_EXP_SEQIDENT)                               // (timing experiments: wrong results, never defined in the product build)
-        const unsigned int sample = pos;
-#elif defined(GAT_EXP_NOIDENT)
-        const unsigned int sample = (pos & 1023u) | (header & 0u);
-#else
         const unsigned int sample = record_sample(pos, header);
-#endif
         const char* p = ident_base + (u64)(sample < (unsigned int)a.batch ? sample : 0u) * row_bytes;
         asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(I) : "v"(p) : "memory");
         if (EXTRA) {
@@ -1124,14 +1115,6 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
     u32x4 R0, R1, R2, R3, I0, I1, I2, I3;
     unsigned int E0 = 0, E1 = 0, E2 = 0, E3 = 0;
     // ticket t = step t / 16 of the fixed split's wavefront t mod 16: group share * 16 + t mod 16 + (t / 16) * stride
-#ifdef GAT_EXP_NOTAKE
-    unsigned int fixed_t = (unsigned int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    auto take = [&]() {
-        const unsigned int t = fixed_t;
-        fixed_t += GAT_WAVES;
-        return (unsigned int)share * GAT_WAVES + (t & (GAT_WAVES - 1)) + (t / GAT_WAVES) * stride;
-    };
-#else
     // Tickets are taken FOUR at a time (one LDS atomic and its round trip per four steps instead of one per step; round 3): a
     // wavefront's four steps are then the four quartile groups of one tile, short records and long.
     unsigned int ticket_base = 0, ticket_used = 4;
@@ -1145,7 +1128,6 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         const unsigned int t = ticket_base + ticket_used++;
         return (unsigned int)share * GAT_WAVES + (t & (GAT_WAVES - 1)) + (t / GAT_WAVES) * stride;
     };
-#endif
     // position of this lane's record (tile * 64 + rank in the sorted tile)
     auto rec_pos = [&](unsigned int g) {
         const unsigned int group = the_group(g);
@@ -1209,9 +1191,6 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         cmax = max(cmax, (unsigned int)__builtin_amdgcn_readlane((int)c, 31));
         cmax = max(cmax, (unsigned int)__builtin_amdgcn_readlane((int)c, 15));
         const unsigned int mask7 = short_records(G) ? 0xFFFFu : ~0u;          // uniform
-#ifdef GAT_EXP_NOLOOKUP
-        cmax = 0;
-#endif
         switch ((cmax + 1u) >> 1) {
             case 0: break;
             case 1: lookup_halves<1>(part_base, R, mask7, nullpair, X); break;

@@ -52,8 +52,17 @@ def rccl_comm(group=None, ctx=None):
     if not (dist.is_available() and dist.is_initialized()):
         return None
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    box = [_native.Comm.unique_id() if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        # the id, or the reason there is none (librccl does not load here): every rank must hear of it, or the others would
+        # sit in the broadcast for ever
+        try:
+            box[0] = _native.Comm.unique_id()
+        except _native.GF2Error as err:
+            box[0] = (err.code, err.message)
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    if not isinstance(box[0], bytes):
+        raise _native.GF2Error(*box[0])                     # on every rank alike
     return _native.Comm(ctx or _native.default_context(), box[0], world, rank)
 
 

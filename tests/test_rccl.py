@@ -10,6 +10,7 @@ import json
 import os
 import socket
 import subprocess
+import time
 import sys
 
 import numpy as np
@@ -27,7 +28,13 @@ def free_port():
 
 
 def test_rccl_loads_through_the_abi():
-    assert _native.rccl_version() >= 20000                 # NCCL-style version number, e.g. 22707
+    try:
+        version = _native.rccl_version()
+    except _native.GF2Error as err:                        # a CPU box without ROCm's librccl: nothing to load
+        if err.code == _native.GF2_E_RCCL:
+            pytest.skip("librccl cannot be loaded here: %s" % err.message)
+        raise
+    assert version >= 20000                                # NCCL-style version number, e.g. 22707
     with open("/proc/self/maps") as maps:
         assert "librccl" in maps.read()
 
@@ -109,6 +116,18 @@ keep, _native.Comm = _native.Comm, Broken
 comm, note = bench.guarded_comm(ctx, 4097)
 _native.Comm = keep
 assert comm is None and "refused" in note, note
+if os.environ.get("CHILD_STUCK_COMM"):
+    # the TIMEOUT branch: a communicator that does not come up within the limit.  The helper thread is then inside RCCL for good, so
+    # guarded_comm must not return: reason on stderr, flush, os._exit(3) -- nothing below runs
+    import time
+    class Stuck(_native.Comm):
+        def __init__(self, *a):
+            time.sleep(3600)
+    _native.Comm = Stuck
+    print("about to hang", flush=True)
+    bench.guarded_comm(ctx, 4097, seconds=2.0)
+    print("guarded_comm returned from a stuck communicator")
+    sys.exit(0)
 dist.destroy_process_group()
 maps = open("/proc/self/maps").read()
 assert "librccl" in maps and "libgf2hip.so" in maps
@@ -126,6 +145,81 @@ def test_world_size_one_nccl_process_group_in_a_child_process(tmp_path):
                           timeout=600, text=True)
     assert done.returncode == 0, done.stderr[-3000:]
     assert "nccl child ok 200001" in done.stdout
+
+
+@pytest.mark.gpu
+def test_guarded_comm_leaves_the_process_when_the_communicator_never_comes_up(tmp_path):
+    # on timeout the rank must END within a bound (the helper thread stays inside RCCL), by an exit, with
+    # what it had printed flushed
+    script = tmp_path / "nccl_child_stuck.py"
+    script.write_text(NCCL_CHILD % {"root": ROOT})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), GF2_DEVICE="0", CHILD_STUCK_COMM="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t0 = time.monotonic()
+    done = subprocess.run([sys.executable, str(script)], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=600, text=True)
+    assert done.returncode == 3, (done.returncode, done.stderr[-3000:])
+    assert "about to hang" in done.stdout and "returned from a stuck" not in done.stdout
+    assert "not back within 2 s" in done.stderr
+    assert time.monotonic() - t0 < 300
+
+
+@pytest.mark.gpu
+def test_bench_with_its_own_communicator_and_without_when_it_never_comes_up():
+    # `--allreduce gf2` with the one rank a single GPU has: the supervising launcher starts the rank, the communicator is proven and
+    # used for the histogram sum.  Then the same with a communicator that hangs (BENCH_FAULT): the rank leaves with code 3 after
+    # --comm-timeout, the launcher starts a fresh one with --allreduce torch, ONE line comes out and the exit code is 0
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GF2_DEVICE"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--allreduce", "gf2", "--comm-timeout", "3", "--steps", "2",
+           "--warmup", "1", "--batch-log2", "17", "--no-cpu-baseline", "--no-secondary", "--no-settle"]
+    done = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert done.returncode == 0, done.stderr[-3000:]
+    assert bench_line(done)["checks"]["histogram_total"] == 2 << 17
+    t0 = time.monotonic()
+    done = subprocess.run(cmd, cwd=ROOT, env=dict(env, BENCH_FAULT="comm_timeout"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=600, text=True)
+    assert done.returncode == 0, done.stderr[-3000:]
+    assert bench_line(done)["checks"]["histogram_total"] == 2 << 17
+    assert "not back within 3 s" in done.stderr and "fresh ranks with --allreduce torch" in done.stderr
+    assert time.monotonic() - t0 < 300
+
+
+def children_of(pid):
+    import psutil
+    try:
+        return psutil.Process(pid).children(recursive=True)
+    except psutil.NoSuchProcess:
+        return []
+
+
+@pytest.mark.parametrize("how", ["sigterm", "deadline"])
+def test_self_launched_ranks_do_not_outlive_the_launcher(how):
+    # ranks that ignore SIGTERM (BENCH_FAULT=hang: what a rank inside RCCL looks like) must be gone when the launcher is --
+    # whether it is told to stop or its own deadline passes (no GPU needed: the ranks hang before they touch one)
+    import signal
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_FAULT"] = "hang"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + (["--launch-deadline", "2"] if how == "deadline" else [])
+    proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    kids = []
+    for _ in range(100):
+        time.sleep(0.1)
+        kids = children_of(proc.pid)
+        if len(kids) >= 2:
+            break
+    assert len(kids) >= 2, "the launcher did not start its two ranks"
+    if how == "sigterm":
+        time.sleep(0.5)
+        proc.send_signal(signal.SIGTERM)
+    try:
+        _, err = proc.communicate(timeout=60)
+    finally:
+        if proc.poll() is None:
+            proc.kill()
+    assert proc.returncode == (128 + signal.SIGTERM if how == "sigterm" else 124), (proc.returncode, err[-2000:])
+    for kid in kids:
+        assert not kid.is_running() or kid.status() == "zombie", "rank %d outlived the launcher" % kid.pid
 
 
 def bench_line(done):
