@@ -829,8 +829,9 @@ def main():
             plain.kernel = "syndrome_sparse_kernel"
             gather = {"value": 10 * sec / (g_ms / 1e3), "unit": "syndromes/s", "ms_per_step": g_ms / 10,
                       "roofline": roofline(plain, g_launch, g_n)}
-            # SURVEY.md 8d's read + write variant: the same kernel with the syndromes stored, 1536 B per sample
-            # (2 x 512 read, 256 + 255.9 written) instead of 1024 read
+            # SURVEY.md 8d's read + write variant: the same pipeline with the syndromes stored (every gather workgroup its slab's
+            # 64-byte piece; round 3 went to the column-gather kernel for this), 1536 B per sample (2 x 512 read, 256 + 255.9
+            # written) instead of 1024 read
             s1, s2 = ctx.alloc(sec * plain.ls1 * 8), ctx.alloc(sec * plain.ls2 * 8)
             lde = _native.words_for(N_QUBITS)
             for _ in range(2):
@@ -849,7 +850,7 @@ def main():
             rw_bytes = sec * (2 * N_QUBITS / 8.0 + (R1 + R2) / 8.0)
             stored = {"value": sec / (rw_ms / 1e3), "unit": "syndromes/s", "ms_per_step": rw_ms,
                       "bytes_per_syndrome": 2 * N_QUBITS / 8.0 + (R1 + R2) / 8.0,
-                      "roofline": {"bound": "hbm", "kernel": "syndrome_sparse_kernel (syndromes stored)", "achieved": rw_bytes / rw_ms / 1e6,
+                      "roofline": {"bound": "hbm", "kernel": "slab_pipeline (syndromes stored, no histogram)", "achieved": rw_bytes / rw_ms / 1e6,
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rw_bytes / rw_ms / 1e6 / HBM_PEAK_GBS}}
             s1.free(), s2.free()
             plain.free()

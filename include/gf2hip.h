@@ -205,6 +205,18 @@ int gf2_syndrome_table_wide(gf2_ctx* ctx, const uint64_t* h_rows, int64_t r, int
 int gf2_syndrome_table_cols(gf2_ctx* ctx, const uint64_t* h_rows, int64_t r, int64_t n, int64_t ld, int64_t max_weight,
                             uint64_t* table_out, int64_t* t_out, int64_t* entries_out);
 
+/* The same search beyond 24 checks [SURVEY.md 8f item 2: a k = 1 CSS code has r_1 + r_2 = n - 1, so from n = 51 on one of its
+ * checks has more than 24 rows]: an open-addressing hash table on the device, sized from the weight classes it holds instead
+ * of 2^r.  1 <= r <= 127, 1 <= n <= 8192, h_rows: r packed rows of ld words.  Keys are vec_to_int(syndrome) exactly (row 0 =
+ * most significant bit): one word per entry for r <= 63, two (low word first) for 64 <= r <= 127 -- the reference's own keys
+ * wrap beyond 63 bits (bin_matrix.py:40-43).  Output: *entries_out entries (the classes 0 .. t), in no particular order --
+ * keys_out (1 or 2 words each) and vals_out = (weight << 32) | rank in the class (combinatorial number system, as above); they
+ * are written only if capacity >= *entries_out (call again with larger buffers otherwise; capacity 0 just counts).  At most
+ * 2^28 errors are enumerated in all: GF2_E_NOMEM if no collision has shown by then and max_weight (>= 0) does not stop the
+ * search earlier. */
+int gf2_syndrome_table_hashed(gf2_ctx* ctx, const uint64_t* h_rows, int64_t r, int64_t n, int64_t ld, int64_t max_weight,
+                              uint64_t* keys_out, uint64_t* vals_out, int64_t capacity, int64_t* t_out, int64_t* entries_out);
+
 /* css_code.transform_stabilisers (css_code.py:737-781) [SURVEY.md 8f item 3].  mat: k rows of ld words holding the k x 2n
  * stabiliser matrix [X | Z] (column j = bit j), rewritten in place.  gates: ngates rows of three int32 (kind, a, b):
  * kind 0 = H on qubit a (conjugate_h_with_check_mat, :757-767), kind 1 = CNOT control a target b
@@ -251,10 +263,12 @@ int gf2_syndrome_dev(gf2_ctx* ctx, const gf2_check* check, const uint64_t* e_dev
  * sample-major syndromes (s_dev, batch x lds; may be null) and/or accumulates the syndrome-weight histogram (hist_dev
  * with r+1 uint64 bins; may be null) without materialising the syndromes.  Identical results to gf2_syndrome_dev;
  * faster when errors are sparse (DESIGN.md gives the crossover).  Fails for small checks (n, r <= 64) and r > 8192.
- * Three implementations behind it: histogram-only batches of at least 32768 samples on a check
- * with r <= 2048 and n - r <= 2400 take the LDS row-slab pipeline (compact -> gather -> combine, plus a redo pass for
- * columns left out of the records); checks with n <= 512 and r <= 256 the lane-per-sample kernel; everything else one
- * wavefront per sample gathering columns of the transposed check from L2. */
+ * Three implementations behind it: batches of at least 32768 samples on a check with r <= 2048 and
+ * n - r <= 2400 take the LDS row-slab pipeline (compact -> gather -> combine, plus a redo pass for columns left out of the
+ * records), with or without syndromes stored (since round 4 every gather workgroup stores its slab's 64-byte piece); checks
+ * with n <= 512 and r <= 256 the lane-per-sample kernel; everything else one wavefront per sample gathering columns of the
+ * transposed check from L2.  Words of a syndrome row past ceil(r/64) (lds larger than needed) are either left as they were
+ * or zeroed. */
 int gf2_syndrome_sparse_dev(gf2_ctx* ctx, const gf2_check* check, const uint64_t* e_dev, int64_t batch, int64_t lde,
                             uint64_t* s_dev, int64_t lds, uint64_t* hist_dev, int64_t nbins);
 
@@ -299,6 +313,17 @@ int gf2_mc_decode(gf2_ctx* ctx, const gf2_check* check_c1, const gf2_check* chec
                   const uint64_t* table_c1, const uint64_t* table_c2, uint64_t x_operator, uint64_t z_operator,
                   uint64_t seed, int64_t first_sample, int64_t count, double p_x, double p_y, double p_z,
                   uint64_t* counts_out);
+
+/* The same tally for codes of up to 128 qubits through hashed tables [SURVEY.md 8f item 1 for the mid-size codes of item 2]:
+ * checks of up to 127 rows, tables given by their entries instead of 2^r dense words.  h1 / h2: packed rows (ld words each) of
+ * parity_check_c1 / parity_check_c2; keys: vec_to_int(syndrome) of every table entry, one word each for r <= 63 and two (low
+ * word first) beyond; corr: the entry's packed error, two words; x_operator / z_operator: two words each.  counts_out[5] as
+ * above.  GF2_E_ARG if a key occurs twice. */
+int gf2_mc_decode_hashed(gf2_ctx* ctx, int64_t n, int64_t ld, const uint64_t* h1, int64_t r1, const uint64_t* keys1,
+                         const uint64_t* corr1, int64_t entries1, const uint64_t* h2, int64_t r2, const uint64_t* keys2,
+                         const uint64_t* corr2, int64_t entries2, const uint64_t* x_operator, const uint64_t* z_operator,
+                         uint64_t seed, int64_t first_sample, int64_t count, double p_x, double p_y, double p_z,
+                         uint64_t* counts_out);
 
 /* ---- multi-GPU: the histogram all-reduce -------------------------------------------------------------
  * [build-defined, SURVEY.md 8e]  The Monte-Carlo run shards by sample range (sample i = f(seed, i)); ranks never exchange

@@ -34,6 +34,9 @@ def lib():
             "orc_histogram": [_p, _i64, _i64, _i64, ctypes.c_int, _p],
             "orc_sample_errors": [_i64, _u64, _i64, _i64, _dbl, _dbl, _dbl, _p, _p, _i64],
             "orc_mc_decode": [_p, _i64, _p, _i64, _i64, _p, _p, _u64, _u64, _u64, _i64, _i64, _dbl, _dbl, _dbl, _p],
+            "orc_syndrome_table": [_p, _i64, _i64, _i64, _i64, _i64, _p, _p, _i64, _p, _p],
+            "orc_mc_decode_wide": [_p, _i64, _p, _i64, _i64, _i64, _p, _p, _i64, _p, _p, _i64, _p, _p, _u64, _i64, _i64, _dbl, _dbl,
+                                   _dbl, _p],
             "orc_mc": [_p, _i64, _i64, _p, _i64, _i64, _i64, _u64, _i64, _i64, _dbl, _dbl, _dbl, ctypes.c_int,
                        _p, _i64, _p, _i64],
         }
@@ -137,4 +140,53 @@ def mc_decode(h1, r1, h2, r2, n, t1, t2, xop, zop, seed, first, count, p_x, p_y,
     counts = np.zeros(5, dtype=np.uint64)
     lib().orc_mc_decode(_ptr(h1), r1, _ptr(h2), r2, n, _ptr(t1), _ptr(t2), int(xop), int(zop), seed & 0xFFFFFFFFFFFFFFFF,
                         first, count, p_x, p_y, p_z, _ptr(counts))
+    return counts
+
+
+def syndrome_table(h, r, n, max_weight=None):
+    """css_code.syndrome_table (css_code.py:715-735) on packed rows h (r x ld), r <= 128.  Returns (t, keys, errors): keys as
+    Python ints in the reference's insertion order, errors as packed rows (entries x ld)."""
+    h = np.ascontiguousarray(h, dtype="<u8")
+    lde = max(1, words_for(n))
+    cap = 1 << 12
+    while True:
+        keys = np.zeros((cap, 2), dtype="<u8")
+        errs = np.zeros((cap, lde), dtype="<u8")
+        t, entries = _i64(), _i64()
+        rc = lib().orc_syndrome_table(_ptr(h), r, n, h.shape[1], -1 if max_weight is None else max_weight, cap, _ptr(keys), _ptr(errs),
+                                      lde, ctypes.byref(t), ctypes.byref(entries))
+        assert rc == 0, rc
+        if entries.value <= cap:
+            break
+        cap = int(entries.value)
+    count = int(entries.value)
+    return int(t.value), [int(lo) | (int(hi) << 64) for lo, hi in keys[:count].tolist()], errs[:count]
+
+
+def mc_decode_wide(h1, r1, h2, r2, n, keys1, corr1, keys2, corr2, xop, zop, seed, first, count, p_x, p_y, p_z):
+    """Table decode + logical tally for n <= 128: tables as (keys: Python ints, corr: packed errors, entries x ld)."""
+    ld = max(1, words_for(n))
+    h1 = np.ascontiguousarray(h1, dtype="<u8").reshape(r1, ld)
+    h2 = np.ascontiguousarray(h2, dtype="<u8").reshape(r2, ld)
+
+    def two(keys):
+        out = np.zeros((len(keys), 2), dtype="<u8")
+        for i, k in enumerate(keys):
+            out[i, 0], out[i, 1] = int(k) & 0xFFFFFFFFFFFFFFFF, int(k) >> 64
+        return out
+
+    def corr2words(c):
+        out = np.zeros((len(c), 2), dtype="<u8")
+        c = np.asarray(c, dtype="<u8").reshape(len(c), -1)
+        out[:, :c.shape[1]] = c[:, :2]
+        return out
+    k1, k2, c1, c2 = two(keys1), two(keys2), corr2words(corr1), corr2words(corr2)
+    ops = [np.zeros(2, dtype="<u8") for _ in range(2)]
+    for o, src in zip(ops, (xop, zop)):
+        src = np.asarray(src, dtype="<u8").reshape(-1)
+        o[:src.size] = src[:2]
+    counts = np.zeros(5, dtype=np.uint64)
+    rc = lib().orc_mc_decode_wide(_ptr(h1), r1, _ptr(h2), r2, n, ld, _ptr(k1), _ptr(c1), len(k1), _ptr(k2), _ptr(c2), len(k2),
+                                  _ptr(ops[0]), _ptr(ops[1]), seed & 0xFFFFFFFFFFFFFFFF, first, count, p_x, p_y, p_z, _ptr(counts))
+    assert rc == 0, rc
     return counts

@@ -297,3 +297,195 @@ int orc_mc_decode(const u64* h1, int64_t r1, const u64* h2, int64_t r2, int64_t 
     }
     return 0;
 }
+
+/* ---- syndrome_table (css_code.py:715-735) on packed words, for checks of up to 128 rows --------------------------------------
+ * for w = 0, 1, 2, ...: every error of weight w in bin_matrix.weight_w_vectors order (bin_matrix.py:57-72: supports ascending
+ * lexicographically), key = vec_to_int(H e mod 2) (bin_matrix.py:36-43: row 0 is the most significant bit; exact here, two
+ * words, where the reference's int64 wraps beyond 63 bits); a key seen before -- in an earlier class or earlier in this one --
+ * ends the search: return w - 1 and the entries of the classes before w (css_code.py:730-731).  No collision: t = n.
+ * max_weight >= 0 [build-defined cap]: stop before class max_weight + 1 with t = max_weight.
+ * Outputs in insertion order: keys_out[2 i], keys_out[2 i + 1] = low / high word of entry i's key, errs_out[i * lde ..] its
+ * packed error; at most `capacity` entries are written (*entries_out says how many there are).  Returns 0. */
+static u64 mixkey(u64 lo, u64 hi) {
+    u64 z = lo ^ (hi * 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+typedef struct {
+    u64 *lo, *hi;
+    unsigned char* used;
+    u64 slots, count;
+} keyset;
+
+static int keyset_init(keyset* s, u64 slots) {
+    s->lo = (u64*)malloc(slots * 8);
+    s->hi = (u64*)malloc(slots * 8);
+    s->used = (unsigned char*)calloc(slots, 1);
+    s->slots = slots;
+    s->count = 0;
+    return s->lo && s->hi && s->used ? 0 : -1;
+}
+static void keyset_free(keyset* s) {
+    free(s->lo);
+    free(s->hi);
+    free(s->used);
+}
+static int keyset_has(const keyset* s, u64 lo, u64 hi) {
+    for (u64 at = mixkey(lo, hi) & (s->slots - 1); s->used[at]; at = (at + 1) & (s->slots - 1))
+        if (s->lo[at] == lo && s->hi[at] == hi) return 1;
+    return 0;
+}
+static void keyset_put(keyset* s, u64 lo, u64 hi) {
+    u64 at = mixkey(lo, hi) & (s->slots - 1);
+    while (s->used[at]) at = (at + 1) & (s->slots - 1);
+    s->used[at] = 1;
+    s->lo[at] = lo;
+    s->hi[at] = hi;
+    s->count += 1;
+}
+static int keyset_grow(keyset* s) {
+    keyset bigger;
+    if (keyset_init(&bigger, s->slots * 2)) return -1;
+    for (u64 at = 0; at < s->slots; ++at)
+        if (s->used[at]) keyset_put(&bigger, s->lo[at], s->hi[at]);
+    keyset_free(s);
+    *s = bigger;
+    return 0;
+}
+
+int orc_syndrome_table(const u64* h, int64_t r, int64_t n, int64_t ld, int64_t max_weight, int64_t capacity, u64* keys_out,
+                       u64* errs_out, int64_t lde, int64_t* t_out, int64_t* entries_out) {
+    if (r > 128 || r < 0 || n < 0) return -1;
+    /* column keys: bit r - 1 - i of column j = H[i][j] */
+    u64* ck = (u64*)calloc((size_t)(n > 0 ? n : 1) * 2, 8);
+    for (int64_t i = 0; i < r; ++i) {
+        const int64_t b = r - 1 - i;
+        for (int64_t j = 0; j < n; ++j)
+            if (bit(h + i * ld, j)) ck[2 * j + (b >> 6)] |= 1ull << (b & 63);
+    }
+    keyset all, layer;
+    if (keyset_init(&all, 1024) || keyset_init(&layer, 1024)) return -2;
+    int64_t* sup = (int64_t*)malloc((size_t)(n + 1) * sizeof(int64_t));
+    int64_t entries = 0, t = n;
+    for (int64_t w = 0; w <= n; ++w) {
+        if (max_weight >= 0 && w > max_weight) {
+            t = max_weight;
+            break;
+        }
+        /* the class's keys go into `layer` first: a collision discards the class as a whole */
+        memset(layer.used, 0, layer.slots);
+        layer.count = 0;
+        const int64_t first_entry = entries;
+        int collided = 0;
+        for (int64_t k = 0; k < w; ++k) sup[k] = k;                 /* first support in lexicographic order */
+        for (;;) {
+            u64 lo = 0, hi = 0;
+            for (int64_t k = 0; k < w; ++k) {
+                lo ^= ck[2 * sup[k]];
+                hi ^= ck[2 * sup[k] + 1];
+            }
+            if (keyset_has(&all, lo, hi) || keyset_has(&layer, lo, hi)) {
+                collided = 1;
+                break;
+            }
+            if ((layer.count + 1) * 2 > layer.slots && keyset_grow(&layer)) return -2;
+            keyset_put(&layer, lo, hi);
+            if (entries < capacity) {
+                keys_out[2 * entries] = lo;
+                keys_out[2 * entries + 1] = hi;
+                memset(errs_out + entries * lde, 0, (size_t)lde * 8);
+                for (int64_t k = 0; k < w; ++k) errs_out[entries * lde + (sup[k] >> 6)] |= 1ull << (sup[k] & 63);
+            }
+            entries += 1;
+            /* next support, ascending lexicographically: the last position that can still move up does, the ones behind it follow */
+            int64_t k = w - 1;
+            while (k >= 0 && sup[k] == n - w + k) --k;
+            if (k < 0) break;
+            sup[k] += 1;
+            for (int64_t q = k + 1; q < w; ++q) sup[q] = sup[q - 1] + 1;
+        }
+        if (collided) {
+            entries = first_entry;
+            t = w - 1;
+            break;
+        }
+        for (u64 at = 0; at < layer.slots; ++at)
+            if (layer.used[at]) {
+                if ((all.count + 1) * 2 > all.slots && keyset_grow(&all)) return -2;
+                keyset_put(&all, layer.lo[at], layer.hi[at]);
+            }
+    }
+    keyset_free(&all);
+    keyset_free(&layer);
+    free(sup);
+    free(ck);
+    *t_out = t;
+    *entries_out = entries;
+    return 0;
+}
+
+/* [build-defined, SURVEY.md 8f item 1] orc_mc_decode for codes of up to 128 qubits and checks of up to 128 rows, the tables given
+ * by their entries (keys: two words each, low first; corr: two words each) as orc_syndrome_table returns them.  Same rules:
+ * css_code.py:655-657 (no entry: the error stays), css_code.py:640-646 (logical flips).  h1 / h2: packed rows of ld words;
+ * xop / zop: two words each.  counts[5] as in include/gf2hip.h, overwritten. */
+int orc_mc_decode_wide(const u64* h1, int64_t r1, const u64* h2, int64_t r2, int64_t n, int64_t ld, const u64* keys1,
+                       const u64* corr1, int64_t entries1, const u64* keys2, const u64* corr2, int64_t entries2, const u64* xop,
+                       const u64* zop, u64 seed, int64_t first, int64_t count, double p_x, double p_y, double p_z, u64* counts) {
+    if (n > 128 || ld > 2 || ld < 1) return -1;
+    for (int k = 0; k < 5; ++k) counts[k] = 0;
+    /* index of each table: slot -> entry + 1 */
+    const u64* keys[2] = {keys2, keys1};                            /* side 0: X errors against h2, side 1: Z errors against h1 */
+    const u64* corr[2] = {corr2, corr1};
+    const int64_t ents[2] = {entries2, entries1};
+    const u64* hs[2] = {h2, h1};
+    const int64_t rs[2] = {r2, r1};
+    const u64* ops[2] = {zop, xop};
+    u64 slots[2];
+    int64_t* index[2];
+    for (int c = 0; c < 2; ++c) {
+        slots[c] = 1024;
+        while (slots[c] < (u64)ents[c] * 2 + 2) slots[c] <<= 1;
+        index[c] = (int64_t*)calloc(slots[c], sizeof(int64_t));
+        for (int64_t i = 0; i < ents[c]; ++i) {
+            u64 at = mixkey(keys[c][2 * i], keys[c][2 * i + 1]) & (slots[c] - 1);
+            while (index[c][at]) at = (at + 1) & (slots[c] - 1);
+            index[c][at] = i + 1;
+        }
+    }
+    for (int64_t i = 0; i < count; ++i) {
+        u64 e[2][2] = {{0, 0}, {0, 0}};
+        orc_sample_errors(n, seed, first + i, 1, p_x, p_y, p_z, e[0], e[1], ld);
+        int flip[2], miss[2];
+        for (int c = 0; c < 2; ++c) {
+            u64 lo = 0, hi = 0;                                     /* vec_to_int of the syndrome: row 0 most significant */
+            for (int64_t k = 0; k < rs[c]; ++k) {
+                int par = 0;
+                for (int64_t w = 0; w < ld; ++w) par ^= __builtin_popcountll(hs[c][k * ld + w] & e[c][w]) & 1;
+                const int64_t b = rs[c] - 1 - k;
+                if (par) { if (b >> 6) hi |= 1ull << (b & 63); else lo |= 1ull << (b & 63); }
+            }
+            int64_t found = 0;
+            for (u64 at = mixkey(lo, hi) & (slots[c] - 1); index[c][at]; at = (at + 1) & (slots[c] - 1)) {
+                const int64_t ent = index[c][at] - 1;
+                if (keys[c][2 * ent] == lo && keys[c][2 * ent + 1] == hi) { found = ent + 1; break; }
+            }
+            miss[c] = found == 0;
+            u64 res[2] = {e[c][0], e[c][1]};
+            if (found) {
+                res[0] ^= corr[c][2 * (found - 1)];
+                res[1] ^= corr[c][2 * (found - 1) + 1];
+            }
+            flip[c] = (__builtin_popcountll(ops[c][0] & res[0]) + __builtin_popcountll(ops[c][1] & res[1])) & 1;
+        }
+        counts[0] += (u64)flip[0];
+        counts[1] += (u64)flip[1];
+        counts[2] += (u64)(flip[0] | flip[1]);
+        counts[3] += (u64)miss[0];
+        counts[4] += (u64)miss[1];
+    }
+    free(index[0]);
+    free(index[1]);
+    return 0;
+}

@@ -83,6 +83,7 @@ SIGNATURES = {
     "gf2_syndrome_table": [_p, _p, _c_i64, _c_i64, _c_i64, _p, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)],
     "gf2_syndrome_table_wide": [_p, _p, _c_i64, _c_i64, _c_i64, _p, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)],
     "gf2_syndrome_table_cols": [_p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _p, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)],
+    "gf2_syndrome_table_hashed": [_p, _p, _c_i64, _c_i64, _c_i64, _c_i64, _p, _p, _c_i64, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)],
     "gf2_check_create": [_p, _p, _c_i64, _c_i64, _c_i64, _pp],
     "gf2_check_destroy": [_p, _p],
     "gf2_syndrome_batch": [_p, _p, _c_i64, _c_i64, _c_i64, _p, _c_i64, _c_i64, ctypes.c_int, _p, _c_i64],
@@ -96,6 +97,8 @@ SIGNATURES = {
     "gf2_retile_dev": [_p, _p, _c_i64, _c_i64, _c_i64, _p],
     "gf2_mc_decode": [_p, _p, _p, _p, _p, _c_u64, _c_u64, _c_u64, _c_i64, _c_i64, ctypes.c_double, ctypes.c_double,
                       ctypes.c_double, _p],
+    "gf2_mc_decode_hashed": [_p, _c_i64, _c_i64, _p, _c_i64, _p, _p, _c_i64, _p, _c_i64, _p, _p, _c_i64, _p, _p, _c_u64, _c_i64, _c_i64,
+                             ctypes.c_double, ctypes.c_double, ctypes.c_double, _p],
     "gf2_mc_run": [_p, _p, _p, _c_u64, _c_i64, _c_i64, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                    ctypes.c_int, _p, _c_i64, _p, _c_i64],
     "gf2_comm_unique_id": [_p, ctypes.c_size_t],
@@ -534,6 +537,44 @@ class Context(object):
                                             -1 if max_weight is None else max_weight, _ptr(dense), ctypes.byref(t),
                                             ctypes.byref(entries)))
         return int(t.value), dense
+
+    TABLE_HASH_MAX_R, TABLE_HASH_MAX_N = 127, 8192
+
+    def syndrome_table_hashed(self, packed, r, n, max_weight=None):
+        """css_code.syndrome_table beyond 24 checks (1 <= r <= 127, n <= 8192): a hash table on the device.  Returns
+        (t, keys, weights, ranks): keys as a uint64 array (r <= 63) or a list of Python ints (two-word keys), the entries'
+        weights and their ranks inside their weight class (unrank with unrank_supports), in no particular order."""
+        rows = np.ascontiguousarray(packed, dtype="<u8")
+        kw = 1 if r <= 63 else 2
+        cap = 1 << 16
+        t, entries = _c_i64(), _c_i64()
+        while True:
+            keys = np.empty((cap, kw), dtype="<u8")
+            vals = np.empty(cap, dtype="<u8")
+            check(lib().gf2_syndrome_table_hashed(self.handle, _ptr(rows), r, n, rows.shape[1], -1 if max_weight is None else max_weight,
+                                                  _ptr(keys), _ptr(vals), cap, ctypes.byref(t), ctypes.byref(entries)))
+            if entries.value <= cap:
+                break
+            cap = int(entries.value)                    # (the search runs once more: the classes were counted, not kept)
+        count = int(entries.value)
+        keys, vals = keys[:count], vals[:count]
+        weights = (vals >> np.uint64(32)).astype(np.int64)
+        ranks = vals & np.uint64(0xFFFFFFFF)
+        if kw == 1:
+            return int(t.value), keys[:, 0].copy(), weights, ranks
+        return int(t.value), [int(lo) | (int(hi) << 64) for lo, hi in keys.tolist()], weights, ranks
+
+    def mc_decode_hashed(self, n, h1, r1, keys1, corr1, h2, r2, keys2, corr2, x_operator, z_operator, seed, first, count,
+                         p_x, p_y, p_z):
+        """gf2_mc_decode_hashed: h1 / h2 packed rows (ld words), keys (entries x 1 or 2 words), corr (entries x 2 words),
+        operators (2 words).  Returns the five counts."""
+        h1, h2 = np.ascontiguousarray(h1, dtype="<u8"), np.ascontiguousarray(h2, dtype="<u8")
+        arrays = [np.ascontiguousarray(a, dtype="<u8") for a in (keys1, corr1, keys2, corr2, x_operator, z_operator)]
+        counts = np.zeros(5, dtype=np.uint64)
+        check(lib().gf2_mc_decode_hashed(self.handle, n, h1.shape[1], _ptr(h1), r1, _ptr(arrays[0]), _ptr(arrays[1]), len(arrays[1]),
+                                         _ptr(h2), r2, _ptr(arrays[2]), _ptr(arrays[3]), len(arrays[3]), _ptr(arrays[4]),
+                                         _ptr(arrays[5]), seed & 0xFFFFFFFFFFFFFFFF, first, count, p_x, p_y, p_z, _ptr(counts)))
+        return counts
 
     # -- syndromes ----------------------------------------------------------------------------------------
     def check_create(self, packed, r, n):

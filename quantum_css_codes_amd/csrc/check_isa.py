@@ -2,13 +2,13 @@
 """
 Build-time guard for the hand-scheduled kernels of gf2_slabs.hip (run by `make`, see Makefile: build/slabs_isa.ok).
 
-slab_compact_kernel<T> and slab_gather_fast_kernel<EXTRA, CROSS> issue their loads through inline assembly and wait with hand-counted
+slab_compact_kernel<T> and slab_gather_fast_kernel<EXTRA, CROSS, SYN> issue their loads through inline assembly and wait with hand-counted
 `s_waitcnt vmcnt(N)`.  The compiler neither sees those loads nor knows that their destination registers are still being filled,
 so two things must hold in the generated code, and a compiler upgrade or an innocent edit can break either:
 
   1. Counts.  Vector memory operations complete in order; `vmcnt(N)` is right only if exactly the assumed operations are issued
      between two counted waits.  Checked: in the gather kernel's step loop every counted wait is followed by exactly
-     1 store + 1 record load + 1 identity load (+ 1 for EXTRA) before the next one; in the compact kernel every sub-pass issues
+     1 store (2 with SYN: the syndrome piece) + 1 record load + 1 identity load (+ 1 for EXTRA) before the next one; in the compact kernel every sub-pass issues
      exactly T loads between counted waits (plus the tile's 4 record stores once per tile); no scratch (spill) traffic at all.
   2. Registers in flight.  Between a load's issue and the wait that covers it no instruction may read or write its destination
      registers (DESIGN.md section 3 records a compiler-placed v_mov of such a register that produced wrong syndromes).
@@ -22,10 +22,14 @@ import re
 import sys
 
 KERNELS = {
-    "slab_gather_fast_kernelILb0ELb0E": {"step_vmem": 3, "wait": 3},
-    "slab_gather_fast_kernelILb0ELb1E": {"step_vmem": 3, "wait": 3},
-    "slab_gather_fast_kernelILb1ELb0E": {"step_vmem": 4, "wait": 4},
-    "slab_gather_fast_kernelILb1ELb1E": {"step_vmem": 4, "wait": 4},
+    # <EXTRA, CROSS, SYN>: operations per step = stores (the partial weight; SYN: and the syndrome piece) + loads (record, identity
+    # words; EXTRA: and the fifth dword)
+    "slab_gather_fast_kernelILb0ELb0ELb0E": {"step_vmem": 3, "wait": 3, "stores": 1},
+    "slab_gather_fast_kernelILb0ELb1ELb0E": {"step_vmem": 3, "wait": 3, "stores": 1},
+    "slab_gather_fast_kernelILb1ELb0ELb0E": {"step_vmem": 4, "wait": 4, "stores": 1},
+    "slab_gather_fast_kernelILb1ELb1ELb0E": {"step_vmem": 4, "wait": 4, "stores": 1},
+    "slab_gather_fast_kernelILb0ELb0ELb1E": {"step_vmem": 4, "wait": 4, "stores": 2},
+    "slab_gather_fast_kernelILb1ELb0ELb1E": {"step_vmem": 5, "wait": 5, "stores": 2},
     "slab_compact_kernelILi4ELb0E": {"rounds": 4},
     "slab_compact_kernelILi4ELb1E": {"rounds": 4},
     "slab_compact_kernelILi5ELb0E": {"rounds": 5},
@@ -134,9 +138,9 @@ def check_counts(name, stream, spec, errors):
             between = [text.split()[0] for _, text, _ in ops[a:b] if VMEM.match(text.split()[0])]
             stores = sum(1 for o in between if "_store" in o)
             loads = sum(1 for o in between if "_load" in o)
-            if (stores, loads) != (1, spec["step_vmem"] - 1):
-                errors.add("%s line %d: a step issues %d stores and %d loads, the wait counts assume 1 and %d"
-                              % (name, ops[a][0], stores, loads, spec["step_vmem"] - 1))
+            if (stores, loads) != (spec["stores"], spec["step_vmem"] - spec["stores"]):
+                errors.add("%s line %d: a step issues %d stores and %d loads, the wait counts assume %d and %d"
+                              % (name, ops[a][0], stores, loads, spec["stores"], spec["step_vmem"] - spec["stores"]))
     else:
         rounds = spec["rounds"]
         loads_between = []

@@ -1186,87 +1186,211 @@ __global__ void nullspace_kernel(const u64* __restrict__ red, int64_t n, int64_t
 
 // ---- RREF of small matrices, one wavefront per matrix --------------------------------------------------------------------
 //
-// Up to 64 * RPL rows of up to 64 * LD columns: lane l holds rows l, l + 64, ... in registers (RPL rows of LD words).  The
+// Up to 64 * RPL rows of up to 64 * LD columns: lane l holds rows l, l + 64, ... in registers (RPL rows of 2 LD dwords).  The
 // columns are walked left to right; a column that still has a 1 in an unused row gets that row as its pivot (the RREF
-// does not depend on which one: the lowest lane of the lowest register row here), the pivot row is broadcast with
-// readlane and added to every other row that has the bit.  No LDS, no barrier; the matrix is read once and written once
-// (rows go out in pivot order, the zero rows after them), so a large batch of small matrices streams at what the walk
-// allows: ~20 instructions per column.  Grid-stride over the batch.
+// does not depend on which one: the lowest lane of the lowest register row here) and the pivot row is added to every other row
+// that has the bit.  The matrix is read once and written once (rows go out in pivot order, the zero rows after them), so a
+// large batch of small matrices streams at what the walk allows, and the walk is what round 4 rewrote (round 1's form: 70 vector
+// instructions per pivot, 850 GB/s on 64 x 512 matrices):
+//   * the dword that holds the column is a compile-time register (the walk is unrolled over the 2 LD dwords of a row, a runtime
+//     loop over the 32 bits inside), so there is no select chain over the words of a row: a column's test is an AND and a compare;
+//   * which rows are still unused, and which rows have the bit, are 64-bit lane masks in scalar registers, and the rows that
+//     take the pivot row are the exec mask as it stands (inverse_ballot): no per-lane predicate arithmetic;
+//   * the pivot row travels through LDS (its lane writes it, every lane reads it back at one address: a broadcast) instead of
+//     sixteen v_readlane, and only from the 16-byte piece that holds the column on -- an unused row is zero to the left of the
+//     column, so the words before it cannot change;
+//   * a matrix whose rows are contiguous (ld == LD) is loaded and stored in 16-byte pieces, 1 KiB contiguous per instruction,
+//     and handed to / taken from the row-per-lane layout through LDS (80-byte row pitch: conflict-free 16-byte accesses).
+// About 20 vector instructions per pivot are left: the XORs themselves.  Grid-stride over the batch.
+#define SMALL_WAVES 4
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int RPL, int LD>
-__global__ __launch_bounds__(256) void rref_small_kernel(u64* __restrict__ base, int64_t batch, int m, int n, int64_t ld,
-                                                         int64_t* __restrict__ pivots_base, int64_t cap,
-                                                         int64_t* __restrict__ rank_out) {
+__global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __restrict__ base, int64_t batch, int m, int n, int64_t ld,
+                                                                      int64_t* __restrict__ pivots_base, int64_t cap,
+                                                                      int64_t* __restrict__ rank_out) {
+    constexpr int DW = 2 * LD;                                      // dwords per row
+    constexpr int PITCH = LD >= 2 ? LD * 8 + 16 : 16;               // LDS bytes per staged row (64 rows at a time)
+    constexpr bool STAGED = LD >= 2;                                // rows of whole 16-byte pieces
+    __shared__ __align__(16) unsigned char stage_all[SMALL_WAVES][STAGED ? 64 * PITCH : 16];
+    __shared__ __align__(16) unsigned int bcast_all[SMALL_WAVES][DW < 4 ? 4 : DW];
     const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* const stage = stage_all[wv];
+    unsigned int* const bcast = bcast_all[wv];
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const bool dense = STAGED && ld == LD && (reinterpret_cast<uintptr_t>(base) & 15) == 0;       // uniform
     for (int64_t mat = wave; mat < batch; mat += nwaves) {
         u64* a = base + mat * m * ld;
-        u64 w[RPL][LD];
+        unsigned int w[RPL][DW];
         int pivcol[RPL];                                            // >= 0 once this row has become a pivot row: its column
         int myrank[RPL];
+        u64 unused[RPL];                                            // lane masks (scalar): rows that exist and are not pivot rows yet
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
-            const int row = lane + 64 * q;
             pivcol[q] = -1;
             myrank[q] = 0;
+            unused[q] = __ballot(lane + 64 * q < m);
+        }
+        if (dense) {
+            // 64 rows at a time: piece p (16 bytes) of the block belongs to row p / (LD / 2); lanes take consecutive pieces
+            constexpr int PPR = LD / 2;                             // pieces per row
 #pragma unroll
-            for (int k = 0; k < LD; ++k) w[q][k] = (row < m && k < ld) ? a[(int64_t)row * ld + k] : 0ull;
+            for (int q = 0; q < RPL; ++q) {
+                const int rows_here = m - 64 * q < 64 ? m - 64 * q : 64;    // uniform
+                const u32x4* src = reinterpret_cast<const u32x4*>(a + (int64_t)64 * q * ld);
+                if (rows_here > 0) {
+#pragma unroll
+                    for (int it = 0; it < PPR; ++it) {
+                        const int p = it * 64 + lane;
+                        if (p < rows_here * PPR) {
+                            const u32x4 v = src[p];
+                            *reinterpret_cast<u32x4*>(stage + (p / PPR) * PITCH + (p % PPR) * 16) = v;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < PPR; ++j) {
+                    u32x4 v = {0, 0, 0, 0};
+                    if (lane < rows_here) v = *reinterpret_cast<const u32x4*>(stage + lane * PITCH + j * 16);
+                    w[q][4 * j] = v.x, w[q][4 * j + 1] = v.y, w[q][4 * j + 2] = v.z, w[q][4 * j + 3] = v.w;
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                const int row = lane + 64 * q;
+#pragma unroll
+                for (int k = 0; k < LD; ++k) {
+                    const u64 v = (row < m && k < ld) ? a[(int64_t)row * ld + k] : 0ull;
+                    w[q][2 * k] = (unsigned int)v;
+                    w[q][2 * k + 1] = (unsigned int)(v >> 32);
+                }
+            }
         }
         int rank = 0;
-        for (int col = 0; col < n && rank < m; ++col) {
-            const int k = col >> 6, b = col & 63;                   // uniform
-            bool has[RPL];
-            int src_q = -1, src_lane = 0;
 #pragma unroll
-            for (int q = 0; q < RPL; ++q) {
-                u64 word = 0;
+        for (int d = 0; d < DW; ++d) {                              // the dword of the row that holds the column: a constant below
+            if (d * 32 >= n || rank >= m) break;                    // uniform
+            const int d4 = d & ~3;                                  // the pivot row is zero before its column: pieces from here on
+#pragma unroll 1
+            for (int bb = 0; bb < 32; ++bb) {
+                const int col = d * 32 + bb;
+                if (col >= n || rank >= m) break;                   // uniform
+                const unsigned int bit = 1u << bb;
+                u64 has[RPL];
+                int src_q = -1;
+                u64 cand = 0;
 #pragma unroll
-                for (int kk = 0; kk < LD; ++kk)
-                    if (kk == k) word = w[q][kk];
-                has[q] = (word >> b) & 1ull;
-                const u64 cand = __ballot(has[q] && pivcol[q] < 0);
-                if (src_q < 0 && cand) {
-                    src_q = q;
-                    src_lane = __ffsll((long long)cand) - 1;
+                for (int q = 0; q < RPL; ++q) {
+                    has[q] = __ballot((w[q][d] & bit) != 0);
+                    if (src_q < 0 && (has[q] & unused[q])) {
+                        src_q = q;
+                        cand = has[q] & unused[q];
+                    }
                 }
-            }
-            if (src_q < 0) continue;                                // no unused row has this column: not a pivot column
-            u64 pr[LD];
+                if (src_q < 0) continue;                            // no unused row has this column: not a pivot column
+                const int src_lane = __ffsll((long long)cand) - 1;
+                const u64 src_bit = 1ull << src_lane;
+                // the pivot row through LDS: written by its lane, read back by all at one address
 #pragma unroll
-            for (int kk = 0; kk < LD; ++kk) {
-                u64 from = 0;
+                for (int q = 0; q < RPL; ++q) {
+                    if (q != src_q) continue;                       // uniform
+                    if (__builtin_amdgcn_inverse_ballot_w64(src_bit)) {
 #pragma unroll
-                for (int q = 0; q < RPL; ++q)
-                    if (q == src_q) from = w[q][kk];
-                pr[kk] = readlane64(from, src_lane);
-            }
-#pragma unroll
-            for (int q = 0; q < RPL; ++q) {
-                const bool is_pivot = q == src_q && lane == src_lane;
-                if (is_pivot) {
-                    pivcol[q] = col;
-                    myrank[q] = rank;
-                } else if (has[q]) {
-#pragma unroll
-                    for (int kk = 0; kk < LD; ++kk) w[q][kk] ^= pr[kk];
+                        for (int dd = 0; dd < DW; dd += 4) {
+                            if (dd < d4) continue;
+                            if (DW >= 4)
+                                *reinterpret_cast<u32x4*>(bcast + dd) = u32x4{w[q][dd], w[q][dd + 1], w[q][dd + 2], w[q][dd + 3]};
+                            else
+                                for (int e = 0; e < DW; ++e) bcast[e] = w[q][e];
+                        }
+                        pivcol[q] = col;
+                        myrank[q] = rank;
+                    }
                 }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                unsigned int pr[DW];
+#pragma unroll
+                for (int dd = 0; dd < DW; dd += 4) {
+                    if (dd < d4) continue;
+                    if (DW >= 4) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(bcast + dd);
+                        pr[dd] = v.x, pr[dd + 1] = v.y, pr[dd + 2] = v.z, pr[dd + 3] = v.w;
+                    } else
+                        for (int e = 0; e < DW; ++e) pr[e] = bcast[e];
+                }
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    const u64 take = q == src_q ? has[q] & ~src_bit : has[q];
+                    if (__builtin_amdgcn_inverse_ballot_w64(take)) {
+#pragma unroll
+                        for (int dd = 0; dd < DW; ++dd)
+                            if (dd >= d4) w[q][dd] ^= pr[dd];
+                    }
+                }
+                unused[src_q < 0 ? 0 : src_q] &= ~src_bit;
+                rank += 1;
+                __builtin_amdgcn_wave_barrier();                    // (the next pivot row is written after every lane has read this one)
             }
-            rank += 1;
         }
         // rows out in pivot order; everything from row `rank` on is zero
+        if (dense) {
+            constexpr int PPR = LD / 2;
+            // the rows into the staging area at their final places (64 rows of the result at a time), then out in 16-byte pieces
 #pragma unroll
-        for (int q = 0; q < RPL; ++q) {
-            const int row = lane + 64 * q;
-            if (pivcol[q] >= 0) {
+            for (int blk = 0; blk < RPL; ++blk) {
+                const int rows_here = m - 64 * blk < 64 ? m - 64 * blk : 64;    // uniform
+                if (rows_here <= 0) break;
+                // zero rows first (rows >= rank), then the pivot rows that land in this block
+                const int rr = 64 * blk + lane;
+                if (lane < rows_here && rr >= rank) {
 #pragma unroll
-                for (int k = 0; k < LD; ++k)
-                    if (k < ld) a[(int64_t)myrank[q] * ld + k] = w[q][k];
-                if (pivots_base) pivots_base[mat * cap + myrank[q]] = pivcol[q];
+                    for (int j = 0; j < PPR; ++j) *reinterpret_cast<u32x4*>(stage + lane * PITCH + j * 16) = u32x4{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    if (pivcol[q] >= 0 && (myrank[q] >> 6) == blk) {
+                        unsigned char* const dst = stage + (myrank[q] & 63) * PITCH;
+#pragma unroll
+                        for (int j = 0; j < PPR; ++j)
+                            *reinterpret_cast<u32x4*>(dst + j * 16) = u32x4{w[q][4 * j], w[q][4 * j + 1], w[q][4 * j + 2], w[q][4 * j + 3]};
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                u32x4* dstg = reinterpret_cast<u32x4*>(a + (int64_t)64 * blk * ld);
+#pragma unroll
+                for (int it = 0; it < PPR; ++it) {
+                    const int p = it * 64 + lane;
+                    if (p < rows_here * PPR) dstg[p] = *reinterpret_cast<const u32x4*>(stage + (p / PPR) * PITCH + (p % PPR) * 16);
+                }
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            if (row >= rank && row < m) {
 #pragma unroll
-                for (int k = 0; k < LD; ++k)
-                    if (k < ld) a[(int64_t)row * ld + k] = 0ull;
+            for (int q = 0; q < RPL; ++q)
+                if (pivots_base && pivcol[q] >= 0) pivots_base[mat * cap + myrank[q]] = pivcol[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) {
+                const int row = lane + 64 * q;
+                if (pivcol[q] >= 0) {
+#pragma unroll
+                    for (int k = 0; k < LD; ++k)
+                        if (k < ld) a[(int64_t)myrank[q] * ld + k] = ((u64)w[q][2 * k + 1] << 32) | w[q][2 * k];
+                    if (pivots_base) pivots_base[mat * cap + myrank[q]] = pivcol[q];
+                }
+                if (row >= rank && row < m) {
+#pragma unroll
+                    for (int k = 0; k < LD; ++k)
+                        if (k < ld) a[(int64_t)row * ld + k] = 0ull;
+                }
             }
         }
         if (lane == 0) rank_out[mat] = rank;
@@ -1276,10 +1400,10 @@ __global__ __launch_bounds__(256) void rref_small_kernel(u64* __restrict__ base,
 template <int RPL, int LD>
 static int launch_rref_small(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld, int64_t* pivots_dev,
                              int64_t cap, int64_t* rank_dev) {
-    int64_t blocks = gf2_cdiv(batch, 4);
+    int64_t blocks = gf2_cdiv(batch, SMALL_WAVES);
     if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
-    hipLaunchKernelGGL((rref_small_kernel<RPL, LD>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, a_dev, batch, (int)m, (int)n,
+    hipLaunchKernelGGL((rref_small_kernel<RPL, LD>), dim3((unsigned)blocks), dim3(64 * SMALL_WAVES), 0, ctx->stream, a_dev, batch, (int)m, (int)n,
                        ld, pivots_dev, cap, rank_dev);
     GF2_TRY(gf2_prof_end(ctx));
     GF2_HIP(hipGetLastError());

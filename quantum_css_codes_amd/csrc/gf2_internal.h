@@ -118,8 +118,9 @@ int gf2_syndrome_lane(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, 
                       int64_t lds, uint64_t* hist_dev, hipStream_t stream);
 bool gf2_slabs_ok(const gf2_check* ck);
 // stream: the context's stream or one of its side streams; ws_slot: 2 or 3 (one per stream that may run concurrently)
+// hist_dev (r + 1 bins, accumulated into) and / or s_dev (syndromes, lds words per sample): either may be null
 int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde,
-                       uint64_t* hist_dev, hipStream_t stream, int ws_slot);
+                       uint64_t* hist_dev, hipStream_t stream, int ws_slot, uint64_t* s_dev = nullptr, int64_t lds = 0);
 int gf2_slabs_reserve(gf2_ctx* ctx, const gf2_check* ck, int64_t batch, int ws_slot);
 // gf2_mc_run's path without packed rows: the sampler writes the records and the identity words itself (gf2_slabs.hip)
 struct SegTables;

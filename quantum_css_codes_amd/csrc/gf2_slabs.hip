@@ -88,7 +88,9 @@ struct CompactArgs {
     const u64* e;
     const uint32_t* ht;        // transposed check of the wavefront-per-sample routine (samples beyond a record)
     u32x4* rec;                // ceil(batch / 64) * 64 records of 64 bytes
-    u64* hist;
+    u64* hist;                 // null: syndromes only
+    uint32_t* syn;             // syndromes out (null: none): samples finished here store theirs, lds32 dwords per sample
+    int64_t lds32;
     int64_t batch, lde;
     int r, n, ident_off, null_ord;
     u64 skip_words;            // words whose few non-identity columns are left to the redo pass (bit w = word w)
@@ -171,8 +173,9 @@ __device__ __forceinline__ void combine_positions(const unsigned short* __restri
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x)
-        if (bins[i]) atomicAdd(&hist[i], (u64)bins[i]);
+    if (hist)
+        for (int i = threadIdx.x; i < nbins; i += blockDim.x)
+            if (bins[i]) atomicAdd(&hist[i], (u64)bins[i]);
     const unsigned int mine = redo_n < 1024 ? redo_n : 1024;
     if (mine) {                                                     // uniform
         if (threadIdx.x == 0) redo_base = atomicAdd(redo_count, mine);
@@ -426,8 +429,10 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void sl
                 const int j = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 const u64 ww = lane < words ? a.e[(s0 + j) * a.lde + lane] : 0ull;
-                const unsigned int wt = sparse_component_weight(ww, side, a.n, lane, slow_list);
-                if (lane == 0) atomicAdd(&a.hist[wt], 1ull);
+                unsigned int sdw;
+                const unsigned int wt = sparse_component_weight(ww, side, a.n, lane, slow_list, &sdw);
+                if (lane == 0 && a.hist) atomicAdd(&a.hist[wt], 1ull);
+                if (a.syn && lane < ((a.r + 63) >> 6) * 2) a.syn[(s0 + j) * a.lds32 + lane] = sdw;       // (the gather kernel skips finished samples)
             }
             wave_lds_sync();
         }
@@ -728,6 +733,10 @@ struct GatherArgs {
     const u64* e;
     const u32x4* rec;
     unsigned short* pw;        // nslabs x batch_pad partial weights
+    char* syn;                 // syndromes out (null: none): every workgroup stores its slab's 64-byte piece per sample, syn_pitch
+    int64_t syn_pitch;         // bytes apart (round 4: before, a call that wanted syndromes went to the column-gather kernel)
+    int syn_row;               // bytes of a syndrome: 8 ceil(r / 64); nothing is written past them
+    char* syn_sink;            // 1 KiB that lanes with nothing to store write to (hand-scheduled kernel: every step issues its store)
     int64_t batch, batch_pad, lde;   // batch_pad: stride of the partial weights; records exist for ceil(batch / 64) * 64 positions
     int tab_stride, nslabs, r, ident_off, null_ord;   // tab_stride: entries per row-part plane (= 4 mod 16)
     int stray_n, stray_col[2];   // columns compact left out (hand-scheduled kernel only): a sample that has one is flagged REC_STRAY
@@ -968,6 +977,13 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_kernel(GatherArgs 
         wt += __builtin_amdgcn_update_dpp(0u, wt, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
         // partial weights are stored by record position (contiguous), which is all the histogram needs
         if (part == 0) pw[pos] = (unsigned short)(flagged || !valid ? REC_FLAG : wt);
+        if (a.syn && !flagged && valid) {                           // this lane's 16 bytes of the sample's syndrome, what the row holds of them
+            unsigned int* const out =
+                reinterpret_cast<unsigned int*>(a.syn + (u64)record_sample(pos, slot0) * (u64)a.syn_pitch + slab * 64 + part * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (slab * 64 + part * 16 + q * 4 + 4 <= a.syn_row) out[q] = X[q];
+        }
     };
 #pragma unroll 1
     while (grp < ngroups) {
@@ -995,7 +1011,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // EXTRA: ident_off is not a multiple of 32, a fifth dword per row part; CROSS: GatherArgs::cross (a template parameter: the
 // step's address arithmetic is scalar code on its critical path)
-template <bool EXTRA, bool CROSS>
+// SYN: the syndromes are stored too (GatherArgs::syn): one more store per step, the counted waits allow for it
+template <bool EXTRA, bool CROSS, bool SYN>
 __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(GatherArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];            // the only LDS: the table starts at LDS address 0
     const int lane = threadIdx.x & 63;
@@ -1066,6 +1083,7 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
     const i32x4 rsrc = {__builtin_amdgcn_readfirstlane((int)(unsigned int)rec_base),
                         __builtin_amdgcn_readfirstlane((int)((unsigned int)(rec_base >> 32) & 0xFFFFu)),
                         __builtin_amdgcn_readfirstlane((int)(((a.batch + 63) >> 6) * TILE_REC_BYTES)), 0x00020000};
+    const unsigned int syn_lane = (unsigned int)slab * 64u + (unsigned int)part * 16u;          // this lane's piece of a syndrome row
     const char* const ident_base = reinterpret_cast<const char*>(a.e) + dw0 * 4u;
     const unsigned int fifth_off = ((dw0 + 4 < row_dwords ? dw0 + 4 : 0u) - dw0) * 4u;       // from ident_base, wraps
 
@@ -1214,14 +1232,27 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         wt += __builtin_amdgcn_update_dpp(0u, wt, 0xB1, 0xF, 0xF, true);    // quad_perm [1,0,3,2]
         wt += __builtin_amdgcn_update_dpp(0u, wt, 0x4E, 0xF, 0xF, true);    // quad_perm [2,3,0,1]
         // (a super-tile's last tiles may lie past the batch: their records read as zeros and nothing is stored for them)
+        if (SYN) {
+            // this lane's 16 bytes of the sample's syndrome (a sample finished by the compact kernel has stored its own; one that has a
+            // column compact left out is stored again, whole, by the redo kernel).  One store instruction per step whatever the data.
+            // A lane with nothing to store writes to its own 16 bytes of a sink instead: no branch, so the instruction is issued in
+            // every step (a step whose sixteen records are all finished or past the batch would otherwise issue one operation fewer
+            // than the wait below counts).
+            const u32x4 xs = {X[0], X[1], X[2], X[3]};
+            const bool mine = !flagged && valid && pos < positions;
+            char* const out = mine ? a.syn + (u64)record_sample(pos, slot0) * (u64)a.syn_pitch + syn_lane : a.syn_sink + lane * 16;
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(out), "v"(xs) : "memory");
+        }
         if (part == 0 && pos < positions)
             pw[pos] = (unsigned short)(flagged || !valid ? REC_FLAG : (stray ? REC_STRAY | ((slot0 >> 8) & 63u) : wt));
-        // refill the buffers this step has emptied: exactly one store, one record load and one (EXTRA: two) identity loads
-        // per step, in this order -- the wait counts above depend on it
+        // refill the buffers this step has emptied: exactly one store (SYN: two), one record load and one (EXTRA: two) identity
+        // loads per step, in this order -- the wait counts above depend on it
         asm volatile("" ::: "memory");
         G = take();
         issue_record(R, G);
-        if (EXTRA)
+        if (EXTRA && SYN)
+            asm volatile("s_waitcnt vmcnt(5)" : "+v"(Rn), "+v"(In), "+v"(En), "+v"(Rp3)::"memory");
+        else if (EXTRA || SYN)
             asm volatile("s_waitcnt vmcnt(4)" : "+v"(Rn), "+v"(In), "+v"(En), "+v"(Rp3)::"memory");
         else
             asm volatile("s_waitcnt vmcnt(3)" : "+v"(Rn), "+v"(In), "+v"(En), "+v"(Rp3)::"memory");
@@ -1260,7 +1291,8 @@ __global__ __launch_bounds__(1024) void slab_combine_kernel(const unsigned short
 __global__ __launch_bounds__(256) void slab_redo_kernel(const u64* __restrict__ e, int64_t batch, int64_t lde,
                                                         const unsigned int* __restrict__ redo_count,
                                                         const unsigned int* __restrict__ redo_list, const uint32_t* __restrict__ ht, int r,
-                                                        int n, int ident_off, u64* __restrict__ hist) {
+                                                        int n, int ident_off, u64* __restrict__ hist, uint32_t* __restrict__ syn,
+                                                        int64_t lds32) {
     __shared__ unsigned int lists[4][SPARSE_LIST_CAP + 8];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1271,8 +1303,10 @@ __global__ __launch_bounds__(256) void slab_redo_kernel(const u64* __restrict__ 
         const int64_t sample = (int64_t)redo_list[i];
         if (sample >= batch) continue;                              // uniform
         const u64 ww = lane < words ? e[sample * lde + lane] : 0ull;
-        const unsigned int wt = sparse_component_weight(ww, side, n, lane, lists[wave]);
-        if (lane == 0) atomicAdd(&hist[wt], 1ull);
+        unsigned int sdw;
+        const unsigned int wt = sparse_component_weight(ww, side, n, lane, lists[wave], &sdw);
+        if (lane == 0 && hist) atomicAdd(&hist[wt], 1ull);
+        if (syn && lane < ((r + 63) >> 6) * 2) syn[sample * lds32 + lane] = sdw;       // over what the gather kernel stored without the column
     }
 }
 
@@ -1374,22 +1408,26 @@ static int slab_lds_optin(gf2_ctx* ctx) {
     if (!ctx->lds_optin[2]) {
         GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
-        GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_fast_kernel<false, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
-        GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_fast_kernel<true, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
-        GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_fast_kernel<false, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
-        GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_fast_kernel<true, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
+#define GF2_GATHER_OPTIN(E, C, S)                                                                                  \
+    GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_fast_kernel<E, C, S>),                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64))
+        GF2_GATHER_OPTIN(false, false, false);
+        GF2_GATHER_OPTIN(true, false, false);
+        GF2_GATHER_OPTIN(false, true, false);
+        GF2_GATHER_OPTIN(true, true, false);
+        GF2_GATHER_OPTIN(false, false, true);
+        GF2_GATHER_OPTIN(true, false, true);
+#undef GF2_GATHER_OPTIN
         ctx->lds_optin[2] = true;
     }
     return GF2_OK;
 }
 
 // The gather kernel of one pass: records, identity words (rows of lde words at e) and the workspace are in place.
+// syn (null: none): where the pass' first sample's syndrome goes, pitch bytes per sample; sink: 1 KiB for the lanes that store nothing
 static int launch_gather(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u32x4* rec, unsigned short* pw, int64_t count, int64_t pad,
-                         int64_t lde, bool fast, const StrayPlan& stray, hipStream_t stream, u64* clk_dev) {
+                         int64_t lde, bool fast, const StrayPlan& stray, hipStream_t stream, u64* clk_dev, char* syn = nullptr,
+                         int64_t syn_pitch = 0, char* syn_sink = nullptr) {
     const size_t lds_bytes = (size_t)ck->slab_cols * 64;
     GatherArgs ga;
     ga.tab = (const u32x4*)ck->slab_tab_dev;
@@ -1408,8 +1446,12 @@ static int launch_gather(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u
     ga.stray_col[0] = stray.col[0];
     ga.stray_col[1] = stray.col[1];
     ga.clk = clk_dev;
+    ga.syn = syn;
+    ga.syn_pitch = syn_pitch;
+    ga.syn_sink = syn_sink;
+    ga.syn_row = (int)gf2_words(ck->r) * 8;
     ga.reverse = ctx->opt[GF2_OPT_GATHER_REVERSE] == 0 ? 0 : 1;
-    ga.cross = ctx->opt[GF2_OPT_GATHER_CROSS] == 1 ? 1 : 0;
+    ga.cross = ctx->opt[GF2_OPT_GATHER_CROSS] == 1 && !syn ? 1 : 0;       // (the cross-tile grouping has no variant that stores syndromes)
     // GF2_OPT_GATHER_OVER workgroups per CU over the launch (default 1): more of them let a CU that is done early take another
     // share, at the price of one more copy of the slab's table into LDS each
     const int64_t over = ctx->opt[GF2_OPT_GATHER_OVER] > 0 ? ctx->opt[GF2_OPT_GATHER_OVER] : 1;
@@ -1419,14 +1461,18 @@ static int launch_gather(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u
     if (shares < 1) shares = 1;
     const dim3 ggrid((unsigned)(shares * ck->nslabs512));
     const bool extra = (ck->ident_off & 31) != 0;
-    if (fast && extra && ga.cross)
-        hipLaunchKernelGGL((slab_gather_fast_kernel<true, true>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+    if (fast && syn && extra)
+        hipLaunchKernelGGL((slab_gather_fast_kernel<true, false, true>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+    else if (fast && syn)
+        hipLaunchKernelGGL((slab_gather_fast_kernel<false, false, true>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+    else if (fast && extra && ga.cross)
+        hipLaunchKernelGGL((slab_gather_fast_kernel<true, true, false>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
     else if (fast && extra)
-        hipLaunchKernelGGL((slab_gather_fast_kernel<true, false>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+        hipLaunchKernelGGL((slab_gather_fast_kernel<true, false, false>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
     else if (fast && ga.cross)
-        hipLaunchKernelGGL((slab_gather_fast_kernel<false, true>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+        hipLaunchKernelGGL((slab_gather_fast_kernel<false, true, false>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
     else if (fast)
-        hipLaunchKernelGGL((slab_gather_fast_kernel<false, false>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+        hipLaunchKernelGGL((slab_gather_fast_kernel<false, false, false>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
     else
         hipLaunchKernelGGL(slab_gather_kernel, ggrid, dim3(GAT_THREADS), lds_bytes, stream, ga);
     GF2_HIP(hipGetLastError());
@@ -1452,11 +1498,11 @@ static int launch_combine(gf2_ctx* ctx, const gf2_check* ck, const unsigned shor
 
 // The redo kernel over the whole call's batch: the samples the combine steps have listed (they have a column compact left out).
 static int launch_redo(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde, unsigned int* redo_count,
-                       unsigned int* redo_list, uint64_t* hist_dev, hipStream_t stream) {
+                       unsigned int* redo_list, uint64_t* hist_dev, uint64_t* s_dev, int64_t lds, hipStream_t stream) {
     const int64_t per_cu = ctx->opt[GF2_OPT_REDO_BLOCKS_PER_CU] > 0 ? ctx->opt[GF2_OPT_REDO_BLOCKS_PER_CU] : 8;
     hipLaunchKernelGGL(slab_redo_kernel, dim3((unsigned)(ctx->num_cus * per_cu)), dim3(256), 0, stream, (const u64*)e_dev, batch, lde,
                        (const unsigned int*)redo_count, (const unsigned int*)redo_list, ck->ht_dev, (int)ck->r, (int)ck->n,
-                       (int)ck->ident_off, (u64*)hist_dev);
+                       (int)ck->ident_off, (u64*)hist_dev, (uint32_t*)s_dev, lds * 2);
     GF2_HIP(hipGetLastError());
     return GF2_OK;
 }
@@ -1465,7 +1511,10 @@ static int launch_redo(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
 struct SlabCall {
     const gf2_check* ck;
     const uint64_t* e_dev;
-    uint64_t* hist_dev;
+    uint64_t* hist_dev;            // null: syndromes only
+    uint64_t* s_dev;               // syndromes out, lds words per sample (null: histogram only)
+    int64_t lds;
+    char* syn_sink;
     int64_t batch, lde, pass, pad;
     u32x4* rec;
     unsigned short* pw;
@@ -1476,11 +1525,13 @@ struct SlabCall {
 };
 
 static int slab_call_setup(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde, uint64_t* hist_dev,
-                           int ws_slot, SlabCall* c) {
+                           uint64_t* s_dev, int64_t lds, int ws_slot, SlabCall* c) {
     GF2_TRY(slab_lds_optin(ctx));
     c->ck = ck;
     c->e_dev = e_dev;
     c->hist_dev = hist_dev;
+    c->s_dev = s_dev;
+    c->lds = lds;
     c->batch = batch;
     c->lde = lde;
     c->pass = slab_pass(ctx, batch);
@@ -1488,15 +1539,18 @@ static int slab_call_setup(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_
     // records and partial weights of one pass; the redo list is the call's (one redo launch at the end)
     const size_t rec_bytes = (size_t)c->pad * 64, pw_bytes = (size_t)ck->nslabs512 * c->pad * 2;
     const size_t redo_bytes = (size_t)(batch > c->pad ? gf2_cdiv(batch, 64) * 64 : c->pad) * 4 + 256;
-    GF2_TRY(gf2_ws_reserve(ctx, ws_slot, rec_bytes + pw_bytes + redo_bytes));
+    GF2_TRY(gf2_ws_reserve(ctx, ws_slot, rec_bytes + pw_bytes + redo_bytes + 1024));
     c->rec = (u32x4*)ctx->ws[ws_slot];
     c->pw = (unsigned short*)((char*)ctx->ws[ws_slot] + rec_bytes);
     c->redo_count = (unsigned int*)((char*)ctx->ws[ws_slot] + rec_bytes + pw_bytes);
     c->redo_list = c->redo_count + 64;
+    c->syn_sink = (char*)ctx->ws[ws_slot] + rec_bytes + pw_bytes + redo_bytes;
     // the hand-scheduled gather kernel needs every slab's identity words to be whole 16-byte pieces inside the row
     const int64_t first_dw = ck->ident_off >= 0 ? ck->ident_off >> 5 : 0;
     c->fast = ck->ident_off >= 0 && (lde & 1) == 0 && (reinterpret_cast<uintptr_t>(e_dev) & 15) == 0 && (first_dw & 3) == 0 &&
               first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) <= lde * 2 && !gf2_flag(ctx, GF2_F_GATHER_GENERIC);
+    // ... and, when it stores syndromes, every slab's 64-byte piece to lie inside a syndrome row
+    if (s_dev && ((int64_t)ck->nslabs512 * 64 > gf2_words(ck->r) * 8 || (reinterpret_cast<uintptr_t>(s_dev) & 15) != 0 || (lds & 1) != 0)) c->fast = false;
     const StrayPlan none = {0, 0, {0, 0}};
     c->stray = c->fast ? plan_stray(ctx, ck) : none;
     // GF2_F_COMBINE_FOLDED: between two passes of a call the combine step rides in the next pass' compact kernel (its first
@@ -1517,6 +1571,8 @@ static int launch_compact(gf2_ctx* ctx, const SlabCall& c, int64_t first, hipStr
     ca.ht = ck->ht_dev;
     ca.rec = c.rec;
     ca.hist = (u64*)c.hist_dev;
+    ca.syn = c.s_dev ? (uint32_t*)(c.s_dev + first * c.lds) : nullptr;
+    ca.lds32 = c.lds * 2;
     ca.batch = count;
     ca.lde = c.lde;
     ca.r = (int)ck->r;
@@ -1563,17 +1619,21 @@ static int launch_compact(gf2_ctx* ctx, const SlabCall& c, int64_t first, hipStr
 // gather and (unless it rides in the next compact kernel) combine of the pass that starts at `first`.
 static int launch_rest_of_pass(gf2_ctx* ctx, const SlabCall& c, int64_t first, hipStream_t stream, u64* clk_dev) {
     const int64_t count = c.batch - first < c.pass ? c.batch - first : c.pass;
-    GF2_TRY(launch_gather(ctx, c.ck, c.e_dev + first * c.lde, c.rec, c.pw, count, c.pad, c.lde, c.fast, c.stray, stream, clk_dev));
+    GF2_TRY(launch_gather(ctx, c.ck, c.e_dev + first * c.lde, c.rec, c.pw, count, c.pad, c.lde, c.fast, c.stray, stream, clk_dev,
+                          c.s_dev ? (char*)(c.s_dev + first * c.lds) : nullptr, c.lds * 8, c.syn_sink));
+    if (!c.hist_dev && !c.stray.n_cols) return GF2_OK;               // syndromes only and nothing to list: no combine step
     if (!c.fold || first + c.pass >= c.batch)
         GF2_TRY(launch_combine(ctx, c.ck, c.pw, c.redo_count, c.redo_list, count, c.pad, (unsigned int)first, c.hist_dev, stream, clk_dev));
     return GF2_OK;
 }
 
-// Weight histogram of batch resident sample-major errors (hist: r + 1 bins, accumulated into).
+// Resident sample-major errors through the pipeline.
+// Weight histogram (hist_dev: r + 1 bins, accumulated into; null: none) and / or syndromes (s_dev: lds words per sample; null: none).
 int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev, int64_t batch, int64_t lde,
-                       uint64_t* hist_dev, hipStream_t stream, int ws_slot) {
+                       uint64_t* hist_dev, hipStream_t stream, int ws_slot, uint64_t* s_dev, int64_t lds) {
     SlabCall c;
-    GF2_TRY(slab_call_setup(ctx, ck, e_dev, batch, lde, hist_dev, ws_slot, &c));
+    GF2_TRY(slab_call_setup(ctx, ck, e_dev, batch, lde, hist_dev, s_dev, lds, ws_slot, &c));
+    if (c.fold && !hist_dev) c.fold = false;
     GF2_HIP(hipMemsetAsync(c.redo_count, 0, 4, stream));
     for (int64_t first = 0; first < batch; first += c.pass) {
         u64* clk_dev = nullptr;
@@ -1595,7 +1655,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
             GF2_HIP(hipFree(clk_dev));
         }
     }
-    if (c.stray.n_cols) GF2_TRY(launch_redo(ctx, ck, e_dev, batch, lde, c.redo_count, c.redo_list, hist_dev, stream));
+    if (c.stray.n_cols) GF2_TRY(launch_redo(ctx, ck, e_dev, batch, lde, c.redo_count, c.redo_list, hist_dev, s_dev, lds, stream));
     return GF2_OK;
 }
 
@@ -1604,7 +1664,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
 int gf2_slabs_reserve(gf2_ctx* ctx, const gf2_check* ck, int64_t batch, int ws_slot) {
     const int64_t pass = slab_pass(ctx, batch);
     const int64_t pad = gf2_cdiv(pass, 64) * 64;
-    return gf2_ws_reserve(ctx, ws_slot, (size_t)pad * 64 + (size_t)ck->nslabs512 * pad * 2 + (size_t)pad * 4 + 256);
+    return gf2_ws_reserve(ctx, ws_slot, (size_t)pad * 64 + (size_t)ck->nslabs512 * pad * 2 + (size_t)pad * 4 + 256 + 1024);
 }
 
 // ---- the Monte-Carlo run's own way in: records from the sampler ---------------------------------------------------------------

@@ -340,9 +340,10 @@ int gf2_syndrome_sparse_dev(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e
     // loads; GF2_SPARSE_SLABS / GF2_SPARSE_GATHER force one or the other (same results)
     if (gf2_lane_ok(ck) && !gf2_flag(ctx, GF2_F_SPARSE_GATHER) && !gf2_flag(ctx, GF2_F_SPARSE_SLABS))
         GF2_TRY(gf2_syndrome_lane(ctx, ck, e_dev, batch, lde, s_dev, lds, hist_dev, ctx->stream));   // n <= 512, r <= 256
-    else if (!s_dev && gf2_slabs_ok(ck) && !gf2_flag(ctx, GF2_F_SPARSE_GATHER) &&
-        (batch >= 32768 || gf2_flag(ctx, GF2_F_SPARSE_SLABS)))
-        GF2_TRY(gf2_syndrome_slabs(ctx, ck, e_dev, batch, lde, hist_dev, ctx->stream, 2));
+    else if (gf2_slabs_ok(ck) && !gf2_flag(ctx, GF2_F_SPARSE_GATHER) && (batch >= 32768 || gf2_flag(ctx, GF2_F_SPARSE_SLABS)))
+        // (round 4: with the syndromes stored too -- every gather workgroup its slab's 64-byte piece -- instead of the
+        // column-gather kernel for any call that wanted them)
+        GF2_TRY(gf2_syndrome_slabs(ctx, ck, e_dev, batch, lde, hist_dev, ctx->stream, 2, s_dev, lds));
     else if (s_dev && hist_dev)
         launch_sparse<true, true>(ctx, ck, e_dev, batch, lde, (uint32_t*)s_dev, lds * 2, (u64*)hist_dev, (int)nbins);
     else if (s_dev)

@@ -34,8 +34,9 @@ struct SparseSide {
     int nbins;
 };
 
+// Returns the syndrome's weight; *syn_out (if given) = this lane's syndrome dword (rows 32 lane .. 32 lane + 31, zero past r).
 __device__ __forceinline__ unsigned int sparse_component_weight(u64 w, const SparseSide& side, int64_t n, int lane,
-                                                               unsigned int* mylist) {
+                                                               unsigned int* mylist, unsigned int* syn_out = nullptr) {
     // identity block: dword `lane` covers rows 32*lane.. <-> error bits ident_off + 32*lane ..
     unsigned int acc = 0;
     if (side.ident_off >= 0) {
@@ -91,6 +92,7 @@ __device__ __forceinline__ unsigned int sparse_component_weight(u64 w, const Spa
             }
         }
     }
+    if (syn_out) *syn_out = acc;
     return wave_total((unsigned int)__popc(acc));
 }
 

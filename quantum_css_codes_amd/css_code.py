@@ -292,8 +292,8 @@ class CSSCode(QECC):
         a logical measurement: for every sampled error the syndrome is looked up in this code's tables
         (quil_classical_correct, css_code.py:649-685: the correction is applied when the syndrome is in the table,
         otherwise the error stays), and the logical Z (X) measurement flips iff z_operator . residual_x
-        (x_operator . residual_z) is odd (noisy_measure, css_code.py:640-646).  Small codes only (n <= 63,
-        r_1, r_2 <= 20).  Returns counts: logical_x, logical_z, logical_any, uncorrectable_x, uncorrectable_z, samples."""
+        (x_operator . residual_z) is odd (noisy_measure, css_code.py:640-646).  Codes of at most 128 qubits (dense tables of
+        2^r words for n <= 63 and r_1, r_2 <= 20, hash tables on the device beyond).  Returns counts: logical_x, logical_z, logical_any, uncorrectable_x, uncorrectable_z, samples."""
         from . import montecarlo
         return montecarlo.decode_local(self, num_samples, p_x, p_y, p_z, seed=seed, first_sample=first_sample)
 
@@ -322,7 +322,8 @@ def syndrome_table(parity_check, max_weight=None, _packed=None):
     return it along with a lookup table from syndromes (as bin_matrix.vec_to_int keys) to error vectors
     of weight at most t (css_code.py:715-735).
 
-    Codes of at most 8192 bits and 24 checks are searched entirely on the device (gf2_table.hip).  Otherwise each
+    Codes of at most 8192 bits are searched entirely on the device (gf2_table.hip): up to 24 checks against a dense table of
+    2^r slots, up to 127 checks against a hash table sized from the weight classes it holds.  Otherwise (r > 127) each
     weight class is enumerated in bin_matrix.weight_w_vectors order, in chunks, and its syndromes are computed on the GPU; a class containing a syndrome already seen (in an earlier class or earlier in the
     same class) ends the search and is discarded as a whole, exactly as the reference's loop does.  Keys are
     formed and compared as machine words when r <= 63 (the reference's own keys are only meaningful there,
@@ -360,6 +361,21 @@ def syndrome_table(parity_check, max_weight=None, _packed=None):
             sel = np.flatnonzero(weight == w)
             supports = _native.unrank_supports(rank[sel], n, w)
             # the reference's insertion order inside a class: supports ascending lexicographically (bin_matrix.py:57-72)
+            order = np.lexsort(tuple(supports[:, k] for k in range(w - 1, -1, -1))) if w else np.arange(sel.size)
+            errs = np.zeros((sel.size, n), dtype='int')
+            if w:
+                errs[np.arange(sel.size)[:, None], supports] = 1
+            table.update(zip(keys[sel][order].tolist(), errs[order]))
+        return t, table
+    if ctx.TABLE_MAX_R < r <= ctx.TABLE_HASH_MAX_R and 0 < n <= ctx.TABLE_HASH_MAX_N:
+        # more than 24 checks (round 4; every k = 1 CSS code from n = 51 on has such a check): an open-addressing hash table on
+        # the device, sized from the weight classes it holds (gf2_syndrome_table_hashed); exact keys of up to 127 bits
+        t, keys, weight, rank = ctx.syndrome_table_hashed(packed_h, r, n, max_weight)
+        keys = np.asarray(keys, dtype=object if r > 63 else np.uint64)
+        table = {}
+        for w in range(int(weight.max()) + 1 if weight.size else 0):
+            sel = np.flatnonzero(weight == w)
+            supports = _native.unrank_supports(rank[sel], n, w)
             order = np.lexsort(tuple(supports[:, k] for k in range(w - 1, -1, -1))) if w else np.arange(sel.size)
             errs = np.zeros((sel.size, n), dtype='int')
             if w:

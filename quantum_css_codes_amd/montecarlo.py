@@ -131,12 +131,42 @@ def packed_word(vec):
     return word
 
 
-def decode_local(code, num_samples, p_x, p_y, p_z, seed=0, first_sample=0):
-    """Table decode + logical-error tally of samples [first_sample, first_sample + num_samples) on this GPU
-    (gf2_mc_decode).  Returns a dict of counts (DECODE_FIELDS) plus 'samples'."""
-    if code.n > 63 or code.r_1 > 20 or code.r_2 > 20:
-        raise ValueError("table decode needs n <= 63 and r_1, r_2 <= 20")
+def table_entries(table, r, n):
+    """A syndrome table (dict: vec_to_int(syndrome) -> error vector) as the arrays gf2_mc_decode_hashed takes: keys (entries x 1
+    word for r <= 63, x 2 words, low first, beyond) and the packed errors (entries x 2 words, n <= 128)."""
+    kw = 1 if r <= 63 else 2
+    keys = np.zeros((len(table), kw), dtype=np.uint64)
+    mask = (1 << 64) - 1
+    for i, key in enumerate(table):
+        key = int(key)
+        keys[i, 0] = key & mask
+        if kw == 2:
+            keys[i, 1] = key >> 64
+    errs = np.array(list(table.values()), dtype=np.uint8).reshape(len(table), n)
+    corr = np.zeros((len(table), 2), dtype=np.uint64)
+    packed = _native.pack_rows(errs) if len(table) else np.zeros((0, 1), dtype=np.uint64)
+    corr[:, :packed.shape[1]] = packed[:, :2]
+    return keys, corr
+
+
+def decode_local(code, num_samples, p_x, p_y, p_z, seed=0, first_sample=0, hashed=None):
+    """Table decode + logical-error tally of samples [first_sample, first_sample + num_samples) on this GPU: gf2_mc_decode
+    (dense tables of 2^r words) for n <= 63 and r_1, r_2 <= 20, gf2_mc_decode_hashed (the tables' entries in hash tables on the
+    device) for every other code of at most 128 qubits.  Returns a dict of counts (DECODE_FIELDS) plus 'samples'."""
+    if code.n > 128 or max(code.r_1, code.r_2) > 127 or min(code.r_1, code.r_2) < 1:
+        raise ValueError("table decode needs n <= 128 and 1 <= r_1, r_2 <= 127")
     ctx = _native.default_context()
+    if hashed or code.n > 63 or code.r_1 > 20 or code.r_2 > 20:      # (hashed=True: the hash-table kernel for a small code too)
+        two = lambda vec: np.pad(_native.pack_rows(np.asarray(vec).reshape(1, -1))[0], (0, 2))[:2]
+        keys1, corr1 = table_entries(code._c1_syndromes, code.r_1, code.n)
+        keys2, corr2 = table_entries(code._c2_syndromes, code.r_2, code.n)
+        counts = ctx.mc_decode_hashed(code.n, _native.pack_rows(code.parity_check_c1), code.r_1, keys1, corr1,
+                                      _native.pack_rows(code.parity_check_c2), code.r_2, keys2, corr2,
+                                      two(code.x_operator_matrix()[0]), two(code.z_operator_matrix()[0]),
+                                      int(seed), int(first_sample), int(num_samples), float(p_x), float(p_y), float(p_z))
+        out = {name: int(v) for name, v in zip(DECODE_FIELDS, counts)}
+        out['samples'] = int(num_samples)
+        return out
     chk1, chk2 = code._device_checks()
     counts = ctx.mc_decode(chk1, chk2, dense_table(code._c1_syndromes, code.r_1, code.n),
                            dense_table(code._c2_syndromes, code.r_2, code.n),

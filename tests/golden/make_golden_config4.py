@@ -81,6 +81,21 @@ def main():
     e = np.random.default_rng(78).integers(0, 2, (16, n)).astype(np.int64)
     g["syn_c1_sha"] = np.array(sha(pack_rows(np.array([np.mod(np.matmul(code.parity_check_c1, e[i]), 2) for i in range(16)]))))
     g["syn_c2_sha"] = np.array(sha(pack_rows(np.array([np.mod(np.matmul(code.parity_check_c2, e[i]), 2) for i in range(16)]))))
+    # What the reference's syndrome_table (css_code.py:715-735) itself returns on these two checks: its keys come from
+    # bin_matrix.vec_to_int (bin_matrix.py:40-43), whose running value is a NumPy int64 from the first addition on, so a key of
+    # 2048 (2047) bits keeps its low 64 bits only.  The first weight-1 error, e_0, has the syndrome of H's column 0 -- for
+    # parity_check_c1 = [I | A] the unit vector of row 0, key 2^2047 -> 0 after the wrap, the key of the zero error: the search ends
+    # in class 1 with t = 0 and the one-entry table {0: 0}.  (Exact keys find no collision at weight 1: every column of a
+    # standard form is non-zero and no two are equal for a code of distance >= 3; the drop-in answers t >= 1, DESIGN.md
+    # section 5.)  Stored: t and the table's keys as the reference made them.
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")                          # (NumPy's overflow warnings of exactly that wrap)
+        for name, h in (("c1", code.parity_check_c1), ("c2", code.parity_check_c2)):
+            t, table = real_table(h)
+            g["ref_table_%s_t" % name] = np.array(t)
+            g["ref_table_%s_keys" % name] = np.array([int(k) for k in table.keys()], dtype=np.int64)
+            g["ref_table_%s_weights" % name] = np.array([int(np.sum(v)) for v in table.values()], dtype=np.int64)
     np.savez_compressed(os.path.join(HERE, "config4_golden.npz"), **g)
     print("wrote", len(g), "arrays;", "swaps", len(swap_log[0][1]), len(swap_log[1][1]), "gates", g["gates"])
 

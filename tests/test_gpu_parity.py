@@ -528,6 +528,30 @@ def test_monte_carlo_n4096_weight_histograms(ctx):
     assert int(hz.sum()) == count and int(hx.sum()) == count
 
 
+def test_syndrome_table_on_the_config4_checks_and_what_the_reference_returns(config4_golden):
+    # BASELINE.json configs[3]: "syndrome_table capped at weight <= 1" at n = 4096.  The drop-in's keys are exact integers of 2048
+    # (2047) bits: the weight-0 and weight-1 classes of both standard forms, 4097 entries each, in the reference's insertion order,
+    # against bin_matrix.vec_to_int restated on Python ints (oracle/cpu_ref.py on object arrays) of every column.  Beside it what
+    # the REFERENCE itself returns there (tests/golden/make_golden_config4.py ran its syndrome_table): t = 0 and the one-entry
+    # table {0: 0}, because its int64 keys wrap and the first weight-1 key collides with 0 (bin_matrix.py:40-43).
+    import bench
+    code, _, _ = bench.build_code()
+    g = config4_golden
+    for name, h in (("c1", code.parity_check_c1), ("c2", code.parity_check_c2)):
+        assert int(g["ref_table_%s_t" % name]) == 0 and [int(k) for k in g["ref_table_%s_keys" % name]] == [0]
+        t, table = css_code.syndrome_table(h, max_weight=1)
+        hobj = np.array(h, dtype=object)
+        want_keys = [0] + [int(cpu_ref.vec_to_int(hobj[:, j])) for j in range(h.shape[1])]
+        assert len(set(want_keys)) == len(want_keys)                  # exact keys do not collide at weight 1 ...
+        assert t == 1 and list(table.keys()) == want_keys             # ... so the capped search answers t = 1
+        errs = np.array(list(table.values()))
+        assert not errs[0].any() and np.array_equal(errs[1:], np.identity(h.shape[1], dtype=int))
+        # the reference's keys are the low 64 bits of the exact ones: among THEM the weight-1 class collides (an identity column of
+        # one of the first r - 64 rows wraps to 0, the zero error's key), hence its t = 0
+        low = [k & 0xFFFFFFFFFFFFFFFF for k in want_keys]
+        assert len(set(low)) < len(low) and 0 in low[1:]
+
+
 def test_monte_carlo_on_the_config4_code_itself(ctx, route):
     # BASELINE.json configs[4] as bench.py builds it -- H2 the dual of H1, both in the reference's standard form (digests of
     # config4_golden.npz asserted by build_code) -- not a stand-in with independent random checks: 2^17 + 4097 samples through
@@ -553,6 +577,15 @@ def test_monte_carlo_on_the_config4_code_itself(ctx, route):
     ctx.syndrome_sparse_dev(c2, ex, count, lde, None, 0, hx, bench.R2 + 1)
     assert np.array_equal(hz.download((bench.R1 + 1,), np.uint64), want[0]), "resident errors, slab pipeline, H1.e_z"
     assert np.array_equal(hx.download((bench.R2 + 1,), np.uint64), want[1]), "resident errors, slab pipeline, H2.e_x"
+    # ... and the syndromes of every one of those samples, stored by the same pipeline (SURVEY.md 8d's read-errors-write-syndromes
+    # variant, what bench.py's secondary.read_write_1536B times), word for word against the oracle's product (css_code.py:728)
+    e_z, e_x = ez.download((count, lde), "<u8"), ex.download((count, lde), "<u8")
+    for chk, hh, rr, e_host, e_dev in ((c1, h1, bench.R1, e_z, ez), (c2, h2, bench.R2, e_x, ex)):
+        lds = _native.words_for(rr)
+        s_dev = ctx.alloc(count * lds * 8).zero()
+        ctx.syndrome_sparse_dev(chk, e_dev, count, lde, s_dev, lds)
+        assert np.array_equal(s_dev.download((count, lds), "<u8"), c_oracle.syndrome_batch(hh, rr, bench.N_QUBITS, e_host, count)), rr
+        s_dev.free()
     for b in (ex, ez, hz, hx):
         b.free()
 
@@ -964,14 +997,20 @@ def test_syndrome_table_mid_size_codes_vs_oracle():
     t, table = css_code.syndrome_table(h, max_weight=1)
     want_t, want = cpu_ref.syndrome_table(np.array(h, dtype=object), max_weight=1)
     assert t == want_t and list(table.keys()) == [int(k) for k in want.keys()] and len(table) == 81
-    # chunked enumeration across several GPU batches: n = 60, weight <= 4 is 523k vectors; compare with a direct count
+    # n = 60, r = 30, weight <= 4: 523k errors (the hash-table search since round 4; rounds 1-3 enumerated in Python and were
+    # checked by count): t, every key in the reference's insertion order and every error against the C oracle's enumeration
     h = rng.integers(0, 2, (30, 60))
     t, table = css_code.syndrome_table(h, max_weight=4)
-    assert 0 <= t <= 4
+    want_t, want_keys, want_errs = c_oracle.syndrome_table(c_oracle.pack_rows(h), 30, 60, 4)
+    assert t == want_t and list(table.keys()) == want_keys
+    assert np.array_equal(np.array(list(table.values())), c_oracle.unpack_rows(want_errs, 60))
     from math import comb
     assert len(table) == sum(comb(60, w) for w in range(t + 1))
-    for key, err in list(table.items())[::5000]:
-        assert key == bin_matrix.vec_to_int(np.mod(h @ err, 2))
+    # more than 127 checks: the host enumerates, the device computes the syndromes, keys are exact Python ints
+    h = rng.integers(0, 2, (130, 140))
+    t, table = css_code.syndrome_table(h, max_weight=1)
+    want_t, want = cpu_ref.syndrome_table(np.array(h, dtype=object), max_weight=1)
+    assert t == want_t and list(table.keys()) == [int(k) for k in want.keys()] and len(table) == 141
 
 
 @pytest.mark.parametrize("case", [(65, 10, None), (96, 12, None), (127, 14, None), (127, 20, 2), (128, 24, 2), (100, 0, 1), (70, 7, None)])
@@ -1153,6 +1192,21 @@ def test_syndrome_slab_pipeline(case, ctx, route):
     hist = ctx.alloc((r + 1) * 8).zero()
     ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist, r + 1)
     assert np.array_equal(hist.download((r + 1,), np.uint64), want)
+    # the syndromes themselves out of the same pipeline (round 4: every gather workgroup stores its slab's 64-byte piece; samples
+    # beyond a record are stored by the compact kernel), with and without the histogram, at the tightest pitch and a wider one
+    want_s = c_oracle.syndrome_batch(h, r, n, e, batch)
+    for lds in (want_s.shape[1], want_s.shape[1] + 3):
+        for with_hist in (True, False):
+            s_buf = ctx.alloc(batch * lds * 8).upload(np.full((batch, lds), 0xA5A5A5A5A5A5A5A5, dtype=np.uint64))
+            hist_s = ctx.alloc((r + 1) * 8).zero()
+            ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, s_buf, lds, hist_s if with_hist else None, r + 1 if with_hist else 0)
+            got_s = s_buf.download((batch, lds), np.uint64)
+            assert np.array_equal(got_s[:, :want_s.shape[1]], want_s), (lds, with_hist)
+            pad = got_s[:, want_s.shape[1]:]                # (pad words of a row: left alone by the slab pipeline, zeroed by the column-gather kernel)
+            assert ((pad == 0xA5A5A5A5A5A5A5A5) | (pad == 0)).all(), "something was written past the syndromes"
+            if with_hist:
+                assert np.array_equal(hist_s.download((r + 1,), np.uint64), want)
+            s_buf.free(), hist_s.free()
     # ... and with a gather step's 16 records taken from four sorted tiles instead of a quartile of one (GF2_OPT_GATHER_CROSS)
     ctx.set_option(_native.OPT_GATHER_CROSS, 1)
     try:
@@ -1191,10 +1245,22 @@ def test_slab_pipeline_columns_left_to_the_redo_pass(case, ctx, route):
     hist = ctx.alloc((r + 1) * 8).zero()
     ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist, r + 1)
     assert np.array_equal(hist.download((r + 1,), np.uint64), want)
+    # stored syndromes: a sample with a left-out column is stored twice, without the column by the gather kernel and then whole
+    # by the redo kernel
+    want_s = c_oracle.syndrome_batch(h, r, n, e, batch)
+    lds = want_s.shape[1]
+    s_buf = ctx.alloc(batch * lds * 8).zero()
+    hist_s = ctx.alloc((r + 1) * 8).zero()
+    ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, s_buf, lds, hist_s, r + 1)
+    assert np.array_equal(s_buf.download((batch, lds), np.uint64), want_s)
+    assert np.array_equal(hist_s.download((r + 1,), np.uint64), want)
     route.force("GF2_NO_REDO")
     hist2 = ctx.alloc((r + 1) * 8).zero()
     ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, None, 0, hist2, r + 1)
     assert np.array_equal(hist2.download((r + 1,), np.uint64), want)
+    s_buf.zero()
+    ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, s_buf, lds, None, 0)
+    assert np.array_equal(s_buf.download((batch, lds), np.uint64), want_s)
 
 
 def test_syndrome_slab_pipeline_default_route_large_batch(ctx, route):
