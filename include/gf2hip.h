@@ -88,7 +88,8 @@ int gf2_ctx_sync(gf2_ctx* ctx);
 #define GF2_F_COMBINE_FOLDED       (1u << 15)  /* slab pipeline: the combine step of a pass inside the next pass' compact kernel */
 #define GF2_F_RREF_NO_LOOKAHEAD    (1u << 16)  /* gf2_rref* on more than 8192 rows: the next pair's panels after, not under, the trailing pass */
 #define GF2_F_RREF_LOOKAHEAD       (1u << 17)  /* ... under it whatever the size (default: from 128 MiB of matrix on)              */
-#define GF2_F_ALL                  ((1u << 18) - 1u)   /* every defined flag; gf2_ctx_set_flags refuses other bits              */
+#define GF2_F_COMBINE_SEPARATE     (1u << 18)  /* slab pipeline: a combine kernel after every pass (default since round 4: the combine step of a pass rides in the next pass' gather kernel) */
+#define GF2_F_ALL                  ((1u << 19) - 1u)   /* every defined flag; gf2_ctx_set_flags refuses other bits              */
 int gf2_ctx_set_flags(gf2_ctx* ctx, uint32_t flags);
 int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
 /* Tunables of a context (value < 0 restores the default). */
@@ -100,7 +101,8 @@ int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
 #define GF2_OPT_COMBINE_THREADS 5   /* slab pipeline: threads per workgroup of the combine kernel, 64 / 128 / 256 / 512 / 1024 (default 1024) */
 #define GF2_OPT_GATHER_CROSS    6   /* slab pipeline: 1 = a gather step takes ranks 4k..4k+3 of four sorted tiles, 0 (default) = a quartile of one */
 #define GF2_OPT_GATHER_OVER     7   /* slab pipeline: gather workgroups per CU over a launch, 1..8 (default 1)                            */
-#define GF2_OPT_COUNT           8
+#define GF2_OPT_RREF_SMALL_BCAST 8  /* wavefront-per-matrix RREF: 0 (default) = the pivot row travels through LDS, 1 = through v_readlane */
+#define GF2_OPT_COUNT           9
 int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value);
 
 /* Device memory and stream-ordered copies on the context's stream (copies are synchronous). */

@@ -11,6 +11,8 @@ from quantum_css_codes_amd import _native  # noqa: E402
 from oracle import c_oracle  # noqa: E402
 
 ctx = _native.default_context()
+if os.environ.get("GF2_RREF_BCAST"):
+    ctx.set_option(_native.OPT_RREF_SMALL_BCAST, int(os.environ["GF2_RREF_BCAST"]))
 rng = np.random.default_rng(4096)
 
 

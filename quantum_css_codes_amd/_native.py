@@ -22,9 +22,9 @@ K_SYNDROME, K_HIST, K_SAMPLER, K_ELIM = 0, 1, 2, 3
 # routing flags of a context (GF2_F_* of include/gf2hip.h) and its tunables (GF2_OPT_*)
 (F_SPARSE_GATHER, F_SPARSE_SLABS, F_NO_REDO, F_GATHER_GENERIC, F_MC_UNFUSED, F_MC_DENSE, F_MC_FUSED, F_MC_PIPELINE,
  F_RREF_SEQUENTIAL, F_RREF_NO_SMALL, F_NORMALIZE_SEQUENTIAL, F_SAMPLER_GENERIC, F_DIAG_CLOCKS,
- F_DIAG_MC_TIMES, F_MC_ROWS, F_COMBINE_FOLDED, F_RREF_NO_LOOKAHEAD, F_RREF_LOOKAHEAD) = (1 << k for k in range(18))
+ F_DIAG_MC_TIMES, F_MC_ROWS, F_COMBINE_FOLDED, F_RREF_NO_LOOKAHEAD, F_RREF_LOOKAHEAD, F_COMBINE_SEPARATE) = (1 << k for k in range(19))
 (OPT_SLAB_PASS_LOG2, OPT_COMBINE_BLOCKS, OPT_GATHER_REVERSE, OPT_REDO_BLOCKS_PER_CU, OPT_MC_CHUNK_LOG2, OPT_COMBINE_THREADS,
- OPT_GATHER_CROSS, OPT_GATHER_OVER) = range(8)
+ OPT_GATHER_CROSS, OPT_GATHER_OVER, OPT_RREF_SMALL_BCAST) = range(9)
 
 
 class GF2Error(RuntimeError):

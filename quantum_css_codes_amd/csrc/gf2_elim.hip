@@ -1204,7 +1204,7 @@ __global__ void nullspace_kernel(const u64* __restrict__ red, int64_t n, int64_t
 // About 20 vector instructions per pivot are left: the XORs themselves.  Grid-stride over the batch.
 #define SMALL_WAVES 4
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <int RPL, int LD>
+template <int RPL, int LD, bool VIA_LDS>
 __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __restrict__ base, int64_t batch, int m, int n, int64_t ld,
                                                                       int64_t* __restrict__ pivots_base, int64_t cap,
                                                                       int64_t* __restrict__ rank_out) {
@@ -1296,34 +1296,49 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
                 if (src_q < 0) continue;                            // no unused row has this column: not a pivot column
                 const int src_lane = __ffsll((long long)cand) - 1;
                 const u64 src_bit = 1ull << src_lane;
-                // the pivot row through LDS: written by its lane, read back by all at one address
-#pragma unroll
-                for (int q = 0; q < RPL; ++q) {
-                    if (q != src_q) continue;                       // uniform
-                    if (__builtin_amdgcn_inverse_ballot_w64(src_bit)) {
-#pragma unroll
-                        for (int dd = 0; dd < DW; dd += 4) {
-                            if (dd < d4) continue;
-                            if (DW >= 4)
-                                *reinterpret_cast<u32x4*>(bcast + dd) = u32x4{w[q][dd], w[q][dd + 1], w[q][dd + 2], w[q][dd + 3]};
-                            else
-                                for (int e = 0; e < DW; ++e) bcast[e] = w[q][e];
-                        }
-                        pivcol[q] = col;
-                        myrank[q] = rank;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 unsigned int pr[DW];
+                if (VIA_LDS) {
+                    // the pivot row through LDS: written by its lane, read back by all at one address (the LDS serves a wavefront's
+                    // operations in order: no wait between the two)
 #pragma unroll
-                for (int dd = 0; dd < DW; dd += 4) {
-                    if (dd < d4) continue;
-                    if (DW >= 4) {
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(bcast + dd);
-                        pr[dd] = v.x, pr[dd + 1] = v.y, pr[dd + 2] = v.z, pr[dd + 3] = v.w;
-                    } else
-                        for (int e = 0; e < DW; ++e) pr[e] = bcast[e];
+                    for (int q = 0; q < RPL; ++q) {
+                        if (q != src_q) continue;                   // uniform
+                        if (__builtin_amdgcn_inverse_ballot_w64(src_bit)) {
+#pragma unroll
+                            for (int dd = 0; dd < DW; dd += 4) {
+                                if (dd < d4) continue;
+                                if (DW >= 4)
+                                    *reinterpret_cast<u32x4*>(bcast + dd) = u32x4{w[q][dd], w[q][dd + 1], w[q][dd + 2], w[q][dd + 3]};
+                                else
+                                    for (int e = 0; e < DW; ++e) bcast[e] = w[q][e];
+                            }
+                            pivcol[q] = col;
+                            myrank[q] = rank;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int dd = 0; dd < DW; dd += 4) {
+                        if (dd < d4) continue;
+                        if (DW >= 4) {
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(bcast + dd);
+                            pr[dd] = v.x, pr[dd + 1] = v.y, pr[dd + 2] = v.z, pr[dd + 3] = v.w;
+                        } else
+                            for (int e = 0; e < DW; ++e) pr[e] = bcast[e];
+                    }
+                } else {
+                    // ... or lane to scalar registers with one v_readlane per dword
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) {
+                        if (q != src_q) continue;                   // uniform
+#pragma unroll
+                        for (int dd = 0; dd < DW; ++dd)
+                            if (dd >= d4) pr[dd] = (unsigned int)__builtin_amdgcn_readlane((int)w[q][dd], src_lane);
+                        if (__builtin_amdgcn_inverse_ballot_w64(src_bit)) {
+                            pivcol[q] = col;
+                            myrank[q] = rank;
+                        }
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < RPL; ++q) {
@@ -1403,8 +1418,12 @@ static int launch_rref_small(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m,
     int64_t blocks = gf2_cdiv(batch, SMALL_WAVES);
     if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
-    hipLaunchKernelGGL((rref_small_kernel<RPL, LD>), dim3((unsigned)blocks), dim3(64 * SMALL_WAVES), 0, ctx->stream, a_dev, batch, (int)m, (int)n,
-                       ld, pivots_dev, cap, rank_dev);
+    if (ctx->opt[GF2_OPT_RREF_SMALL_BCAST] == 1)
+        hipLaunchKernelGGL((rref_small_kernel<RPL, LD, false>), dim3((unsigned)blocks), dim3(64 * SMALL_WAVES), 0, ctx->stream, a_dev, batch,
+                           (int)m, (int)n, ld, pivots_dev, cap, rank_dev);
+    else
+        hipLaunchKernelGGL((rref_small_kernel<RPL, LD, true>), dim3((unsigned)blocks), dim3(64 * SMALL_WAVES), 0, ctx->stream, a_dev, batch,
+                           (int)m, (int)n, ld, pivots_dev, cap, rank_dev);
     GF2_TRY(gf2_prof_end(ctx));
     GF2_HIP(hipGetLastError());
     return GF2_OK;

@@ -107,6 +107,9 @@ struct gf2_check {
     void* lane_tab_dev;
     int slab_cols, slab_null, nslabs512;   // entries per row-part plane, index of a zero entry, row slabs
     uint64_t rows_small[64];
+    // n <= 4096: bit j = column j of the check has a 1 somewhere (a column of zeros changes no syndrome: the slab pipeline neither
+    // lists it nor sends the samples that have it through the redo pass)
+    uint64_t col_any[64];
 };
 
 int gf2_stream_wait(hipStream_t stream);            // polls, then blocks (gf2_ctx.hip)

@@ -44,6 +44,8 @@
 #define SLAB_MAX_COLS 2400                    // (cols + 1) * 64 bytes of LDS <= 150 KiB
 #define SLAB_MAX_BINS 2304
 #define SLAB_MAX_BATCH (1 << 24)              // most samples per pass through the workspace (record positions and buffer offsets are 32-bit)
+#define SLAB_GATHER_LDS_MAX (160 * 1024)      // what a workgroup may ask for: the slab's table, the ticket counter and, when the previous pass'
+                                              // combine step rides along, its counters
 #define SLAB_DEFAULT_BATCH (1 << 22)              // (2^21 until round 3: 2^22 is 5 % faster on two streams, 2^23 and 2^24 no more: profiles/r03_sweep_pass.log)
 
 // Records of a tile of 64 samples, sorted by count: the 32 shortest as 32-byte records (15 columns + header), the 32 longest
@@ -743,6 +745,16 @@ struct GatherArgs {
     int reverse;               // hand-scheduled kernel: walk the records from the last tile to the first (see gf2_syndrome_slabs)
     int cross;                 // hand-scheduled kernel: a step takes ranks 4k .. 4k + 3 of FOUR tiles instead of a quartile of one
     u64* clk;                  // debugging (GF2_GATHER_CLOCK): earliest entry / latest exit of the workgroups at [2], [3], else null
+    // the PREVIOUS pass' partial weights (its own buffer: the passes' weights alternate between two), summed into the histogram
+    // by this launch's workgroups while nothing of their own is in flight yet (hand-scheduled kernel; null: nothing to combine):
+    // the combine kernel's work without its launch, and without the two kernel boundaries around it, between two passes
+    const unsigned short* cmb_pw;
+    int64_t cmb_positions, cmb_pad;
+    unsigned int cmb_sample0;
+    int cmb_nbins;
+    u64* cmb_hist;
+    unsigned int* redo_count;
+    unsigned int* redo_list;
 };
 
 __device__ __forceinline__ unsigned int keep_rows(int r, int row0) {
@@ -1049,6 +1061,12 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
     // four wavefronts of a SIMD finish one after the other (the first after 55 % of the kernel's duration) and the last
     // quarter of the work runs on one wavefront per SIMD with nothing to hide its latencies behind.
     unsigned int* const next_step = reinterpret_cast<unsigned int*>(lds + (size_t)a.tab_stride * 64);
+    if (a.cmb_pw) {
+        // (its counters and staging area lie behind the table and the ticket counter; the host has checked that they fit)
+        unsigned int* const scratch = next_step + 4;
+        combine_positions(a.cmb_pw, a.cmb_positions, a.cmb_pad, a.nslabs, a.cmb_hist, a.cmb_nbins, a.redo_count, a.redo_list,
+                          a.cmb_sample0, scratch, scratch + SLAB_MAX_BINS, scratch + SLAB_MAX_BINS + 1024);
+    }
     if (threadIdx.x == 0) *next_step = 0;
     __syncthreads();
 
@@ -1287,26 +1305,50 @@ __global__ __launch_bounds__(1024) void slab_combine_kernel(const unsigned short
     if (clk && threadIdx.x == 0) atomicMax(&clk[1], (u64)wall_clock64());
 }
 
-// The samples on the redo list (they have a column that compact left out), one wavefront each, from the packed row.
+// The samples on the redo list (they have a column that compact left out), one wavefront each, from the packed row.  The next
+// listed sample's row is requested before this one's columns are gathered, and the weights are counted in LDS first: one global
+// atomic per listed sample (round 3) made 900 thousand of them per call of 2^27 samples on the sixty or so bins that the weights
+// of one check fall into.
 __global__ __launch_bounds__(256) void slab_redo_kernel(const u64* __restrict__ e, int64_t batch, int64_t lde,
                                                         const unsigned int* __restrict__ redo_count,
                                                         const unsigned int* __restrict__ redo_list, const uint32_t* __restrict__ ht, int r,
                                                         int n, int ident_off, u64* __restrict__ hist, uint32_t* __restrict__ syn,
                                                         int64_t lds32) {
     __shared__ unsigned int lists[4][SPARSE_LIST_CAP + 8];
+    __shared__ unsigned int bins[SLAB_MAX_BINS];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned int count = *redo_count;
+    if (blockIdx.x * 4u >= count) return;                           // (uniform over the workgroup: nothing listed for it)
+    if (hist) {
+        for (int i = threadIdx.x; i <= r; i += blockDim.x) bins[i] = 0;
+        __syncthreads();
+    }
     const SparseSide side = {ht, (int64_t)r, (int64_t)ident_off, nullptr, 0};
     const int words = (n + 63) >> 6;
-    for (unsigned int i = blockIdx.x * 4 + wave; i < count; i += gridDim.x * 4) {
-        const int64_t sample = (int64_t)redo_list[i];
-        if (sample >= batch) continue;                              // uniform
-        const u64 ww = lane < words ? e[sample * lde + lane] : 0ull;
+    const unsigned int stride = gridDim.x * 4u;
+    unsigned int i = blockIdx.x * 4u + wave;
+    auto row_of = [&](unsigned int at) -> int64_t {
+        const int64_t sample = at < count ? (int64_t)redo_list[at] : batch;
+        return sample < batch ? sample : -1;
+    };
+    int64_t sample = row_of(i);
+    u64 w_next = (sample >= 0 && lane < words) ? e[sample * lde + lane] : 0ull;
+    for (; i < count; i += stride) {
+        const u64 ww = w_next;
+        const int64_t mine = sample;
+        sample = row_of(i + stride);
+        w_next = (sample >= 0 && lane < words) ? e[sample * lde + lane] : 0ull;
+        if (mine < 0) continue;                                     // uniform
         unsigned int sdw;
         const unsigned int wt = sparse_component_weight(ww, side, n, lane, lists[wave], &sdw);
-        if (lane == 0 && hist) atomicAdd(&hist[wt], 1ull);
-        if (syn && lane < ((r + 63) >> 6) * 2) syn[sample * lds32 + lane] = sdw;       // over what the gather kernel stored without the column
+        if (lane == 0 && hist) atomicAdd(&bins[wt], 1u);
+        if (syn && lane < ((r + 63) >> 6) * 2) syn[mine * lds32 + lane] = sdw;       // over what the gather kernel stored without the column
+    }
+    if (hist) {
+        __syncthreads();
+        for (int k = threadIdx.x; k <= r; k += blockDim.x)
+            if (bins[k]) atomicAdd(&hist[k], (u64)bins[k]);
     }
 }
 
@@ -1383,16 +1425,22 @@ static StrayPlan plan_stray(const gf2_ctx* ctx, const gf2_check* ck) {
     for (int side = 0; side < 2; ++side) {
         const int64_t c0 = cand[side][0], c1 = cand[side][1];              // non-identity columns of the edge word
         if ((side == 0 && (lo & 63) == 0) || (side == 1 && ((hi & 63) == 0 || hi >= ck->n))) continue;
-        if (c1 - c0 < 1 || plan.n_cols + (c1 - c0) > 2) continue;
+        // (a column of zeros adds nothing to any syndrome: it needs neither a place in the records nor the redo pass -- the last
+        // column of H2 = first n - r_1 - 1 rows of [A^T | I] is one, BASELINE.json configs[3])
+        auto nonzero = [&](int64_t c) { return ((ck->col_any[c >> 6] >> (c & 63)) & 1ull) != 0; };
+        int64_t live = 0;
+        for (int64_t c = c0; c < c1; ++c) live += nonzero(c) ? 1 : 0;
+        if (c1 - c0 < 1 || plan.n_cols + live > 2) continue;
         bool visible = true;
-        for (int64_t c = c0; c < c1; ++c) visible = visible && (c >> 5) >= first_dw && (c >> 5) < last_dw;
+        for (int64_t c = c0; c < c1; ++c) visible = visible && (!nonzero(c) || ((c >> 5) >= first_dw && (c >> 5) < last_dw));
         if (!visible) continue;
         // the word must not hold non-identity columns on its other side too (r < 64)
         if ((side == 0 ? hi : lo) > (c0 >> 6) * 64 && (side == 0 ? hi : lo) < (c0 >> 6) * 64 + 64 && ck->r < 64) continue;
-        for (int64_t c = c0; c < c1; ++c) plan.col[plan.n_cols++] = (int)c;
+        for (int64_t c = c0; c < c1; ++c)
+            if (nonzero(c)) plan.col[plan.n_cols++] = (int)c;
         plan.skip_words |= 1ull << (c0 >> 6);
     }
-    if (!plan.n_cols) return none;
+    if (!plan.skip_words) return none;
     const int rounds_all = (CMP_SUB * non_identity_words(ck, 0) + 63) / 64;
     const int rounds_cut = (CMP_SUB * non_identity_words(ck, plan.skip_words) + 63) / 64;
     return rounds_cut < rounds_all ? plan : none;
@@ -1410,7 +1458,7 @@ static int slab_lds_optin(gf2_ctx* ctx) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64));
 #define GF2_GATHER_OPTIN(E, C, S)                                                                                  \
     GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(slab_gather_fast_kernel<E, C, S>),                     \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (SLAB_MAX_COLS + 16) * 64))
+                                hipFuncAttributeMaxDynamicSharedMemorySize, SLAB_GATHER_LDS_MAX))
         GF2_GATHER_OPTIN(false, false, false);
         GF2_GATHER_OPTIN(true, false, false);
         GF2_GATHER_OPTIN(false, true, false);
@@ -1427,7 +1475,7 @@ static int slab_lds_optin(gf2_ctx* ctx) {
 // syn (null: none): where the pass' first sample's syndrome goes, pitch bytes per sample; sink: 1 KiB for the lanes that store nothing
 static int launch_gather(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u32x4* rec, unsigned short* pw, int64_t count, int64_t pad,
                          int64_t lde, bool fast, const StrayPlan& stray, hipStream_t stream, u64* clk_dev, char* syn = nullptr,
-                         int64_t syn_pitch = 0, char* syn_sink = nullptr) {
+                         int64_t syn_pitch = 0, char* syn_sink = nullptr, const GatherArgs* combine_of = nullptr) {
     const size_t lds_bytes = (size_t)ck->slab_cols * 64;
     GatherArgs ga;
     ga.tab = (const u32x4*)ck->slab_tab_dev;
@@ -1450,6 +1498,24 @@ static int launch_gather(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u
     ga.syn_pitch = syn_pitch;
     ga.syn_sink = syn_sink;
     ga.syn_row = (int)gf2_words(ck->r) * 8;
+    ga.cmb_pw = nullptr;
+    ga.cmb_positions = ga.cmb_pad = 0;
+    ga.cmb_sample0 = 0;
+    ga.cmb_nbins = 0;
+    ga.cmb_hist = nullptr;
+    ga.redo_count = ga.redo_list = nullptr;
+    size_t extra_lds = 16;
+    if (combine_of && fast) {                                          // the previous pass' combine step rides in this launch
+        ga.cmb_pw = combine_of->cmb_pw;
+        ga.cmb_positions = combine_of->cmb_positions;
+        ga.cmb_pad = combine_of->cmb_pad;
+        ga.cmb_sample0 = combine_of->cmb_sample0;
+        ga.cmb_nbins = combine_of->cmb_nbins;
+        ga.cmb_hist = combine_of->cmb_hist;
+        ga.redo_count = combine_of->redo_count;
+        ga.redo_list = combine_of->redo_list;
+        extra_lds = 16 + (SLAB_MAX_BINS + 1024 + 2) * 4;
+    }
     ga.reverse = ctx->opt[GF2_OPT_GATHER_REVERSE] == 0 ? 0 : 1;
     ga.cross = ctx->opt[GF2_OPT_GATHER_CROSS] == 1 && !syn ? 1 : 0;       // (the cross-tile grouping has no variant that stores syndromes)
     // GF2_OPT_GATHER_OVER workgroups per CU over the launch (default 1): more of them let a CU that is done early take another
@@ -1462,17 +1528,17 @@ static int launch_gather(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u
     const dim3 ggrid((unsigned)(shares * ck->nslabs512));
     const bool extra = (ck->ident_off & 31) != 0;
     if (fast && syn && extra)
-        hipLaunchKernelGGL((slab_gather_fast_kernel<true, false, true>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+        hipLaunchKernelGGL((slab_gather_fast_kernel<true, false, true>), ggrid, dim3(GAT_THREADS), lds_bytes + extra_lds, stream, ga);
     else if (fast && syn)
-        hipLaunchKernelGGL((slab_gather_fast_kernel<false, false, true>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+        hipLaunchKernelGGL((slab_gather_fast_kernel<false, false, true>), ggrid, dim3(GAT_THREADS), lds_bytes + extra_lds, stream, ga);
     else if (fast && extra && ga.cross)
-        hipLaunchKernelGGL((slab_gather_fast_kernel<true, true, false>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+        hipLaunchKernelGGL((slab_gather_fast_kernel<true, true, false>), ggrid, dim3(GAT_THREADS), lds_bytes + extra_lds, stream, ga);
     else if (fast && extra)
-        hipLaunchKernelGGL((slab_gather_fast_kernel<true, false, false>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+        hipLaunchKernelGGL((slab_gather_fast_kernel<true, false, false>), ggrid, dim3(GAT_THREADS), lds_bytes + extra_lds, stream, ga);
     else if (fast && ga.cross)
-        hipLaunchKernelGGL((slab_gather_fast_kernel<false, true, false>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+        hipLaunchKernelGGL((slab_gather_fast_kernel<false, true, false>), ggrid, dim3(GAT_THREADS), lds_bytes + extra_lds, stream, ga);
     else if (fast)
-        hipLaunchKernelGGL((slab_gather_fast_kernel<false, false, false>), ggrid, dim3(GAT_THREADS), lds_bytes + 16, stream, ga);
+        hipLaunchKernelGGL((slab_gather_fast_kernel<false, false, false>), ggrid, dim3(GAT_THREADS), lds_bytes + extra_lds, stream, ga);
     else
         hipLaunchKernelGGL(slab_gather_kernel, ggrid, dim3(GAT_THREADS), lds_bytes, stream, ga);
     GF2_HIP(hipGetLastError());
@@ -1521,6 +1587,7 @@ struct SlabCall {
     unsigned int* redo_count;
     unsigned int* redo_list;
     bool fast, fold;
+    bool gfold;                    // the combine step of a pass rides in the next pass' gather kernel (two buffers of partial weights)
     StrayPlan stray;
 };
 
@@ -1537,7 +1604,7 @@ static int slab_call_setup(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_
     c->pass = slab_pass(ctx, batch);
     c->pad = gf2_cdiv(c->pass, 64) * 64;
     // records and partial weights of one pass; the redo list is the call's (one redo launch at the end)
-    const size_t rec_bytes = (size_t)c->pad * 64, pw_bytes = (size_t)ck->nslabs512 * c->pad * 2;
+    const size_t rec_bytes = (size_t)c->pad * 64, pw_bytes = 2 * (size_t)ck->nslabs512 * c->pad * 2;     // (two passes' partial weights)
     const size_t redo_bytes = (size_t)(batch > c->pad ? gf2_cdiv(batch, 64) * 64 : c->pad) * 4 + 256;
     GF2_TRY(gf2_ws_reserve(ctx, ws_slot, rec_bytes + pw_bytes + redo_bytes + 1024));
     c->rec = (u32x4*)ctx->ws[ws_slot];
@@ -1558,6 +1625,11 @@ static int slab_call_setup(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_
     // on the stream's critical path and are stretched by the other stream's big ones; measured: no change on two streams, 5 %
     // slower on one (1280 workgroups' worth of histogram atomics instead of 128: profiles/r02_sweep_fold.log).  Off by default.
     c->fold = gf2_flag(ctx, GF2_F_COMBINE_FOLDED) && !gf2_flag(ctx, GF2_F_DIAG_CLOCKS);
+    // Round 4: by default the combine step of pass k rides in the gather kernel of pass k + 1 instead (its workgroups do it before
+    // they ask for their first records; GF2_F_COMBINE_SEPARATE keeps the kernel after every pass): the hand-scheduled kernel only,
+    // and only if the counters fit behind the slab's table in LDS.
+    c->gfold = c->fast && !c->fold && !gf2_flag(ctx, GF2_F_COMBINE_SEPARATE) && !gf2_flag(ctx, GF2_F_DIAG_CLOCKS) &&
+               (size_t)ck->slab_cols * 64 + 16 + (SLAB_MAX_BINS + 1024 + 2) * 4 <= SLAB_GATHER_LDS_MAX && (hist_dev || c->stray.n_cols);
     return GF2_OK;
 }
 
@@ -1616,14 +1688,30 @@ static int launch_compact(gf2_ctx* ctx, const SlabCall& c, int64_t first, hipStr
     return GF2_OK;
 }
 
-// gather and (unless it rides in the next compact kernel) combine of the pass that starts at `first`.
+// gather and (unless it rides in the next compact or gather kernel) combine of the pass that starts at `first`.
 static int launch_rest_of_pass(gf2_ctx* ctx, const SlabCall& c, int64_t first, hipStream_t stream, u64* clk_dev) {
     const int64_t count = c.batch - first < c.pass ? c.batch - first : c.pass;
-    GF2_TRY(launch_gather(ctx, c.ck, c.e_dev + first * c.lde, c.rec, c.pw, count, c.pad, c.lde, c.fast, c.stray, stream, clk_dev,
-                          c.s_dev ? (char*)(c.s_dev + first * c.lds) : nullptr, c.lds * 8, c.syn_sink));
+    const int64_t index = first / c.pass;
+    const size_t pw_one = (size_t)c.ck->nslabs512 * c.pad;                         // partial weights of one pass (16-bit words)
+    unsigned short* const pw = c.pw + (c.gfold ? (size_t)(index & 1) * pw_one : 0);
+    GatherArgs prev;
+    const bool ride = c.gfold && first > 0;
+    if (ride) {
+        prev.cmb_pw = c.pw + (size_t)((index - 1) & 1) * pw_one;
+        prev.cmb_positions = c.pad;                                                 // (every pass before the last is a full one)
+        prev.cmb_pad = c.pad;
+        prev.cmb_sample0 = (unsigned int)(first - c.pass);
+        prev.cmb_nbins = (int)c.ck->r + 1;
+        prev.cmb_hist = (u64*)c.hist_dev;
+        prev.redo_count = c.redo_count;
+        prev.redo_list = c.redo_list;
+    }
+    GF2_TRY(launch_gather(ctx, c.ck, c.e_dev + first * c.lde, c.rec, pw, count, c.pad, c.lde, c.fast, c.stray, stream, clk_dev,
+                          c.s_dev ? (char*)(c.s_dev + first * c.lds) : nullptr, c.lds * 8, c.syn_sink, ride ? &prev : nullptr));
     if (!c.hist_dev && !c.stray.n_cols) return GF2_OK;               // syndromes only and nothing to list: no combine step
-    if (!c.fold || first + c.pass >= c.batch)
-        GF2_TRY(launch_combine(ctx, c.ck, c.pw, c.redo_count, c.redo_list, count, c.pad, (unsigned int)first, c.hist_dev, stream, clk_dev));
+    const bool last = first + c.pass >= c.batch;
+    if ((!c.fold && !c.gfold) || last)
+        GF2_TRY(launch_combine(ctx, c.ck, pw, c.redo_count, c.redo_list, count, c.pad, (unsigned int)first, c.hist_dev, stream, clk_dev));
     return GF2_OK;
 }
 
@@ -1664,7 +1752,7 @@ int gf2_syndrome_slabs(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_dev,
 int gf2_slabs_reserve(gf2_ctx* ctx, const gf2_check* ck, int64_t batch, int ws_slot) {
     const int64_t pass = slab_pass(ctx, batch);
     const int64_t pad = gf2_cdiv(pass, 64) * 64;
-    return gf2_ws_reserve(ctx, ws_slot, (size_t)pad * 64 + (size_t)ck->nslabs512 * pad * 2 + (size_t)pad * 4 + 256 + 1024);
+    return gf2_ws_reserve(ctx, ws_slot, (size_t)pad * 64 + 2 * (size_t)ck->nslabs512 * pad * 2 + (size_t)pad * 4 + 256 + 1024);
 }
 
 // ---- the Monte-Carlo run's own way in: records from the sampler ---------------------------------------------------------------

@@ -476,6 +476,9 @@ int gf2_check_create(gf2_ctx* ctx, const uint64_t* h, int64_t r, int64_t n, int6
     if ((rc = gf2_dev_alloc(ctx, hbytes, (void**)&ck->h_dev)) != GF2_OK) goto fail;
     if (r > 0 && n > 0 && (rc = gf2_h2d(ctx, ck->h_dev, h, (size_t)r * ld * 8)) != GF2_OK) goto fail;
 
+    if (n <= 4096 && n > 0)
+        for (int64_t i = 0; i < r; ++i)
+            for (int64_t w = 0; w < gf2_words(n); ++w) ck->col_any[w] |= h[i * ld + w];
     if (!ck->small && r > 0 && n > 0) {
         ck->ident_off = find_identity_block(h, r, n, ld);
         // per-slab list of 128-column pairs with a non-zero column outside the identity block

@@ -530,10 +530,15 @@ def test_monte_carlo_n4096_weight_histograms(ctx):
 
 def test_syndrome_table_on_the_config4_checks_and_what_the_reference_returns(config4_golden):
     # BASELINE.json configs[3]: "syndrome_table capped at weight <= 1" at n = 4096.  The drop-in's keys are exact integers of 2048
-    # (2047) bits: the weight-0 and weight-1 classes of both standard forms, 4097 entries each, in the reference's insertion order,
-    # against bin_matrix.vec_to_int restated on Python ints (oracle/cpu_ref.py on object arrays) of every column.  Beside it what
-    # the REFERENCE itself returns there (tests/golden/make_golden_config4.py ran its syndrome_table): t = 0 and the one-entry
-    # table {0: 0}, because its int64 keys wrap and the first weight-1 key collides with 0 (bin_matrix.py:40-43).
+    # (2047) bits; expected here from bin_matrix.vec_to_int restated on Python ints (oracle/cpu_ref.py on object arrays) of every
+    # column, in the reference's insertion order.
+    #   parity_check_c1 = [I | A]: 4097 distinct keys, the capped search answers t = 1 with the weight-0 and weight-1 classes;
+    #   parity_check_c2 = first 2047 rows of [A^T | I], standard form [A' | I | c]: its last column c is ZERO (the row that held
+    #   the last identity column's 1 is the one left out), so e_4095 has the zero error's syndrome: t = 0 and the table {0: 0},
+    #   exactly (the code has a weight-1 logical operator).
+    # Beside it what the REFERENCE itself returns (tests/golden/make_golden_config4.py ran its syndrome_table): t = 0 and {0: 0} for
+    # BOTH checks -- for c1 only because its int64 keys wrap (bin_matrix.py:40-43): the key of e_0, 2^2047, keeps its low 64 bits = 0
+    # (DESIGN.md section 5).
     import bench
     code, _, _ = bench.build_code()
     g = config4_golden
@@ -541,15 +546,17 @@ def test_syndrome_table_on_the_config4_checks_and_what_the_reference_returns(con
         assert int(g["ref_table_%s_t" % name]) == 0 and [int(k) for k in g["ref_table_%s_keys" % name]] == [0]
         t, table = css_code.syndrome_table(h, max_weight=1)
         hobj = np.array(h, dtype=object)
-        want_keys = [0] + [int(cpu_ref.vec_to_int(hobj[:, j])) for j in range(h.shape[1])]
-        assert len(set(want_keys)) == len(want_keys)                  # exact keys do not collide at weight 1 ...
-        assert t == 1 and list(table.keys()) == want_keys             # ... so the capped search answers t = 1
-        errs = np.array(list(table.values()))
-        assert not errs[0].any() and np.array_equal(errs[1:], np.identity(h.shape[1], dtype=int))
-        # the reference's keys are the low 64 bits of the exact ones: among THEM the weight-1 class collides (an identity column of
-        # one of the first r - 64 rows wraps to 0, the zero error's key), hence its t = 0
-        low = [k & 0xFFFFFFFFFFFFFFFF for k in want_keys]
-        assert len(set(low)) < len(low) and 0 in low[1:]
+        col_keys = [int(cpu_ref.vec_to_int(hobj[:, j])) for j in range(h.shape[1])]
+        if name == "c1":
+            assert len(set([0] + col_keys)) == 4097                   # exact keys do not collide at weight 1 ...
+            assert t == 1 and list(table.keys()) == [0] + col_keys    # ... so the capped search answers t = 1
+            errs = np.array(list(table.values()))
+            assert not errs[0].any() and np.array_equal(errs[1:], np.identity(h.shape[1], dtype=int))
+            # the reference's keys are the low 64 bits of the exact ones: the first weight-1 key is 0 there, the zero error's
+            assert col_keys[0] == 1 << 2047 and col_keys[0] & 0xFFFFFFFFFFFFFFFF == 0
+        else:
+            assert col_keys[4095] == 0 and not h[:, 4095].any()
+            assert t == 0 and list(table.keys()) == [0] and not table[0].any()
 
 
 def test_monte_carlo_on_the_config4_code_itself(ctx, route):
@@ -1223,7 +1230,10 @@ def test_syndrome_slab_pipeline(case, ctx, route):
 
 @pytest.mark.parametrize("case", [(2047, 4096, 2048, 3000, 0.007, None), (2046, 4096, 2048, 1500, 0.01, None),
                                   (2047, 4096, 2049, 1500, 0.007, None), (2047, 4096, 2048, 700, 0.004, 4095),
-                                  (1023, 2048, 1024, 2100, 0.01, None), (2045, 4096, 2048, 500, 0.01, None)])
+                                  (1023, 2048, 1024, 2100, 0.01, None), (2045, 4096, 2048, 500, 0.01, None),
+                                  # ... and the benchmark's own H2: that column is ZERO (first n - r_1 - 1 rows of [A^T | I]): nothing
+                                  # to list and nothing to redo; with a zero and a non-zero column side by side only the latter counts
+                                  (2047, 4096, 2048, 3000, 0.007, "zero"), (2046, 4096, 2048, 1500, 0.01, "zero")])
 def test_slab_pipeline_columns_left_to_the_redo_pass(case, ctx, route):
     # a check with one or two non-identity columns next to the identity block (H2 of a CSS code with k = 1, 2): compact leaves
     # their word out, the gather kernel flags the samples that have them and the redo kernel computes those from the row;
@@ -1233,6 +1243,10 @@ def test_slab_pipeline_columns_left_to_the_redo_pass(case, ctx, route):
     hm = rng.integers(0, 2, (r, n))
     hm[:, ioff:ioff + r] = np.identity(r, dtype=int)
     em = (rng.random((batch, n)) < density).astype(np.uint8)
+    if all_set == "zero":
+        hm[:, n - 1] = 0
+        em[:, n - 1] = rng.integers(0, 2, batch)               # half the samples have the column that changes nothing
+        all_set = None
     if all_set is not None:
         em[:, all_set] = 1                                     # every sample goes through the redo pass
     em[5] = (rng.random(n) < 0.03).astype(np.uint8)            # beyond a record's capacity: finished by compact
@@ -1293,9 +1307,9 @@ def test_syndrome_slab_pipeline_default_route_large_batch(ctx, route):
 
 @pytest.mark.parametrize("shape", [(2047, 4096, 2048), (2048, 4096, 0), (1000, 3000, 1024)])
 def test_slab_pipeline_many_passes_and_the_folded_combine_step(shape, ctx, route):
-    # a call of many passes (2^12 samples each here; 2^21 by default): a combine kernel after every pass, and the redo list
-    # (H2-shaped check: a column next to the identity block) is the call's, worked off once at the end.  With
-    # GF2_F_COMBINE_FOLDED the combine step between two passes is done by the next pass' compact kernel instead.  Same
+    # a call of many passes (2^12 samples each here; 2^22 by default): the combine step of a pass rides in the next pass' gather
+    # kernel (round 4; GF2_F_COMBINE_SEPARATE: a combine kernel after every pass, GF2_F_COMBINE_FOLDED: in the next pass' compact
+    # kernel), and the redo list (H2-shaped check: a column next to the identity block) is the call's, worked off once at the end.  Same
     # histogram either way, as the column-gather kernel and, on a prefix, as the oracle; ragged last pass and ragged last tile.
     r, n, ioff = shape
     batch = 9 * 4096 + 1234
@@ -1310,7 +1324,7 @@ def test_slab_pipeline_many_passes_and_the_folded_combine_step(shape, ctx, route
     got = {}
     ctx.set_option(_native.OPT_SLAB_PASS_LOG2, 12)
     try:
-        for name in ("default", "GF2_COMBINE_FOLDED", "GF2_NO_REDO"):
+        for name in ("default", "GF2_COMBINE_FOLDED", "GF2_COMBINE_SEPARATE", "GF2_NO_REDO"):
             if name != "default":
                 route.force(name)
             route.force("GF2_SPARSE_SLABS")
