@@ -1196,9 +1196,9 @@ __global__ void nullspace_kernel(const u64* __restrict__ red, int64_t n, int64_t
 //     loop over the 32 bits inside), so there is no select chain over the words of a row: a column's test is an AND and a compare;
 //   * which rows are still unused, and which rows have the bit, are 64-bit lane masks in scalar registers, and the rows that
 //     take the pivot row are the exec mask as it stands (inverse_ballot): no per-lane predicate arithmetic;
-//   * the pivot row travels through LDS (its lane writes it, every lane reads it back at one address: a broadcast) instead of
-//     sixteen v_readlane, and only from the 16-byte piece that holds the column on -- an unused row is zero to the left of the
-//     column, so the words before it cannot change;
+//   * the pivot row travels to scalar registers by v_readlane (one row per lane) or through LDS (more: its lane writes it, every
+//     lane reads it back at one address), and only from the 16-byte piece that holds the column on -- an unused row is zero to
+//     the left of the column, so the words before it cannot change;
 //   * a matrix whose rows are contiguous (ld == LD) is loaded and stored in 16-byte pieces, 1 KiB contiguous per instruction,
 //     and handed to / taken from the row-per-lane layout through LDS (80-byte row pitch: conflict-free 16-byte accesses).
 // About 20 vector instructions per pivot are left: the XORs themselves.  Grid-stride over the batch.
@@ -1418,7 +1418,11 @@ static int launch_rref_small(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m,
     int64_t blocks = gf2_cdiv(batch, SMALL_WAVES);
     if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
-    if (ctx->opt[GF2_OPT_RREF_SMALL_BCAST] == 1)
+    // the pivot row's way to the other rows: v_readlane into scalar registers when a lane holds one row (0.49 against 0.58 ms for
+    // 256 MiB of 64 x 512 matrices), LDS when it holds more (the same 0.72 ms for 128 x 512; with four rows per lane the scalar
+    // form runs out of registers); GF2_OPT_RREF_SMALL_BCAST forces one or the other
+    const bool readlane = ctx->opt[GF2_OPT_RREF_SMALL_BCAST] >= 0 ? ctx->opt[GF2_OPT_RREF_SMALL_BCAST] == 1 && RPL <= 2 : RPL == 1;
+    if (readlane)
         hipLaunchKernelGGL((rref_small_kernel<RPL, LD, false>), dim3((unsigned)blocks), dim3(64 * SMALL_WAVES), 0, ctx->stream, a_dev, batch,
                            (int)m, (int)n, ld, pivots_dev, cap, rank_dev);
     else
