@@ -129,10 +129,8 @@ int gf2_slabs_reserve(gf2_ctx* ctx, const gf2_check* ck, int64_t batch, int ws_s
 struct SegTables;
 bool gf2_mc_records_ok(const gf2_check* c1, const gf2_check* c2);
 size_t gf2_mc_records_bytes(int64_t n, int64_t pass);
-int gf2_mc_records_sample(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t seed, int64_t first_sample, int64_t count,
-                          int64_t pass, const SegTables& th, void* buf, hipStream_t stream);
-int gf2_mc_records_weigh(gf2_ctx* ctx, const gf2_check* ck, int comp, uint64_t seed, int64_t first_sample, int64_t count, int64_t pass,
-                         const SegTables& th, void* buf, uint64_t* hist_dev, hipStream_t stream, int ws_slot);
+int gf2_mc_records_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t seed, int64_t first_sample, int64_t count,
+                       int64_t pass, const SegTables& th, void* buf, uint64_t* hz_dev, uint64_t* hx_dev, hipStream_t stream);
 bool gf2_mc_sparse_fused_ok(const gf2_check* c1, const gf2_check* c2);
 int gf2_mc_sparse_fused(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t seed, int64_t first_sample,
                         int64_t count, double p_x, double p_y, double p_z, uint64_t* hz_dev, uint64_t* hx_dev);

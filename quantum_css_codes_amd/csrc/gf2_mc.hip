@@ -489,14 +489,7 @@ int gf2_mc_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t 
         uint64_t* dx = (uint64_t*)(q + set_bytes + al(hzb));
         GF2_TRY(gf2_dev_zero(ctx, dz, hzb));
         GF2_TRY(gf2_dev_zero(ctx, dx, hxb));
-        for (int64_t done = 0; done < count; done += chunk_s) {
-            const int64_t now = count - done < chunk_s ? count - done : chunk_s;
-            GF2_TRY(gf2_prof_begin(ctx, GF2_K_SAMPLER));
-            GF2_TRY(gf2_mc_records_sample(ctx, c1, c2, seed, first_sample + done, now, chunk_s, th, q, ctx->stream));
-            GF2_TRY(gf2_prof_end(ctx));
-            GF2_TRY(gf2_mc_records_weigh(ctx, c1, 1, seed, first_sample + done, now, chunk_s, th, q, dz, ctx->stream, 2));
-            GF2_TRY(gf2_mc_records_weigh(ctx, c2, 0, seed, first_sample + done, now, chunk_s, th, q, dx, ctx->stream, 3));
-        }
+        GF2_TRY(gf2_mc_records_run(ctx, c1, c2, seed, first_sample, count, chunk_s, th, q, dz, dx, ctx->stream));
         GF2_TRY(gf2_d2h(ctx, hist_z, dz, hzb));
         GF2_TRY(gf2_d2h(ctx, hist_x, dx, hxb));
         return GF2_OK;

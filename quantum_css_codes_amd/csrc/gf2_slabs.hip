@@ -481,7 +481,7 @@ __global__ __launch_bounds__(CMP_THREADS, T <= 4 ? 5 : (T <= 5 ? 4 : 3)) void sl
 struct RecSide {
     u32x4* rec;                  // the tile records (TILE_REC_BYTES per tile)
     u64* eident;                 // error rows of lde words of which only the words under the identity block are written
-    unsigned int* misfit_count;
+    unsigned int* misfit_count;  // (this chunk's slot of the two)
     unsigned int* misfit_list;   // sample index inside the pass
     int ident_off, r, null_ord;
     int seg_lo, seg_hi;          // segments whose words the gather kernel may read
@@ -698,20 +698,33 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
     }
 }
 
-// The listed samples once more, as packed rows of one component, and their weights by the wavefront-per-sample routine.
+// The listed samples once more, as packed rows of their component, and their weights by the wavefront-per-sample routine.  One
+// launch for both components (the first half of the workgroups: component 0).  The lists' counters come in two slots that the
+// chunks of a run take in turn: this launch reads slot `parity` and clears the other one for the next chunk's sampler (nobody
+// else touches it meanwhile) -- round 3 cleared them with two memsets per chunk and ran two launches.
 #define MISFIT_WAVES 4
-__global__ __launch_bounds__(64 * MISFIT_WAVES) void slab_misfit_kernel(const unsigned int* __restrict__ count_ptr,
-                                                                       const unsigned int* __restrict__ list, u64 seed,
-                                                                       int64_t first_sample, SegTables th, SparseSide side, int comp,
+struct MisfitArgs {
+    const unsigned int* count[2];    // per component: two counter slots
+    const unsigned int* list[2];
+    SparseSide side[2];
+    unsigned int* clear[2];          // the other slot of each component
+};
+__global__ __launch_bounds__(64 * MISFIT_WAVES) void slab_misfit_kernel(MisfitArgs a, int parity, u64 seed, int64_t first_sample, SegTables th,
                                                                        int64_t n) {
     __shared__ unsigned int img[MISFIT_WAVES][8 * 33];
     __shared__ unsigned int cols[MISFIT_WAVES][SPARSE_LIST_CAP + 8];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const unsigned int total = *count_ptr;
+    const int half = gridDim.x >> 1;
+    const int comp = (int)blockIdx.x >= half ? 1 : 0;
+    const int block = (int)blockIdx.x - comp * half;
+    if (block == 0 && threadIdx.x == 0) *a.clear[comp] = 0;
+    const unsigned int total = a.count[comp][parity];
+    const unsigned int* const list = a.list[comp];
+    const SparseSide side = a.side[comp];
     const int words = (int)((n + 63) >> 6);
     const bool last = lane == th.nseg - 1;
-    for (unsigned int e = blockIdx.x * MISFIT_WAVES + wave; e < total; e += gridDim.x * MISFIT_WAVES) {
+    for (unsigned int e = block * MISFIT_WAVES + wave; e < total; e += half * MISFIT_WAVES) {
         const u64 sample = (u64)(first_sample + (int64_t)list[e]);
         if (lane < th.nseg)
             sample_segment(sample_key(seed, sample), lane, last ? th.nb_last : GF2_SEG_BITS, th.cdf + (last ? GF2_SEG_CDF : 0), th.t_1,
@@ -751,7 +764,7 @@ struct GatherArgs {
     const unsigned short* cmb_pw;
     int64_t cmb_positions, cmb_pad;
     unsigned int cmb_sample0;
-    int cmb_nbins;
+    int cmb_nbins, cmb_nslabs;   // (of the check those weights belong to: the Monte-Carlo run's two components ride in each other's launches)
     u64* cmb_hist;
     unsigned int* redo_count;
     unsigned int* redo_list;
@@ -1064,7 +1077,7 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
     if (a.cmb_pw) {
         // (its counters and staging area lie behind the table and the ticket counter; the host has checked that they fit)
         unsigned int* const scratch = next_step + 4;
-        combine_positions(a.cmb_pw, a.cmb_positions, a.cmb_pad, a.nslabs, a.cmb_hist, a.cmb_nbins, a.redo_count, a.redo_list,
+        combine_positions(a.cmb_pw, a.cmb_positions, a.cmb_pad, a.cmb_nslabs, a.cmb_hist, a.cmb_nbins, a.redo_count, a.redo_list,
                           a.cmb_sample0, scratch, scratch + SLAB_MAX_BINS, scratch + SLAB_MAX_BINS + 1024);
     }
     if (threadIdx.x == 0) *next_step = 0;
@@ -1501,7 +1514,7 @@ static int launch_gather(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u
     ga.cmb_pw = nullptr;
     ga.cmb_positions = ga.cmb_pad = 0;
     ga.cmb_sample0 = 0;
-    ga.cmb_nbins = 0;
+    ga.cmb_nbins = ga.cmb_nslabs = 0;
     ga.cmb_hist = nullptr;
     ga.redo_count = ga.redo_list = nullptr;
     size_t extra_lds = 16;
@@ -1511,6 +1524,7 @@ static int launch_gather(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u
         ga.cmb_pad = combine_of->cmb_pad;
         ga.cmb_sample0 = combine_of->cmb_sample0;
         ga.cmb_nbins = combine_of->cmb_nbins;
+        ga.cmb_nslabs = combine_of->cmb_nslabs;
         ga.cmb_hist = combine_of->cmb_hist;
         ga.redo_count = combine_of->redo_count;
         ga.redo_list = combine_of->redo_list;
@@ -1702,6 +1716,7 @@ static int launch_rest_of_pass(gf2_ctx* ctx, const SlabCall& c, int64_t first, h
         prev.cmb_pad = c.pad;
         prev.cmb_sample0 = (unsigned int)(first - c.pass);
         prev.cmb_nbins = (int)c.ck->r + 1;
+        prev.cmb_nslabs = c.ck->nslabs512;
         prev.cmb_hist = (u64*)c.hist_dev;
         prev.redo_count = c.redo_count;
         prev.redo_list = c.redo_list;
@@ -1787,69 +1802,119 @@ size_t gf2_mc_records_bytes(int64_t n, int64_t pass) {
     return 2 * (row + ((rec + 255) & ~(size_t)255) + mis);
 }
 
-// Draws samples first_sample .. + count (count <= the pass the buffers were sized for) into `buf`: records, identity words and
-// misfit lists of both components, on `stream`.
-int gf2_mc_records_sample(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t seed, int64_t first_sample, int64_t count,
-                          int64_t pass, const SegTables& th, void* buf, hipStream_t stream) {
+// The Monte-Carlo run's chunks (gf2_mc_run at n <= 4096, sparse rates; buf: one buffer set of gf2_mc_records_bytes(n, pass) bytes,
+// hz / hx: the two weight histograms on the device, accumulated into), all on `stream`.  Per chunk of at most `pass` samples:
+//   the record sampler (records, identity words and misfit lists of both components);
+//   gather Z (against c1), with the combine step of the PREVIOUS chunk's X component in its workgroups' prologue;
+//   gather X (against c2), with the combine step of this chunk's Z component in its prologue;
+//   one launch of the misfit kernel for both components.
+// Four launches per chunk (round 3: nine operations -- two memsets of the misfit counters, the sampler, and gather, combine, misfit per
+// component); the last chunk's X component is combined by a launch of its own at the end.
+int gf2_mc_records_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, uint64_t seed, int64_t first_sample, int64_t count,
+                       int64_t pass, const SegTables& th, void* buf, uint64_t* hz_dev, uint64_t* hx_dev, hipStream_t stream) {
+    GF2_TRY(slab_lds_optin(ctx));
     const int64_t n = c1->n, lde = gf2_words(n);
     const size_t pad = (size_t)gf2_cdiv(pass, 64) * 64;
-    const size_t row = (size_t)pad * lde * 8, rec = ((pad / 64 * TILE_REC_BYTES) + 255) & ~(size_t)255, mis = 256 + pad * 4;
-    RecSamplerArgs a;
-    a.seed = seed;
-    a.first_sample = first_sample;
-    a.count = count;
-    a.lde = lde;
-    a.th = th;
-    a.n = (int)n;
-    char* q = (char*)buf;
-    for (int c = 0; c < 2; ++c) {
-        const gf2_check* ck = c == 0 ? c2 : c1;                      // X errors against H2, Z errors against H1 (css_code.py:457-470)
-        RecSide& sd = a.side[c];
-        sd.eident = (u64*)q; q += row;
-        sd.rec = (u32x4*)q; q += rec;
-        sd.misfit_count = (unsigned int*)q;
-        sd.misfit_list = (unsigned int*)q + 64;
-        q += mis;
-        sd.ident_off = (int)ck->ident_off;
-        sd.r = (int)ck->r;
-        sd.null_ord = ck->slab_null;
-        identity_segments(ck, th.nseg, &sd.seg_lo, &sd.seg_hi);
-        GF2_HIP(hipMemsetAsync(sd.misfit_count, 0, 256, stream));
-    }
-    int64_t blocks = gf2_cdiv(count, 64);
-    // one wavefront per workgroup, 17 KiB of LDS each: 9 per CU (2, 4, 6 per CU: 0.31, 0.61, 0.78 of the rate at 9 -- the kernel
-    // is bound by what one wavefront issues, and more of them is what helps)
-    if (blocks > (int64_t)ctx->num_cus * 9) blocks = (int64_t)ctx->num_cus * 9;
-    hipLaunchKernelGGL(slab_record_sampler_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, a);
-    GF2_HIP(hipGetLastError());
-    return GF2_OK;
-}
-
-// gather -> combine -> misfits of component `comp` (0: X against c2 = ck, 1: Z against c1 = ck) of a buffer set, on `stream`;
-// partial weights in workspace `ws_slot`.
-int gf2_mc_records_weigh(gf2_ctx* ctx, const gf2_check* ck, int comp, uint64_t seed, int64_t first_sample, int64_t count, int64_t pass,
-                         const SegTables& th, void* buf, uint64_t* hist_dev, hipStream_t stream, int ws_slot) {
-    GF2_TRY(slab_lds_optin(ctx));
-    const int64_t n = ck->n, lde = gf2_words(n);
-    const size_t pad = (size_t)gf2_cdiv(pass, 64) * 64;
     const size_t row = (size_t)pad * lde * 8, rec_b = ((pad / 64 * TILE_REC_BYTES) + 255) & ~(size_t)255, mis = 256 + pad * 4;
-    char* q = (char*)buf + (size_t)comp * (row + rec_b + mis);
-    const uint64_t* eident = (const uint64_t*)q;
-    u32x4* rec = (u32x4*)(q + row);
-    unsigned int* misfit_count = (unsigned int*)(q + row + rec_b);
-    const size_t pw_bytes = (size_t)ck->nslabs512 * pad * 2, redo_bytes = (size_t)pad * 4 + 256;
-    GF2_TRY(gf2_ws_reserve(ctx, ws_slot, (size_t)pad * 64 + pw_bytes + redo_bytes));
-    unsigned short* pw = (unsigned short*)((char*)ctx->ws[ws_slot] + (size_t)pad * 64);
-    unsigned int* redo_count = (unsigned int*)((char*)ctx->ws[ws_slot] + (size_t)pad * 64 + pw_bytes);
-    const int64_t first_dw = ck->ident_off >> 5;
-    const bool fast = (lde & 1) == 0 && (first_dw & 3) == 0 && first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) <= lde * 2 &&
-                      !gf2_flag(ctx, GF2_F_GATHER_GENERIC);
+    // component 0: X errors against c2, component 1: Z errors against c1 (css_code.py:457-470)
+    const gf2_check* cks[2] = {c2, c1};
+    uint64_t* hists[2] = {hx_dev, hz_dev};
+    const int ws_slots[2] = {3, 2};
+    struct Side {
+        const uint64_t* eident;
+        u32x4* rec;
+        unsigned int* counters;      // two slots, then (from word 64 on) the list
+        unsigned short* pw;
+        unsigned int* redo_count;
+        bool fast, can_carry;
+    } side[2];
+    for (int c = 0; c < 2; ++c) {
+        const gf2_check* ck = cks[c];
+        char* q = (char*)buf + (size_t)c * (row + rec_b + mis);
+        side[c].eident = (const uint64_t*)q;
+        side[c].rec = (u32x4*)(q + row);
+        side[c].counters = (unsigned int*)(q + row + rec_b);
+        const size_t pw_bytes = (size_t)ck->nslabs512 * pad * 2, redo_bytes = (size_t)pad * 4 + 256;
+        GF2_TRY(gf2_ws_reserve(ctx, ws_slots[c], (size_t)pad * 64 + pw_bytes + redo_bytes));
+        side[c].pw = (unsigned short*)((char*)ctx->ws[ws_slots[c]] + (size_t)pad * 64);
+        side[c].redo_count = (unsigned int*)((char*)ctx->ws[ws_slots[c]] + (size_t)pad * 64 + pw_bytes);
+        const int64_t first_dw = ck->ident_off >> 5;
+        side[c].fast = (lde & 1) == 0 && (first_dw & 3) == 0 && first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) <= lde * 2 &&
+                       !gf2_flag(ctx, GF2_F_GATHER_GENERIC);
+        // its launch can carry the other component's combine step: the hand-scheduled kernel, and room behind its table
+        side[c].can_carry = side[c].fast && !gf2_flag(ctx, GF2_F_COMBINE_SEPARATE) &&
+                            (size_t)ck->slab_cols * 64 + 16 + (SLAB_MAX_BINS + 1024 + 2) * 4 <= SLAB_GATHER_LDS_MAX;
+        GF2_HIP(hipMemsetAsync(side[c].counters, 0, 256, stream));          // both slots, once per run
+    }
     const StrayPlan none = {0, 0, {0, 0}};
-    GF2_TRY(launch_gather(ctx, ck, eident, rec, pw, count, (int64_t)pad, lde, fast, none, stream, nullptr));
-    GF2_TRY(launch_combine(ctx, ck, pw, redo_count, redo_count + 64, count, (int64_t)pad, 0u, hist_dev, stream, nullptr));
-    const SparseSide side = {ck->ht_dev, ck->r, ck->ident_off, (u64*)hist_dev, (int)(ck->r + 1)};
-    hipLaunchKernelGGL(slab_misfit_kernel, dim3(64), dim3(64 * MISFIT_WAVES), 0, stream, (const unsigned int*)misfit_count,
-                       (const unsigned int*)(misfit_count + 64), (u64)seed, first_sample, th, side, comp, n);
-    GF2_HIP(hipGetLastError());
-    return GF2_OK;
+    GatherArgs pending;                                               // the combine step nobody has done yet
+    int pending_of = -1;
+    int64_t pending_count = 0;
+    auto flush = [&]() -> int {                                       // ... by a launch of its own
+        if (pending_of < 0) return GF2_OK;
+        const Side& sd = side[pending_of];
+        GF2_TRY(launch_combine(ctx, cks[pending_of], sd.pw, sd.redo_count, sd.redo_count + 64, pending_count, (int64_t)pad, 0u,
+                               hists[pending_of], stream, nullptr));
+        pending_of = -1;
+        return GF2_OK;
+    };
+    int64_t chunk = 0;
+    for (int64_t done = 0; done < count; done += pass, ++chunk) {
+        const int64_t now = count - done < pass ? count - done : pass;
+        const int parity = (int)(chunk & 1);
+        RecSamplerArgs a;
+        a.seed = seed;
+        a.first_sample = first_sample + done;
+        a.count = now;
+        a.lde = lde;
+        a.th = th;
+        a.n = (int)n;
+        for (int c = 0; c < 2; ++c) {
+            RecSide& sd = a.side[c];
+            sd.eident = const_cast<u64*>((const u64*)side[c].eident);
+            sd.rec = side[c].rec;
+            sd.misfit_count = side[c].counters + parity;
+            sd.misfit_list = side[c].counters + 64;
+            sd.ident_off = (int)cks[c]->ident_off;
+            sd.r = (int)cks[c]->r;
+            sd.null_ord = cks[c]->slab_null;
+            identity_segments(cks[c], th.nseg, &sd.seg_lo, &sd.seg_hi);
+        }
+        int64_t blocks = gf2_cdiv(now, 64);
+        // one wavefront per workgroup, 17 KiB of LDS each: 9 per CU (2, 4, 6 per CU: 0.31, 0.61, 0.78 of the rate at 9 -- the kernel
+        // is bound by what one wavefront issues, and more of them is what helps)
+        if (blocks > (int64_t)ctx->num_cus * 9) blocks = (int64_t)ctx->num_cus * 9;
+        GF2_TRY(gf2_prof_begin(ctx, GF2_K_SAMPLER));
+        hipLaunchKernelGGL(slab_record_sampler_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, a);
+        GF2_TRY(gf2_prof_end(ctx));
+        GF2_HIP(hipGetLastError());
+        for (int c = 1; c >= 0; --c) {                                // Z first, then X
+            const Side& sd = side[c];
+            const bool carry = pending_of >= 0 && sd.can_carry;
+            if (pending_of >= 0 && !carry) GF2_TRY(flush());
+            GF2_TRY(launch_gather(ctx, cks[c], sd.eident, sd.rec, sd.pw, now, (int64_t)pad, lde, sd.fast, none, stream, nullptr, nullptr, 0,
+                                  nullptr, carry ? &pending : nullptr));
+            pending.cmb_pw = sd.pw;                                   // this component's own combine step is due now
+            pending.cmb_positions = gf2_cdiv(now, 64) * 64;
+            pending.cmb_pad = (int64_t)pad;
+            pending.cmb_sample0 = 0;
+            pending.cmb_nbins = (int)cks[c]->r + 1;
+            pending.cmb_nslabs = cks[c]->nslabs512;
+            pending.cmb_hist = (u64*)hists[c];
+            pending.redo_count = sd.redo_count;
+            pending.redo_list = sd.redo_count + 64;
+            pending_of = c;
+            pending_count = now;
+        }
+        MisfitArgs ma;
+        for (int c = 0; c < 2; ++c) {
+            ma.count[c] = side[c].counters;
+            ma.list[c] = side[c].counters + 64;
+            ma.side[c] = SparseSide{cks[c]->ht_dev, cks[c]->r, cks[c]->ident_off, (u64*)hists[c], (int)(cks[c]->r + 1)};
+            ma.clear[c] = side[c].counters + (parity ^ 1);
+        }
+        hipLaunchKernelGGL(slab_misfit_kernel, dim3(128), dim3(64 * MISFIT_WAVES), 0, stream, ma, parity, (u64)seed, first_sample + done, th, n);
+        GF2_HIP(hipGetLastError());
+    }
+    return flush();
 }
