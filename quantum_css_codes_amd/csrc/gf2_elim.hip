@@ -1204,7 +1204,7 @@ __global__ void nullspace_kernel(const u64* __restrict__ red, int64_t n, int64_t
 // About 20 vector instructions per pivot are left: the XORs themselves.  Grid-stride over the batch.
 #define SMALL_WAVES 4
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-template <int RPL, int LD, bool VIA_LDS>
+template <int RPL, int LD, int RL>
 __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __restrict__ base, int64_t batch, int m, int n, int64_t ld,
                                                                       int64_t* __restrict__ pivots_base, int64_t cap,
                                                                       int64_t* __restrict__ rank_out) {
@@ -1296,48 +1296,51 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
                 if (src_q < 0) continue;                            // no unused row has this column: not a pivot column
                 const int src_lane = __ffsll((long long)cand) - 1;
                 const u64 src_bit = 1ull << src_lane;
+                // The pivot row's way to the other rows.  Two ways, and the kernel uses both: dwords d4 .. split - 1 by v_readlane into
+                // scalar registers (a vector instruction each), the rest through LDS (written by the pivot's lane, read back by all
+                // at one address; the LDS serves a wavefront's operations in order, so no wait between the two) -- the LDS round trip
+                // runs under the readlanes and the XORs of the first part.  All by readlane is bound by issuing them, all through LDS by
+                // the round trip and the LDS itself (RL = dwords by readlane, counted from d4).
+                const int split = d4 + RL < DW ? (d4 + RL + 3) & ~3 : DW;         // (whole 16-byte pieces go through LDS; a constant after unrolling)
                 unsigned int pr[DW];
-                if (VIA_LDS) {
-                    // the pivot row through LDS: written by its lane, read back by all at one address (the LDS serves a wavefront's
-                    // operations in order: no wait between the two)
 #pragma unroll
-                    for (int q = 0; q < RPL; ++q) {
-                        if (q != src_q) continue;                   // uniform
-                        if (__builtin_amdgcn_inverse_ballot_w64(src_bit)) {
+                for (int q = 0; q < RPL; ++q) {
+                    if (q != src_q) continue;                       // uniform
+                    if (__builtin_amdgcn_inverse_ballot_w64(src_bit)) {
+                        if constexpr (DW >= 4) {
 #pragma unroll
                             for (int dd = 0; dd < DW; dd += 4) {
-                                if (dd < d4) continue;
-                                if (DW >= 4)
-                                    *reinterpret_cast<u32x4*>(bcast + dd) = u32x4{w[q][dd], w[q][dd + 1], w[q][dd + 2], w[q][dd + 3]};
-                                else
-                                    for (int e = 0; e < DW; ++e) bcast[e] = w[q][e];
+                                if (dd < split) continue;
+                                *reinterpret_cast<u32x4*>(bcast + dd) = u32x4{w[q][dd], w[q][dd + 1], w[q][dd + 2], w[q][dd + 3]};
                             }
-                            pivcol[q] = col;
-                            myrank[q] = rank;
                         }
+                        pivcol[q] = col;
+                        myrank[q] = rank;
                     }
-                    __builtin_amdgcn_wave_barrier();
+                }
+                __builtin_amdgcn_wave_barrier();
+                if constexpr (DW >= 4) {
 #pragma unroll
-                    for (int dd = 0; dd < DW; dd += 4) {
-                        if (dd < d4) continue;
-                        if (DW >= 4) {
+                    for (int dd = 0; dd < DW; dd += 4)
+                        if (dd >= split) {
                             const u32x4 v = *reinterpret_cast<const u32x4*>(bcast + dd);
                             pr[dd] = v.x, pr[dd + 1] = v.y, pr[dd + 2] = v.z, pr[dd + 3] = v.w;
-                        } else
-                            for (int e = 0; e < DW; ++e) pr[e] = bcast[e];
-                    }
-                } else {
-                    // ... or lane to scalar registers with one v_readlane per dword
+                        }
+                }
 #pragma unroll
-                    for (int q = 0; q < RPL; ++q) {
-                        if (q != src_q) continue;                   // uniform
+                for (int q = 0; q < RPL; ++q) {
+                    if (q != src_q) continue;                       // uniform
+#pragma unroll
+                    for (int dd = 0; dd < DW; ++dd)
+                        if (dd >= d4 && dd < split) pr[dd] = (unsigned int)__builtin_amdgcn_readlane((int)w[q][dd], src_lane);
+                }
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    const u64 take = q == src_q ? has[q] & ~src_bit : has[q];
+                    if (__builtin_amdgcn_inverse_ballot_w64(take)) {
 #pragma unroll
                         for (int dd = 0; dd < DW; ++dd)
-                            if (dd >= d4) pr[dd] = (unsigned int)__builtin_amdgcn_readlane((int)w[q][dd], src_lane);
-                        if (__builtin_amdgcn_inverse_ballot_w64(src_bit)) {
-                            pivcol[q] = col;
-                            myrank[q] = rank;
-                        }
+                            if (dd >= d4 && dd < split) w[q][dd] ^= pr[dd];
                     }
                 }
 #pragma unroll
@@ -1346,7 +1349,7 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
                     if (__builtin_amdgcn_inverse_ballot_w64(take)) {
 #pragma unroll
                         for (int dd = 0; dd < DW; ++dd)
-                            if (dd >= d4) w[q][dd] ^= pr[dd];
+                            if (dd >= split) w[q][dd] ^= pr[dd];
                     }
                 }
                 unused[src_q < 0 ? 0 : src_q] &= ~src_bit;
@@ -1418,16 +1421,25 @@ static int launch_rref_small(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m,
     int64_t blocks = gf2_cdiv(batch, SMALL_WAVES);
     if (blocks > (int64_t)ctx->num_cus * 8) blocks = (int64_t)ctx->num_cus * 8;
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
-    // the pivot row's way to the other rows: v_readlane into scalar registers when a lane holds one row (0.49 against 0.58 ms for
-    // 256 MiB of 64 x 512 matrices), LDS when it holds more (the same 0.72 ms for 128 x 512; with four rows per lane the scalar
-    // form runs out of registers); GF2_OPT_RREF_SMALL_BCAST forces one or the other
-    const bool readlane = ctx->opt[GF2_OPT_RREF_SMALL_BCAST] >= 0 ? ctx->opt[GF2_OPT_RREF_SMALL_BCAST] == 1 && RPL <= 2 : RPL == 1;
-    if (readlane)
-        hipLaunchKernelGGL((rref_small_kernel<RPL, LD, false>), dim3((unsigned)blocks), dim3(64 * SMALL_WAVES), 0, ctx->stream, a_dev, batch,
-                           (int)m, (int)n, ld, pivots_dev, cap, rank_dev);
+    // dwords of the pivot row by v_readlane, the rest through LDS (see the kernel): GF2_OPT_RREF_SMALL_BCAST 0 = all through LDS,
+    // 1 = all by readlane where the registers allow (up to two rows per lane), default = half and half
+    const int64_t how = ctx->opt[GF2_OPT_RREF_SMALL_BCAST];
+    const dim3 grid((unsigned)blocks), block(64 * SMALL_WAVES);
+    if (LD < 2)                                                     // (a row of two dwords is no 16-byte piece: by readlane)
+        hipLaunchKernelGGL((rref_small_kernel<RPL, LD, 2 * LD>), grid, block, 0, ctx->stream, a_dev, batch, (int)m, (int)n, ld, pivots_dev,
+                           cap, rank_dev);
+    else if (how == 0)
+        hipLaunchKernelGGL((rref_small_kernel<RPL, LD, 0>), grid, block, 0, ctx->stream, a_dev, batch, (int)m, (int)n, ld, pivots_dev, cap,
+                           rank_dev);
+    else if (how == 1 && RPL <= 2)
+        hipLaunchKernelGGL((rref_small_kernel<RPL, LD, 2 * LD>), grid, block, 0, ctx->stream, a_dev, batch, (int)m, (int)n, ld, pivots_dev,
+                           cap, rank_dev);
     else
-        hipLaunchKernelGGL((rref_small_kernel<RPL, LD, true>), dim3((unsigned)blocks), dim3(64 * SMALL_WAVES), 0, ctx->stream, a_dev, batch,
-                           (int)m, (int)n, ld, pivots_dev, cap, rank_dev);
+        // one row of at most 16 dwords per lane: half and half (256 MiB of 64 x 512 matrices: 0.43 ms; all by readlane 0.49, all
+        // through LDS 0.58); longer rows or more rows per lane: all through LDS (64 x 1024: 0.83 against 1.10 and 1.22 ms; 128 x 512:
+        // 0.72 against 0.76 and 0.79) -- gpurun_out/r04/rref_small_hybrid.log
+        hipLaunchKernelGGL((rref_small_kernel<RPL, LD, (RPL == 1 && LD <= 8 ? LD : 0)>), grid, block, 0, ctx->stream, a_dev, batch, (int)m,
+                           (int)n, ld, pivots_dev, cap, rank_dev);
     GF2_TRY(gf2_prof_end(ctx));
     GF2_HIP(hipGetLastError());
     return GF2_OK;
