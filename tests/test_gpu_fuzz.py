@@ -146,6 +146,25 @@ def test_fuzz_sparse_weight_histograms_three_routes(ctx):
             finally:
                 ctx.set_flags(keep)
             assert np.array_equal(got, want), label + ", flags %x" % flags
+        # ... and the syndromes themselves, stored by the slab pipeline (round 4) and by the column-gather kernel, at the tightest
+        # pitch and a wider one, with and without the histogram
+        want_s = c_oracle.syndrome_batch(h, r, n, e, batch)
+        for flags in (_native.F_SPARSE_SLABS, _native.F_SPARSE_GATHER):
+            keep = ctx.get_flags()
+            ctx.set_flags(keep | flags)
+            try:
+                lds = want_s.shape[1] + int(rng.integers(0, 3))
+                s_buf = ctx.alloc(batch * lds * 8).zero()
+                with_hist = bool(rng.integers(0, 2))
+                hist = ctx.alloc((r + 1) * 8).zero()
+                ctx.syndrome_sparse_dev(chk, e_buf, batch, lde, s_buf, lds, hist if with_hist else None, r + 1 if with_hist else 0)
+                got_s = s_buf.download((batch, lds), np.uint64)[:, :want_s.shape[1]]
+                got = hist.download((r + 1,), np.uint64)
+                s_buf.free(), hist.free()
+            finally:
+                ctx.set_flags(keep)
+            assert np.array_equal(got_s, want_s), label + ", stored syndromes, flags %x" % flags
+            assert not with_hist or np.array_equal(got, want), label + ", histogram beside the syndromes, flags %x" % flags
         e_buf.free()
 
 
@@ -286,3 +305,41 @@ def test_fuzz_decode_and_tally_random_small_codes():
         assert [big[f] for f in fields] == [int(v) for v in want], label
         done += 1
     assert done >= 6
+
+
+def test_fuzz_hashed_tables_and_decode_random_dual_pairs():
+    # random k = 1 dual pairs of 26 .. 128 qubits with checks on either side of the 24-row and 63-row marks: both syndrome tables
+    # through the device hash table (css_code.py:715-735; keys of one or two words) against the C oracle's enumeration -- t, keys
+    # in the reference's insertion order, errors --, then the table decode and logical tally (css_code.py:649-685, 599-646) of
+    # 10^5 sampled errors through gf2_mc_decode_hashed against the oracle's tally with the oracle's own tables
+    from quantum_css_codes_amd import bin_matrix, css_code, montecarlo
+    from quantum_css_codes_amd.css_code import CSSCode
+    rng = np.random.default_rng(20268)
+    for case in range(10):
+        n = int(rng.choice([26, 40, 51, 57, 63, 64, 65, 90, 127, 128]))
+        r1 = int(rng.integers(max(2, n // 8), n - 3))
+        while True:
+            h1 = rng.integers(0, 2, (r1, n))
+            if bin_matrix.rank(h1) == r1:
+                break
+        null = bin_matrix.nullspace(h1)
+        h2 = null[: null.shape[0] - 1]
+        cap = int(rng.choice([1, 2, 3])) if n > 70 else int(rng.choice([2, 3, 4]))
+        code = CSSCode(h1, h2, max_table_weight=cap)
+        label = "case %d: n %d, r1 %d, r2 %d, cap %d" % (case, n, code.r_1, code.r_2, cap)
+        tables = []
+        for h, table in ((code.parity_check_c1, code._c1_syndromes), (code.parity_check_c2, code._c2_syndromes)):
+            r = h.shape[0]
+            t, keys, errs = c_oracle.syndrome_table(c_oracle.pack_rows(h), r, n, cap)
+            assert list(table.keys()) == keys, label
+            assert np.array_equal(np.array(list(table.values())), c_oracle.unpack_rows(errs, n)), label
+            tables.append((t, keys, errs))
+        assert code.t == min(tables[0][0], tables[1][0]), label
+        p = [float(v) for v in rng.choice([0.0, 0.002, 0.01, 0.03, 0.1], size=3)]
+        count, first = 100000, int(rng.integers(0, 1 << 40))
+        got = montecarlo.decode_local(code, count, *p, seed=case, first_sample=first, hashed=True)
+        want = c_oracle.mc_decode_wide(c_oracle.pack_rows(code.parity_check_c1), code.r_1, c_oracle.pack_rows(code.parity_check_c2), code.r_2,
+                                       n, tables[0][1], tables[0][2], tables[1][1], tables[1][2],
+                                       c_oracle.pack_rows(code.x_operator_matrix())[0], c_oracle.pack_rows(code.z_operator_matrix())[0],
+                                       case, first, count, *p)
+        assert [got[f] for f in montecarlo.DECODE_FIELDS] == [int(v) for v in want], label
