@@ -9,7 +9,9 @@
 root=$(pwd); out=$root/gpurun_out/r04; mkdir -p $out
 git -C $root rev-parse HEAD > $out/ev_commit.txt 2>/dev/null || echo "(no git on the box: see the commit that holds this file)" > $out/ev_commit.txt
 cd /tmp && export TMPDIR=/tmp
-A="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-settle --batch-log2 22"
+# (2^24 samples per step = four passes per call: the combine step of three of them rides in the next gather launch, as in the
+# default run of 32 passes per call; a call's last pass is combined by a launch of its own)
+A="--steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-settle --batch-log2 24"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ev_trace_two -- python3 $root/bench.py $A > $out/ev_trace_two.json 2> $out/ev_trace_two.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/ev_trace_one -- python3 $root/bench.py $A --one-stream > $out/ev_trace_one.json 2> $out/ev_trace_one.err || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
