@@ -248,7 +248,7 @@ def pmc_traffic(kernel):
         return None, None
     tj = json.load(open(tpath))
     return tj.get(kernel + "_bytes_per_launch"), "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, at " \
-        "commit %s (profiles/r03_evidence.sh)" % tj.get("captured_at_commit", "?")
+        "commit %s (profiles/r04_evidence.sh)" % tj.get("captured_at_commit", "?")
 
 
 def roofline(path, mean_launch_s, launches):

@@ -66,8 +66,11 @@ tj["slab_pipeline_stored_syndromes_raw_r04_per_2^20"] = {
     "algorithmic": 2 ** 20 * 768,
 }
 small = table(os.path.join(src, "ev_rref_small_pmc.md"))
-tj["rref_small_raw_r04"] = {"%s grid %d" % (r[0][:40], r[1]): {c: r[3] * (2 if c == "FETCH_SIZE" else 1) * KIB}
-                            for c in ("FETCH_SIZE", "WRITE_SIZE") for r in small.get(c, []) if r[0].startswith("rref_small_kernel")}
+tj["rref_small_raw_r04"] = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    for r in small.get(c, []):
+        if r[0].startswith("rref_small_kernel"):
+            tj["rref_small_raw_r04"].setdefault(r[0][:40], {})[c + "_bytes"] = round(r[3] * (2 if c == "FETCH_SIZE" else 1) * KIB)
 dense = table(os.path.join(src, "ev_dense_pmc.md"))
 fetch, write = mean_of(dense, "FETCH_SIZE", "syndrome_tiled_kernel"), mean_of(dense, "WRITE_SIZE", "syndrome_tiled_kernel")
 tj["syndrome_tiled_kernel_raw_r04"] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write}

@@ -1277,10 +1277,12 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
         for (int d = 0; d < DW; ++d) {                              // the dword of the row that holds the column: a constant below
             if (d * 32 >= n || rank >= m) break;                    // uniform
             const int d4 = d & ~3;                                  // the pivot row is zero before its column: pieces from here on
+            // (one exit, no `continue`: the compiler turns a loop with several exits into a state machine of scalar moves and
+            // compares -- forty scalar instructions and eight branches per pivot in the first form of this loop)
+            const int nbits = n - d * 32 < 32 ? n - d * 32 : 32;    // uniform
 #pragma unroll 1
-            for (int bb = 0; bb < 32; ++bb) {
+            for (int bb = 0; bb < nbits && rank < m; ++bb) {
                 const int col = d * 32 + bb;
-                if (col >= n || rank >= m) break;                   // uniform
                 const unsigned int bit = 1u << bb;
                 u64 has[RPL];
                 int src_q = -1;
@@ -1293,7 +1295,7 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
                         cand = has[q] & unused[q];
                     }
                 }
-                if (src_q < 0) continue;                            // no unused row has this column: not a pivot column
+                if (src_q >= 0) {                                   // (else: no unused row has this column: not a pivot column)
                 const int src_lane = __ffsll((long long)cand) - 1;
                 const u64 src_bit = 1ull << src_lane;
                 // The pivot row's way to the other rows.  Two ways, and the kernel uses both: dwords d4 .. split - 1 by v_readlane into
@@ -1352,9 +1354,10 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
                             if (dd >= split) w[q][dd] ^= pr[dd];
                     }
                 }
-                unused[src_q < 0 ? 0 : src_q] &= ~src_bit;
+                unused[src_q] &= ~src_bit;
                 rank += 1;
                 __builtin_amdgcn_wave_barrier();                    // (the next pivot row is written after every lane has read this one)
+                }
             }
         }
         // rows out in pivot order; everything from row `rank` on is zero
