@@ -1199,9 +1199,13 @@ __global__ void nullspace_kernel(const u64* __restrict__ red, int64_t n, int64_t
 //   * the pivot row travels to scalar registers by v_readlane (one row per lane) or through LDS (more: its lane writes it, every
 //     lane reads it back at one address), and only from the 16-byte piece that holds the column on -- an unused row is zero to
 //     the left of the column, so the words before it cannot change;
-//   * a matrix whose rows are contiguous (ld == LD) is loaded and stored in 16-byte pieces, 1 KiB contiguous per instruction,
-//     and handed to / taken from the row-per-lane layout through LDS (80-byte row pitch: conflict-free 16-byte accesses).
-// About 20 vector instructions per pivot are left: the XORs themselves.  Grid-stride over the batch.
+//   * a matrix whose rows are contiguous (ld == LD) is loaded and stored in 16-byte pieces, every lane its own rows.  (Whole
+//     1 KiB pieces per instruction, handed to and from the row-per-lane layout through an LDS staging area, were built and
+//     measured: 0.377 against 0.342 ms for 256 MiB of 64 x 512 matrices -- the 5 KiB of LDS per wavefront cost a workgroup per CU,
+//     and the access pattern was never the limit: PMC traffic is 1.06x the algorithmic bytes either way.)
+//   * the column loop has ONE exit: with `continue` and two `break`s the compiler made a state machine of forty scalar
+//     instructions and eight branches per pivot out of it (0.43 -> 0.38 ms).
+// About 30 vector and 20 scalar instructions per pivot are left.  Grid-stride over the batch.
 #define SMALL_WAVES 4
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int RPL, int LD, int RL>
@@ -1209,17 +1213,14 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
                                                                       int64_t* __restrict__ pivots_base, int64_t cap,
                                                                       int64_t* __restrict__ rank_out) {
     constexpr int DW = 2 * LD;                                      // dwords per row
-    constexpr int PITCH = LD >= 2 ? LD * 8 + 16 : 16;               // LDS bytes per staged row (64 rows at a time)
-    constexpr bool STAGED = LD >= 2;                                // rows of whole 16-byte pieces
-    __shared__ __align__(16) unsigned char stage_all[SMALL_WAVES][STAGED ? 64 * PITCH : 16];
+    constexpr bool PIECES = LD >= 2;                                // rows of whole 16-byte pieces
     __shared__ __align__(16) unsigned int bcast_all[SMALL_WAVES][DW < 4 ? 4 : DW];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned char* const stage = stage_all[wv];
     unsigned int* const bcast = bcast_all[wv];
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const bool dense = STAGED && ld == LD && (reinterpret_cast<uintptr_t>(base) & 15) == 0;       // uniform
+    const bool contiguous = PIECES && ld == LD && (reinterpret_cast<uintptr_t>(base) & 15) == 0;   // uniform
     for (int64_t mat = wave; mat < batch; mat += nwaves) {
         u64* a = base + mat * m * ld;
         unsigned int w[RPL][DW];
@@ -1232,33 +1233,20 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
             myrank[q] = 0;
             unused[q] = __ballot(lane + 64 * q < m);
         }
-        if (dense) {
-            // 64 rows at a time: piece p (16 bytes) of the block belongs to row p / (LD / 2); lanes take consecutive pieces
-            constexpr int PPR = LD / 2;                             // pieces per row
+        if (contiguous) {
+            // every lane its own rows, 16 bytes per load
+            if constexpr (PIECES) {
 #pragma unroll
-            for (int q = 0; q < RPL; ++q) {
-                const int rows_here = m - 64 * q < 64 ? m - 64 * q : 64;    // uniform
-                const u32x4* src = reinterpret_cast<const u32x4*>(a + (int64_t)64 * q * ld);
-                if (rows_here > 0) {
+                for (int q = 0; q < RPL; ++q) {
+                    const int row = lane + 64 * q;
+                    const u32x4* src = reinterpret_cast<const u32x4*>(a + (int64_t)row * LD);
 #pragma unroll
-                    for (int it = 0; it < PPR; ++it) {
-                        const int p = it * 64 + lane;
-                        if (p < rows_here * PPR) {
-                            const u32x4 v = src[p];
-                            *reinterpret_cast<u32x4*>(stage + (p / PPR) * PITCH + (p % PPR) * 16) = v;
-                        }
+                    for (int j = 0; j < LD / 2; ++j) {
+                        u32x4 v = {0, 0, 0, 0};
+                        if (row < m) v = src[j];
+                        w[q][4 * j] = v.x, w[q][4 * j + 1] = v.y, w[q][4 * j + 2] = v.z, w[q][4 * j + 3] = v.w;
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-                for (int j = 0; j < PPR; ++j) {
-                    u32x4 v = {0, 0, 0, 0};
-                    if (lane < rows_here) v = *reinterpret_cast<const u32x4*>(stage + lane * PITCH + j * 16);
-                    w[q][4 * j] = v.x, w[q][4 * j + 1] = v.y, w[q][4 * j + 2] = v.z, w[q][4 * j + 3] = v.w;
-                }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         } else {
 #pragma unroll
@@ -1361,42 +1349,24 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
             }
         }
         // rows out in pivot order; everything from row `rank` on is zero
-        if (dense) {
-            constexpr int PPR = LD / 2;
-            // the rows into the staging area at their final places (64 rows of the result at a time), then out in 16-byte pieces
-#pragma unroll
-            for (int blk = 0; blk < RPL; ++blk) {
-                const int rows_here = m - 64 * blk < 64 ? m - 64 * blk : 64;    // uniform
-                if (rows_here <= 0) break;
-                // zero rows first (rows >= rank), then the pivot rows that land in this block
-                const int rr = 64 * blk + lane;
-                if (lane < rows_here && rr >= rank) {
-#pragma unroll
-                    for (int j = 0; j < PPR; ++j) *reinterpret_cast<u32x4*>(stage + lane * PITCH + j * 16) = u32x4{0, 0, 0, 0};
-                }
+        if (contiguous) {
+            if constexpr (PIECES) {
 #pragma unroll
                 for (int q = 0; q < RPL; ++q) {
-                    if (pivcol[q] >= 0 && (myrank[q] >> 6) == blk) {
-                        unsigned char* const dst = stage + (myrank[q] & 63) * PITCH;
+                    const int row = lane + 64 * q;
+                    if (pivcol[q] >= 0) {
+                        u32x4* dst = reinterpret_cast<u32x4*>(a + (int64_t)myrank[q] * LD);
 #pragma unroll
-                        for (int j = 0; j < PPR; ++j)
-                            *reinterpret_cast<u32x4*>(dst + j * 16) = u32x4{w[q][4 * j], w[q][4 * j + 1], w[q][4 * j + 2], w[q][4 * j + 3]};
+                        for (int j = 0; j < LD / 2; ++j) dst[j] = u32x4{w[q][4 * j], w[q][4 * j + 1], w[q][4 * j + 2], w[q][4 * j + 3]};
+                        if (pivots_base) pivots_base[mat * cap + myrank[q]] = pivcol[q];
+                    }
+                    if (row >= rank && row < m) {
+                        u32x4* dst = reinterpret_cast<u32x4*>(a + (int64_t)row * LD);
+#pragma unroll
+                        for (int j = 0; j < LD / 2; ++j) dst[j] = u32x4{0, 0, 0, 0};
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                u32x4* dstg = reinterpret_cast<u32x4*>(a + (int64_t)64 * blk * ld);
-#pragma unroll
-                for (int it = 0; it < PPR; ++it) {
-                    const int p = it * 64 + lane;
-                    if (p < rows_here * PPR) dstg[p] = *reinterpret_cast<const u32x4*>(stage + (p / PPR) * PITCH + (p % PPR) * 16);
-                }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-#pragma unroll
-            for (int q = 0; q < RPL; ++q)
-                if (pivots_base && pivcol[q] >= 0) pivots_base[mat * cap + myrank[q]] = pivcol[q];
         } else {
 #pragma unroll
             for (int q = 0; q < RPL; ++q) {
