@@ -1052,6 +1052,15 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
         slab = blockIdx.x % a.nslabs;
         share = blockIdx.x / a.nslabs;
     }
+    if (a.cmb_pw) {
+        // The previous pass' combine step FIRST, its counters and staging area where the table is about to go: the launch then asks
+        // for the table and the ticket counter only (131 KiB at n = 4096), and the 29 KiB that are left of a CU's LDS take a compact
+        // workgroup of the other stream (30 KiB; 4 x 96 + 96 registers per SIMD lane fit too).  (With the counters behind the table --
+        // 144 KiB -- the step read 0.5053 against 0.5064 of the HBM peak in the same process: gpurun_out/r04/ab5.log.)
+        unsigned int* const scratch = reinterpret_cast<unsigned int*>(lds);
+        combine_positions(a.cmb_pw, a.cmb_positions, a.cmb_pad, a.cmb_nslabs, a.cmb_hist, a.cmb_nbins, a.redo_count, a.redo_list,
+                          a.cmb_sample0, scratch, scratch + SLAB_MAX_BINS, scratch + SLAB_MAX_BINS + 1024);
+    }
     {
         // the slab's table: 9 loads per lane in flight (2400 columns x 4 parts = 9.4 rounds of 1024 lanes), then the LDS stores
         const u32x4* src = a.tab + (int64_t)slab * a.tab_stride * 4;
@@ -1074,12 +1083,6 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
     // four wavefronts of a SIMD finish one after the other (the first after 55 % of the kernel's duration) and the last
     // quarter of the work runs on one wavefront per SIMD with nothing to hide its latencies behind.
     unsigned int* const next_step = reinterpret_cast<unsigned int*>(lds + (size_t)a.tab_stride * 64);
-    if (a.cmb_pw) {
-        // (its counters and staging area lie behind the table and the ticket counter; the host has checked that they fit)
-        unsigned int* const scratch = next_step + 4;
-        combine_positions(a.cmb_pw, a.cmb_positions, a.cmb_pad, a.cmb_nslabs, a.cmb_hist, a.cmb_nbins, a.redo_count, a.redo_list,
-                          a.cmb_sample0, scratch, scratch + SLAB_MAX_BINS, scratch + SLAB_MAX_BINS + 1024);
-    }
     if (threadIdx.x == 0) *next_step = 0;
     __syncthreads();
 
@@ -1528,7 +1531,8 @@ static int launch_gather(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e, u
         ga.cmb_hist = combine_of->cmb_hist;
         ga.redo_count = combine_of->redo_count;
         ga.redo_list = combine_of->redo_list;
-        extra_lds = 16 + (SLAB_MAX_BINS + 1024 + 2) * 4;
+        const size_t scratch = (SLAB_MAX_BINS + 1024 + 2) * 4;             // (in the table's place: no LDS of its own ...
+        if (lds_bytes + extra_lds < scratch) extra_lds = scratch - lds_bytes;   // ... unless the table is smaller: a check of few columns)
     }
     ga.reverse = ctx->opt[GF2_OPT_GATHER_REVERSE] == 0 ? 0 : 1;
     ga.cross = ctx->opt[GF2_OPT_GATHER_CROSS] == 1 && !syn ? 1 : 0;       // (the cross-tile grouping has no variant that stores syndromes)
@@ -1643,7 +1647,7 @@ static int slab_call_setup(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_
     // they ask for their first records; GF2_F_COMBINE_SEPARATE keeps the kernel after every pass): the hand-scheduled kernel only,
     // and only if the counters fit behind the slab's table in LDS.
     c->gfold = c->fast && !c->fold && !gf2_flag(ctx, GF2_F_COMBINE_SEPARATE) && !gf2_flag(ctx, GF2_F_DIAG_CLOCKS) &&
-               (size_t)ck->slab_cols * 64 + 16 + (SLAB_MAX_BINS + 1024 + 2) * 4 <= SLAB_GATHER_LDS_MAX && (hist_dev || c->stray.n_cols);
+               (hist_dev || c->stray.n_cols);
     return GF2_OK;
 }
 
@@ -1841,9 +1845,8 @@ int gf2_mc_records_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, u
         const int64_t first_dw = ck->ident_off >> 5;
         side[c].fast = (lde & 1) == 0 && (first_dw & 3) == 0 && first_dw + (int64_t)ck->nslabs512 * (SLAB_ROWS / 32) <= lde * 2 &&
                        !gf2_flag(ctx, GF2_F_GATHER_GENERIC);
-        // its launch can carry the other component's combine step: the hand-scheduled kernel, and room behind its table
-        side[c].can_carry = side[c].fast && !gf2_flag(ctx, GF2_F_COMBINE_SEPARATE) &&
-                            (size_t)ck->slab_cols * 64 + 16 + (SLAB_MAX_BINS + 1024 + 2) * 4 <= SLAB_GATHER_LDS_MAX;
+        // its launch can carry the other component's combine step: the hand-scheduled kernel
+        side[c].can_carry = side[c].fast && !gf2_flag(ctx, GF2_F_COMBINE_SEPARATE);
         GF2_HIP(hipMemsetAsync(side[c].counters, 0, 256, stream));          // both slots, once per run
     }
     const StrayPlan none = {0, 0, {0, 0}};
