@@ -1643,9 +1643,9 @@ static int slab_call_setup(gf2_ctx* ctx, const gf2_check* ck, const uint64_t* e_
     // on the stream's critical path and are stretched by the other stream's big ones; measured: no change on two streams, 5 %
     // slower on one (1280 workgroups' worth of histogram atomics instead of 128: profiles/r02_sweep_fold.log).  Off by default.
     c->fold = gf2_flag(ctx, GF2_F_COMBINE_FOLDED) && !gf2_flag(ctx, GF2_F_DIAG_CLOCKS);
-    // Round 4: by default the combine step of pass k rides in the gather kernel of pass k + 1 instead (its workgroups do it before
-    // they ask for their first records; GF2_F_COMBINE_SEPARATE keeps the kernel after every pass): the hand-scheduled kernel only,
-    // and only if the counters fit behind the slab's table in LDS.
+    // Round 4: by default the combine step of pass k rides in the gather kernel of pass k + 1 instead (its workgroups do it first
+    // of all, in the LDS their table goes into afterwards; GF2_F_COMBINE_SEPARATE keeps the kernel after every pass): the
+    // hand-scheduled kernel only.
     c->gfold = c->fast && !c->fold && !gf2_flag(ctx, GF2_F_COMBINE_SEPARATE) && !gf2_flag(ctx, GF2_F_DIAG_CLOCKS) &&
                (hist_dev || c->stray.n_cols);
     return GF2_OK;
