@@ -256,6 +256,28 @@ def test_bench_one_rank_under_the_launcher_uses_the_nccl_backend():
     assert out["n_gpus"] == 1 and out["checks"]["histogram_total"] == 2 << 17
 
 
+@pytest.mark.gpu
+def test_bench_total_samples_is_strong_scaling():
+    # --total-samples T: T samples in all, rank g of N taking the g-th of N contiguous shards (configs[4] to the letter is T = 10^8);
+    # one rank, then two ranks sharing this box's GPU over gloo with a T that does not divide evenly: the histogram totals say that
+    # every sample was counted once per step
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["GF2_DEVICE"] = "0"
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-secondary", "--no-settle"]
+    done = subprocess.run(base + ["--gpus", "1", "--total-samples", "300000"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=600, text=True)
+    assert done.returncode == 0, done.stderr[-3000:]
+    out = bench_line(done)
+    assert out["scaling"] == "strong" and out["checks"]["histogram_total"] == 2 * 300000
+    assert out["config"]["global_samples_per_step"] == 300000 and out["config"]["samples_per_gpu_per_step"] == 300000
+    done = subprocess.run(base + ["--gpus", "2", "--dist-backend", "gloo", "--total-samples", "300001"], cwd=ROOT, env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert done.returncode == 0, done.stderr[-3000:]
+    out = bench_line(done)
+    assert out["scaling"] == "strong" and out["n_gpus"] == 2 and out["checks"]["histogram_total"] == 2 * 300001
+    assert out["config"]["global_samples_per_step"] == 300001 and out["config"]["samples_per_gpu_per_step"] == 150001
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     done = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
