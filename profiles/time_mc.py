@@ -20,6 +20,15 @@ c2 = ctx.check_create(_native.pack_rows(hm2), 2047, 4096)
 p = 0.01 / 3
 count = 1 << 24
 ctx.mc_run(c1, c2, 1, 0, count, p, p, p, _native.HIST_WEIGHT)          # (workspaces are sized by the first call)
+for waves in [int(w) for w in os.environ.get("GF2_SAMPLER_WAVES", "").split()]:      # record-sampler wavefronts per CU, in turn
+    ctx.set_option(_native.OPT_MC_SAMPLER_WAVES, waves)
+    t = []
+    for rep in range(4):
+        t0 = time.perf_counter()
+        ctx.mc_run(c1, c2, 1, 0, count, p, p, p, _native.HIST_WEIGHT)
+        t.append(time.perf_counter() - t0)
+    print("  %2d sampler wavefronts per CU: %.3e samples/s" % (waves, count / min(t)))
+ctx.set_option(_native.OPT_MC_SAMPLER_WAVES, None)
 times = []
 for rep in range(6):
     t0 = time.perf_counter()

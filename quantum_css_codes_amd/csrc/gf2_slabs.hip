@@ -507,6 +507,10 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
     const int lane = threadIdx.x;
     const int64_t ntiles = (a.count + 63) >> 6;
     unsigned int* const my_taken = L.taken + lane * RS_STRIDE;
+    // A lane's record is 64 bytes = a quarter of the banks, and the lanes' counts run nearly in step: sixteen lanes would store
+    // to one bank.  So lane l keeps its record turned by l / 4 dwords (slot k at slot (k + 2 (l / 4)) mod 32 of its 64 bytes):
+    // equal slots of the 64 lanes are 64 banks.  Turned back when the record leaves.
+    const unsigned int turn = (unsigned int)(lane >> 2) * 2u;
 #pragma unroll 1
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t i = tile * 64 + lane;
@@ -579,7 +583,7 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
                             cnt[c] += is_rec ? 1u : 0u;
                             const unsigned int ord = (unsigned int)((int)pos + ((int)pos < lo[c] ? base : base - sd.r)) << 4;
                             unsigned short* const at = (is_rec && cnt[c] < REC_SLOTS)
-                                                           ? reinterpret_cast<unsigned short*>(L.rec[c] + lane * 64 + (cnt[c] - 1u) * 2)
+                                                           ? reinterpret_cast<unsigned short*>(L.rec[c] + lane * 64 + ((cnt[c] - 1u + turn) & 31u) * 2)
                                                            : &L.sink[lane];
                             *at = (unsigned short)ord;
                         }
@@ -676,8 +680,14 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
             const bool misfit = over || (rank < 32 && cc >= SHORT_SLOTS);
             if (misfit && live) sd.misfit_list[atomicAdd(sd.misfit_count, 1u)] = (unsigned int)(tile * 64 + lane);
             u32x4 R[4];
+            {
+                const unsigned int* const mine = reinterpret_cast<const unsigned int*>(L.rec[c]) + lane * 16;
+                unsigned int dw[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) R[q] = reinterpret_cast<const u32x4*>(L.rec[c])[lane * 4 + q];
+                for (int q = 0; q < 16; ++q) dw[q] = mine[(q + (turn >> 1)) & 15];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) R[q] = u32x4{dw[4 * q], dw[4 * q + 1], dw[4 * q + 2], dw[4 * q + 3]};
+            }
             {
                 const unsigned int header = ((over ? REC_OVER : (misfit ? REC_DONE | (SHORT_SLOTS - 1) : cc)) | ((unsigned int)lane << 8)) << 16;
                 if (rank < 32)
@@ -1884,9 +1894,11 @@ int gf2_mc_records_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, u
             identity_segments(cks[c], th.nseg, &sd.seg_lo, &sd.seg_hi);
         }
         int64_t blocks = gf2_cdiv(now, 64);
-        // one wavefront per workgroup, 17 KiB of LDS each: 9 per CU (2, 4, 6 per CU: 0.31, 0.61, 0.78 of the rate at 9 -- the kernel
-        // is bound by what one wavefront issues, and more of them is what helps)
-        if (blocks > (int64_t)ctx->num_cus * 9) blocks = (int64_t)ctx->num_cus * 9;
+        // one wavefront per workgroup, 17 KiB of LDS each: 9 fit a CU, 8 -- two per SIMD, and 2^22 / 64 tiles divide evenly among
+        // 256 x 8 of them -- are faster (end to end 2.37 against 2.26 at 9 and 2.20 at 7 x 10^9 samples/s:
+        // profiles/r04_mc_sampler_waves.log; the kernel is bound by what its wavefronts issue).  GF2_OPT_MC_SAMPLER_WAVES: 1..9
+        const int64_t per_cu = ctx->opt[GF2_OPT_MC_SAMPLER_WAVES] > 0 ? ctx->opt[GF2_OPT_MC_SAMPLER_WAVES] : 8;
+        if (blocks > (int64_t)ctx->num_cus * per_cu) blocks = (int64_t)ctx->num_cus * per_cu;
         GF2_TRY(gf2_prof_begin(ctx, GF2_K_SAMPLER));
         hipLaunchKernelGGL(slab_record_sampler_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, a);
         GF2_TRY(gf2_prof_end(ctx));
