@@ -103,7 +103,8 @@ int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
 #define GF2_OPT_GATHER_OVER     7   /* slab pipeline: gather workgroups per CU over a launch, 1..8 (default 1)                            */
 #define GF2_OPT_RREF_SMALL_BCAST 8  /* wavefront-per-matrix RREF: 0 = the pivot row travels through LDS, 1 = through v_readlane (default: 1 for at most 64 rows, else 0) */
 #define GF2_OPT_MC_SAMPLER_WAVES 9  /* gf2_mc_run at n <= 4096, sparse rates: record-sampler wavefronts per CU, 1..9 (default 8)          */
-#define GF2_OPT_COUNT           10
+#define GF2_OPT_MC_TAIL_CAP     10  /* gf2_mc_run at n <= 4096, sparse rates: erroneous qubits of a 512-qubit segment that the record sampler's lanes take in step; a sample with more in a segment is finished by a lane of its own later.  0 (all in step), 2, 4, 6 or 8 (default: by the rate) */
+#define GF2_OPT_COUNT           11
 int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value);
 
 /* Device memory and stream-ordered copies on the context's stream (copies are synchronous). */

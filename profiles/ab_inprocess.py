@@ -38,7 +38,7 @@ def apply(variant):
             opts[int(key[1:])] = int(value)
     for c in path.contexts():
         c.set_flags(flags)
-        for k in range(10):
+        for k in range(11):
             c.set_option(k, opts.get(k))
 
 

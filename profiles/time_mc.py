@@ -29,6 +29,15 @@ for waves in [int(w) for w in os.environ.get("GF2_SAMPLER_WAVES", "").split()]: 
         t.append(time.perf_counter() - t0)
     print("  %2d sampler wavefronts per CU: %.3e samples/s" % (waves, count / min(t)))
 ctx.set_option(_native.OPT_MC_SAMPLER_WAVES, None)
+for cap in [int(w) for w in os.environ.get("GF2_TAIL_CAP", "").split()]:      # qubits of a segment the sampler's lanes take in step
+    ctx.set_option(_native.OPT_MC_TAIL_CAP, cap)
+    t = []
+    for rep in range(4):
+        t0 = time.perf_counter()
+        ctx.mc_run(c1, c2, 1, 0, count, p, p, p, _native.HIST_WEIGHT)
+        t.append(time.perf_counter() - t0)
+    print("  in step up to %d qubits per segment: %.3e samples/s" % (cap, count / min(t)))
+ctx.set_option(_native.OPT_MC_TAIL_CAP, None)
 times = []
 for rep in range(6):
     t0 = time.perf_counter()

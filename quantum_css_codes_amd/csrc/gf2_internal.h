@@ -66,6 +66,7 @@ struct gf2_ctx {
     // the sampler's two inverse-CDF tables (whole segments, last segment) in device memory, and what they were made for
     uint64_t* seg_cdf_dev;
     uint64_t seg_key_t;
+    int seg_tail_cap;              // record sampler: qubits of a segment the lanes take in step (from the tables' rate; 0: all)
     int seg_key_nb;
 };
 static inline bool gf2_flag(const gf2_ctx* ctx, uint32_t f) { return (ctx->flags & f) != 0; }

@@ -366,6 +366,11 @@ int gf2_seg_tables(gf2_ctx* ctx, double p_x, double p_y, double p_z, int64_t n, 
         GF2_HIP(hipMemcpy(ctx->seg_cdf_dev, host.data(), host.size() * sizeof(u64), hipMemcpyHostToDevice));
         ctx->seg_key_nb = out->nb_last;
         ctx->seg_key_t = t_any;
+        // The record sampler's lanes walk a segment's erroneous qubits in step: the smallest even count (up to 8) that at most one
+        // sample in ten exceeds is where they stop, the rest is a leftover (gf2_slabs.hip).  host[k] = 2^32 P(K <= k).
+        ctx->seg_tail_cap = 0;
+        for (int c = 2; c <= 8 && !ctx->seg_tail_cap; c += 2)
+            if (4294967296.0 - (double)host[c] <= 0.10 * 4294967296.0) ctx->seg_tail_cap = c;
     }
     out->cdf = (const u64*)ctx->seg_cdf_dev;
     return GF2_OK;

@@ -492,15 +492,28 @@ struct RecSamplerArgs {
     SegTables th;
     RecSide side[2];             // [0]: X component (e_x, against H2), [1]: Z component (e_z, against H1)
     int n;
+    int cap;                     // erroneous qubits of a segment a lane takes in step with the others (even, 2 .. RS_CAP_MAX; 0: all)
 };
 #define RS_STRIDE 17             // dwords per lane of a 512-bit map: 16 + 1 (odd: the lanes' dwords spread over the banks)
+#define RS_TAILS 64
+#define RS_CAP_MAX 8
+struct alignas(16) RecTail {     // 32 bytes
+    u64 d;                       // the segment's draw
+    unsigned int meta;           // lane | segment << 6 | K << 10
+    unsigned int pad;
+    unsigned short pos[RS_CAP_MAX];   // the positions taken so far
+};
 struct alignas(16) RecWaveLds {
     unsigned char rec[2][4096 + 16];
     unsigned int taken[64 * RS_STRIDE];
     unsigned int img[64 * RS_STRIDE];     // identity words of the one component that has any in the current segment (gf2_mc_records_ok)
     unsigned int bins[64];
     unsigned short sink[64];              // where a lane's record store goes when there is nothing to store
+    RecTail tails[RS_TAILS];              // (sample, segment) pairs with qubits left over (see the kernel)
+    unsigned int early[64 * RS_CAP_MAX / 2];   // a lane's first positions of the current segment, two per dword; while the leftovers
+                                               // are worked off: the lanes' slot counts (2 x 64)
 };
+static_assert(sizeof(RecWaveLds) <= 160 * 1024 / 8, "eight record-sampler wavefronts per CU");
 
 __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs a) {
     __shared__ RecWaveLds L;
@@ -525,6 +538,84 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
             for (int q = 0; q < 4; ++q) reinterpret_cast<u32x4*>(L.rec[c])[lane * 4 + q] = null4;
         }
         unsigned int cnt[2] = {0, 0};
+        // Leftovers.  The lanes walk a segment in step, as many trips as the LARGEST count among the 64 samples asks for (11 or 12
+        // qubits where the mean is 5): most of the later trips' lanes idle.  So the walk stops after a.cap qubits, and a lane with
+        // more leaves (draw, count, the positions it has taken) in L.tails.  At the end of the tile -- or when 64 pairs are
+        // waiting -- the pairs are worked off one per LANE: the lane marks the positions again in a map of its own, goes on with
+        // Floyd's rule where the sample's lane stopped, and puts what it finds where that lane would have: record slots through a
+        // counter in LDS, identity bits by an atomic OR on the words the segment's flush has stored.
+        unsigned int ntails = 0;                                    // uniform
+        auto run_tails = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the flushes' stores are done: the ORs below meet their words
+            unsigned int* const counts = L.early;
+            wave_lds_sync();
+            counts[lane] = cnt[0];
+            counts[64 + lane] = cnt[1];
+#pragma unroll
+            for (int q = 0; q < RS_STRIDE; ++q) L.taken[q * 64 + lane] = 0;
+            wave_lds_sync();
+            const bool act = (unsigned int)lane < ntails;
+            u64 td = 0;
+            unsigned int meta = 0;
+            u32x4 early4 = {0, 0, 0, 0};
+            if (act) {
+                td = L.tails[lane].d;
+                meta = L.tails[lane].meta;
+                early4 = *reinterpret_cast<const u32x4*>(L.tails[lane].pos);
+            }
+            const unsigned int owner = meta & 63u;
+            const int ts = (int)((meta >> 6) & 15u), tK = (int)(meta >> 10);
+            const int tbase = ts * GF2_SEG_BITS, tnb = ts == a.th.nseg - 1 ? a.th.nb_last : GF2_SEG_BITS;
+            const unsigned int owner_turn = (owner >> 2) * 2u;
+            const int64_t owner_row = (tile * 64 + (int64_t)owner) * a.lde;
+            const unsigned int early_dw[4] = {early4.x, early4.y, early4.z, early4.w};
+#pragma unroll
+            for (int q = 0; q < RS_CAP_MAX; ++q) {
+                if (q < a.cap) {                                    // uniform
+                    const unsigned int p = (early_dw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                    atomicOr(&my_taken[p >> 5], act ? 1u << (p & 31u) : 0u);
+                }
+            }
+            const unsigned int t1_lo = (unsigned int)a.th.t_1, t2_lo = (unsigned int)a.th.t_2;
+            const bool t1_top = (a.th.t_1 >> 32) != 0, t2_top = (a.th.t_2 >> 32) != 0;
+            auto put = [&](bool on, unsigned int pos, unsigned int kind) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const RecSide& sd = a.side[c];
+                    if (!(on && ((kind >> c) & 1u))) continue;
+                    const int rel = (int)pos - (sd.ident_off - tbase);
+                    if ((unsigned int)rel < (unsigned int)sd.r) {
+                        unsigned int* const row = reinterpret_cast<unsigned int*>(sd.eident + owner_row);
+                        atomicOr(row + (((unsigned int)tbase + pos) >> 5), 1u << (pos & 31u));
+                    } else {
+                        const unsigned int slot = atomicAdd(&counts[c * 64 + owner], 1u);
+                        const unsigned int ord = (unsigned int)((int)pos + (rel < 0 ? tbase : tbase - sd.r)) << 4;
+                        if (slot + 1u < REC_SLOTS)
+                            *reinterpret_cast<unsigned short*>(L.rec[c] + owner * 64 + ((slot + owner_turn) & 31u) * 2) = (unsigned short)ord;
+                    }
+                }
+            };
+            u64 x = td + GF2_GOLDEN * (u64)(a.cap + 1);
+            for (int k = a.cap; __ballot(k < tK) != 0; ++k, x += GF2_GOLDEN) {
+                const bool on = k < tK;
+                const u64 v = mix64(x);
+                const unsigned int j = (unsigned int)(tnb - tK + k);
+                unsigned int t = __umulhi((unsigned int)(v >> 32), j + 1u);
+                const unsigned int c32 = (unsigned int)v;
+                const unsigned int kind = ((t2_top || c32 < t2_lo) ? 1u : 0u) | ((!t1_top && c32 >= t1_lo) ? 2u : 0u);
+                if (!on) t = 0;
+                const unsigned int old = atomicOr(&my_taken[t >> 5], on ? 1u << (t & 31u) : 0u);
+                const bool hit = on && ((old >> (t & 31u)) & 1u);
+                const unsigned int jj = j & 511u;
+                if (hit) atomicOr(&my_taken[jj >> 5], 1u << (jj & 31u));
+                put(on, hit ? jj : t, kind);
+            }
+            wave_lds_sync();
+            cnt[0] = counts[lane];
+            cnt[1] = counts[64 + lane];
+            wave_lds_sync();
+            ntails = 0;
+        };
 #pragma unroll 1
         for (int s = 0; s < a.th.nseg; ++s) {
             const bool last = s == a.th.nseg - 1;
@@ -604,7 +695,8 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
                     const unsigned int c = (unsigned int)v;
                     *kind = ((t2_top || c < t2_lo) ? 1u : 0u) | ((!t1_top && c >= t1_lo) ? 2u : 0u);
                 };
-                for (int k = 0; __ballot(k < K) != 0; k += 2, x0 += 2 * GF2_GOLDEN, x1 += 2 * GF2_GOLDEN) {
+                const int stop = a.cap ? a.cap : GF2_SEG_BITS;           // (even)
+                for (int k = 0; __ballot(k < K) != 0 && k < stop; k += 2, x0 += 2 * GF2_GOLDEN, x1 += 2 * GF2_GOLDEN) {
                     const bool on0 = k < K, on1 = k + 1 < K;
                     unsigned int t0, kind0, t1, kind1;
                     draw(x0, k, &t0, &kind0);
@@ -621,6 +713,7 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
                     const unsigned int pos0 = hit0 ? j0 : t0, pos1 = hit1 ? j1 : t1;
                     atomicOr(&my_taken[j0 >> 5], hit0 ? 1u << (j0 & 31u) : 0u);
                     atomicOr(&my_taken[j1 >> 5], hit1 ? 1u << (j1 & 31u) : 0u);
+                    L.early[lane * (RS_CAP_MAX / 2) + ((k >> 1) & (RS_CAP_MAX / 2 - 1))] = pos0 | (pos1 << 16);     // (no branch in the trip)
                     emit(on0, pos0, kind0);
                     emit(on1, pos1, kind1);
                 }
@@ -653,7 +746,25 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            if (a.cap) {                                              // uniform
+                const bool left = K > a.cap;
+                const u64 lm = __ballot(left);
+                if (lm) {                                             // uniform
+                    u32x4 early4 = {0, 0, 0, 0};
+                    if (left) early4 = *reinterpret_cast<const u32x4*>(L.early + lane * (RS_CAP_MAX / 2));
+                    const unsigned int more = (unsigned int)__popcll(lm);
+                    if (ntails + more > RS_TAILS) run_tails();       // uniform (this segment's flush is behind us as well)
+                    if (left) {
+                        RecTail& T = L.tails[ntails + __builtin_amdgcn_mbcnt_hi((unsigned int)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)lm, 0u))];
+                        T.d = d;
+                        T.meta = (unsigned int)lane | ((unsigned int)s << 6) | ((unsigned int)K << 10);
+                        *reinterpret_cast<u32x4*>(T.pos) = early4;
+                    }
+                    ntails += more;
+                }
+            }
         }
+        if (ntails) run_tails();                                      // uniform
         // records out, per component, as the compact kernel leaves them: sorted by count, the 32 shortest as 32-byte records
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -1882,6 +1993,7 @@ int gf2_mc_records_run(gf2_ctx* ctx, const gf2_check* c1, const gf2_check* c2, u
         a.lde = lde;
         a.th = th;
         a.n = (int)n;
+        a.cap = ctx->opt[GF2_OPT_MC_TAIL_CAP] >= 0 ? (int)ctx->opt[GF2_OPT_MC_TAIL_CAP] : ctx->seg_tail_cap;
         for (int c = 0; c < 2; ++c) {
             RecSide& sd = a.side[c];
             sd.eident = const_cast<u64*>((const u64*)side[c].eident);

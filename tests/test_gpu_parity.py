@@ -770,6 +770,13 @@ def test_monte_carlo_n4096_dense_and_sparse_pipelines_agree(ctx, route):
     # ... and the default route's 2.2 million samples against the oracle directly, not only against the other routes
     want_big = c_oracle.mc(h1, 2048, h2, 2047, 4096, *big[:-1], 1)
     assert np.array_equal(piped[0], want_big[0]) and np.array_equal(piped[1], want_big[1])
+    for cap in (0, 2, 6):                                     # (the leftovers of the record sampler: see the next test)
+        ctx.set_option(_native.OPT_MC_TAIL_CAP, cap)
+        try:
+            capped = ctx.mc_run(c1, c2, *big)
+        finally:
+            ctx.set_option(_native.OPT_MC_TAIL_CAP, None)
+        assert np.array_equal(capped[0], want_big[0]) and np.array_equal(capped[1], want_big[1]), cap
     # a rate at which most tiles have samples that do not fit their records (17 columns per sample on average): the misfit
     # kernel draws those again; and a ragged last tile
     hot = (0x5EED, 99, 70001, 0.005, 0.0035, 0.002, _native.HIST_WEIGHT)
@@ -809,6 +816,16 @@ def test_monte_carlo_record_sampler_other_shapes(case, ctx, route):
         assert np.array_equal(got[0], records[0]) and np.array_equal(got[1], records[1])
     want_all = c_oracle.mc(h1, r1, h2, r2, n, *args[:-1], 1)           # the default route's whole call against the oracle
     assert np.array_equal(records[0], want_all[0]) and np.array_equal(records[1], want_all[1])
+    # the sampler's lanes stop after `cap` erroneous qubits of a segment and leave the rest of such a sample to a lane of its own
+    # (default: by the rate; 0 = every lane to the end, as in round 3).  At cap 2 and these rates nearly every (sample, segment)
+    # pair has leftovers, so the list of 64 pairs fills and is worked off in the middle of a tile, segment after segment.
+    for cap in (0, 2, 4, 8):
+        ctx.set_option(_native.OPT_MC_TAIL_CAP, cap)
+        try:
+            capped = ctx.mc_run(c1, c2, *args)
+        finally:
+            ctx.set_option(_native.OPT_MC_TAIL_CAP, None)
+        assert np.array_equal(capped[0], want_all[0]) and np.array_equal(capped[1], want_all[1]), cap
     want = c_oracle.mc(h1, r1, h2, r2, n, 31, 500, 3000, p_total / 2, p_total / 4, p_total / 4, 1)
     small = ctx.mc_run(c1, c2, 31, 500, 3000, p_total / 2, p_total / 4, p_total / 4, _native.HIST_WEIGHT)
     assert np.array_equal(small[0], want[0]) and np.array_equal(small[1], want[1])
