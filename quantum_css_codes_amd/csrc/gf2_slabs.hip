@@ -546,7 +546,6 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
         // counter in LDS, identity bits by an atomic OR on the words the segment's flush has stored.
         unsigned int ntails = 0;                                    // uniform
         auto run_tails = [&]() {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the flushes' stores are done: the ORs below meet their words
             unsigned int* const counts = L.early;
             wave_lds_sync();
             counts[lane] = cnt[0];
@@ -596,6 +595,7 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
                 }
             };
             u64 x = td + GF2_GOLDEN * (u64)(a.cap + 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the flushes' stores are done: the ORs below meet their words
             for (int k = a.cap; __ballot(k < tK) != 0; ++k, x += GF2_GOLDEN) {
                 const bool on = k < tK;
                 const u64 v = mix64(x);
