@@ -524,6 +524,9 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
     // to one bank.  So lane l keeps its record turned by l / 4 dwords (slot k at slot (k + 2 (l / 4)) mod 32 of its 64 bytes):
     // equal slots of the 64 lanes are 64 banks.  Turned back when the record leaves.
     const unsigned int turn = (unsigned int)(lane >> 2) * 2u;
+    u64 cdf16[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cdf16[k] = a.th.cdf[k];
 #pragma unroll 1
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t i = tile * 64 + lane;
@@ -622,21 +625,43 @@ __global__ __launch_bounds__(64) void slab_record_sampler_kernel(RecSamplerArgs 
             const int nb = last ? a.th.nb_last : GF2_SEG_BITS;
             const int base = s * GF2_SEG_BITS;
             const bool flush0 = s >= a.side[0].seg_lo && s < a.side[0].seg_hi, flush1 = s >= a.side[1].seg_lo && s < a.side[1].seg_hi;
+            {
+                // the maps, 16 bytes per lane and store: L.taken and, behind it, L.img (one uniform branch; written as a loop over both
+                // maps' dwords this was 34 stores and as many branches)
+                static_assert(offsetof(RecWaveLds, taken) % 16 == 0 && offsetof(RecWaveLds, img) == offsetof(RecWaveLds, taken) + sizeof(L.taken) &&
+                                  sizeof(L.taken) == 272 * 16,
+                              "the two maps are one run of 544 16-byte pieces");
+                u32x4* const maps = reinterpret_cast<u32x4*>(L.taken);
+                const u32x4 zero4 = {0, 0, 0, 0};
+                if (flush0 || flush1) {                                     // uniform
 #pragma unroll
-            for (int q = 0; q < RS_STRIDE; ++q) {
-                L.taken[q * 64 + lane] = 0;
-                if (flush0 || flush1) L.img[q * 64 + lane] = 0;               // uniform
+                    for (int q = 0; q < 8; ++q) maps[q * 64 + lane] = zero4;
+                    if (lane < 32) maps[512 + lane] = zero4;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) maps[q * 64 + lane] = zero4;
+                    if (lane < 16) maps[256 + lane] = zero4;
+                }
             }
-            u64 d = 0;
+            const u64 d = live ? segment_draw(ks, (u64)s) : 0;
             int K = 0;
-            if (live) {
-                d = segment_draw(ks, (u64)s);
+            {
+                // the count: how many of the table's thresholds the draw reaches.  The whole segments' first 16 thresholds are in
+                // registers since the kernel began (every segment used to wait for eight 16-byte loads of them here)
                 const u64 u = d >> 32;
-                const u64* const tab = a.th.cdf + (last ? GF2_SEG_CDF : 0);
+                if (!last) {                                                // uniform
 #pragma unroll
-                for (int k = 0; k < 16; ++k) K += u >= tab[k] ? 1 : 0;         // uniform addresses: scalar loads
-                if (K == 16)
+                    for (int k = 0; k < 16; ++k) K += u >= cdf16[k] ? 1 : 0;
+                } else {
+                    const u64* const tab = a.th.cdf + GF2_SEG_CDF;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) K += u >= tab[k] ? 1 : 0;
+                }
+                if (K == 16) {
+                    const u64* const tab = a.th.cdf + (last ? GF2_SEG_CDF : 0);
                     while (K < nb && u >= tab[K]) K += 1;
+                }
+                if (!live) K = 0;
             }
             __builtin_amdgcn_wave_barrier();
             // What this segment holds of each component's check (uniform): columns under the identity block (lo <= position < lo + r,
