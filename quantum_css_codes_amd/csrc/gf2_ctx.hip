@@ -169,7 +169,7 @@ int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value) {
             GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_MC_SAMPLER_WAVES must be in 1..9");
         if (option == GF2_OPT_MC_TAIL_CAP && (value > 8 || (value & 1)))
             GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_MC_TAIL_CAP must be 0, 2, 4, 6 or 8");
-        if (option == GF2_OPT_RREF_SMALL_BCAST && value > 1) GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_RREF_SMALL_BCAST must be 0 or 1");
+        if (option == GF2_OPT_RREF_SMALL_BCAST && value > 2) GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_RREF_SMALL_BCAST must be 0, 1 or 2");
     }
     ctx->opt[option] = value < 0 ? -1 : value;
     return GF2_OK;

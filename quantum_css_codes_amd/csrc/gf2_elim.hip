@@ -1388,6 +1388,187 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
     }
 }
 
+// The same walk with the pivot rows taken FOUR AT A TIME (the method of the four Russians, per wavefront).  Adding a pivot row to
+// the rows that have its column costs a broadcast and an XOR per dword of the row whatever the number of rows that take it; so the
+// walk finds four pivots on the ONE dword that holds their columns (a copy x of it: test, pick, one readlane, one masked XOR per
+// pivot), remembers for each which rows took it (four lane masks), and only then touches the whole rows: the four pivot rows go
+// to LDS as they are found, are brought to the state the sequential walk would have left them in (row i takes rows j < i
+// according to the masks: uniform conditions), their sixteen sums are made by the lanes in a (dword, quarter) arrangement --
+// T[c] = sum of the rows in c -- and every row adds the ONE sum its four mask bits name: a 16-byte LDS read and four XORs per piece
+// for four pivots.  A block ends with the dword, and with the last unused row.  Contiguous rows of whole 16-byte pieces only
+// (ld == LD >= 2, 16-byte aligned): everything else takes rref_small_kernel.  Bit-identical to it (RREF is unique; the pivot
+// rows are the same ones: lowest lane of the lowest register row).  Which pivots of the block a row has taken is a per-lane
+// value (`mul`), and what a pivot's row took of the earlier ones is its `mul` when it became one -- its lane leaves it in LDS
+// next to the row: no scalar bookkeeping per pivot (selecting "the masks of step i" by a counter cost twenty scalar instructions
+// per pivot in the first form, writing the four steps out as many for their flags in the second).
+template <int RPL, int LD>
+__global__ __launch_bounds__(64 * SMALL_WAVES) __attribute__((amdgpu_waves_per_eu(RPL * LD <= 8 ? 8 : 4, 8))) void rref_small_m4r_kernel(u64* __restrict__ base, int64_t batch, int m, int n,
+                                                                          int64_t* __restrict__ pivots_base, int64_t cap,
+                                                                          int64_t* __restrict__ rank_out) {
+    constexpr int DW = 2 * LD;                                      // dwords per row (a multiple of 4)
+    static_assert(DW >= 4 && DW <= 64 && (DW & (DW - 1)) == 0, "rows of 1 .. 16 whole 16-byte pieces");
+    constexpr int GROUPS = 64 / DW;                                 // quarters of the sixteen sums a pass of the lanes makes
+    constexpr int PASSES = GROUPS >= 4 ? 1 : 4 / GROUPS;
+    __shared__ __align__(16) unsigned int lds_all[SMALL_WAVES][20 * DW + 4];   // four pivot rows, the sixteen sums, what the four rows took
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned int* const prow = lds_all[wv];
+    unsigned int* const sums = lds_all[wv] + 4 * DW;
+    unsigned int* const meta = lds_all[wv] + 20 * DW;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int my_dd = lane & (DW - 1), my_group = lane / DW;
+    // (one wavefront: the LDS serves its operations in order, so what orders a write before another lane's read is the order of
+    // the instructions -- which is all this has to keep)
+    auto lds_sync = []() {
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (int64_t mat = wave; mat < batch; mat += nwaves) {
+        u64* a = base + mat * m * LD;
+        unsigned int w[RPL][DW];
+        int pivcol[RPL], myrank[RPL];
+        u64 unused[RPL];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            pivcol[q] = -1;
+            myrank[q] = 0;
+            unused[q] = __ballot(lane + 64 * q < m);
+            const int row = lane + 64 * q;
+            const u32x4* src = reinterpret_cast<const u32x4*>(a + (int64_t)row * LD);
+#pragma unroll
+            for (int j = 0; j < LD / 2; ++j) {
+                u32x4 v = {0, 0, 0, 0};
+                if (row < m) v = src[j];
+                w[q][4 * j] = v.x, w[q][4 * j + 1] = v.y, w[q][4 * j + 2] = v.z, w[q][4 * j + 3] = v.w;
+            }
+        }
+        int rank = 0;
+#pragma unroll
+        for (int d = 0; d < DW; ++d) {
+            if (d * 32 >= n || rank >= m) break;                    // uniform
+            const int d4 = d & ~3;                                  // a pivot row is zero before its column: pieces from here on
+            const int nbits = n - d * 32 < 32 ? n - d * 32 : 32;    // uniform
+            unsigned int x[RPL];                                    // the dword of the columns, ahead of the rows by the block's pivots
+            unsigned int mul[RPL];                                  // which pivots of the block the row has taken (bit i: pivot i)
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) x[q] = w[q][d], mul[q] = 0;
+            int npiv = 0;                                           // pivots in the block so far (uniform)
+            // the block's pivot rows into all rows: see above.  What a pivot's row took of the block's earlier pivots is its own
+            // `mul` at the time it became one; its lane has left it next to the row (no scalar bookkeeping per pivot).
+            auto flush = [&]() {
+                lds_sync();
+#pragma unroll
+                for (int pass = 0; pass < PASSES; ++pass) {
+                    const int cg = (pass * GROUPS + my_group) & 3;
+                    const unsigned int p0 = prow[my_dd];
+                    unsigned int p1 = prow[DW + my_dd], p2 = prow[2 * DW + my_dd], p3 = prow[3 * DW + my_dd];
+                    const u32x4 under = *reinterpret_cast<const u32x4*>(meta);          // (one address: the same in every lane)
+                    // a ^ (b & mask), mask = all ones where the bit is set (slots the block did not fill hold older rows: nobody
+                    // names them, `mul` has no bit for them)
+                    auto add_if = [](unsigned int acc, unsigned int row, unsigned int bits, int bit) {
+                        const unsigned int mask = 0u - ((bits >> bit) & 1u);
+                        return __builtin_amdgcn_bitop3_b32(acc, row, mask, 0x78);
+                    };
+                    p1 = add_if(p1, p0, under.y, 0);
+                    p2 = add_if(p2, p0, under.z, 0);
+                    p2 = add_if(p2, p1, under.z, 1);
+                    p3 = add_if(p3, p0, under.w, 0);
+                    p3 = add_if(p3, p1, under.w, 1);
+                    p3 = add_if(p3, p2, under.w, 2);
+                    const unsigned int high = ((cg & 1) ? p2 : 0u) ^ ((cg & 2) ? p3 : 0u);
+                    unsigned int* const out = sums + (4 * cg) * DW + my_dd;
+                    out[0] = high;
+                    out[DW] = high ^ p0;
+                    out[2 * DW] = high ^ p1;
+                    out[3 * DW] = high ^ p0 ^ p1;
+                }
+                lds_sync();
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    const unsigned int* const mine = sums + mul[q] * DW;
+#pragma unroll
+                    for (int dd = 0; dd < DW; dd += 4) {
+                        if (dd < d4) continue;
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(mine + dd);
+                        w[q][dd] ^= v.x, w[q][dd + 1] ^= v.y, w[q][dd + 2] ^= v.z, w[q][dd + 3] ^= v.w;
+                    }
+                    x[q] = w[q][d];
+                    mul[q] = 0;
+                }
+                rank += npiv;
+                npiv = 0;
+                lds_sync();                                         // (the next block's rows and sums are written after these reads)
+            };
+#pragma unroll 1
+            for (int bb = 0; bb < nbits && rank + npiv < m; ++bb) {
+                const unsigned int bit = 1u << bb;
+                u64 has[RPL];
+                int src_q = -1;
+                u64 cand = 0;
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    has[q] = __ballot((x[q] & bit) != 0);
+                    if (src_q < 0 && (has[q] & unused[q])) {
+                        src_q = q;
+                        cand = has[q] & unused[q];
+                    }
+                }
+                if (src_q >= 0) {                                   // a pivot column
+                    const int src_lane = __ffsll((long long)cand) - 1;
+                    const u64 src_bit = 1ull << src_lane;
+                    unsigned int px = 0;
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) {
+                        if (q != src_q) continue;                   // uniform
+                        px = (unsigned int)__builtin_amdgcn_readlane((int)x[q], src_lane);
+                        if (__builtin_amdgcn_inverse_ballot_w64(src_bit)) {          // its row as it stands and what it took, to LDS
+#pragma unroll
+                            for (int dd = 0; dd < DW; dd += 4) {
+                                if (dd < d4) continue;
+                                *reinterpret_cast<u32x4*>(prow + npiv * DW + dd) = u32x4{w[q][dd], w[q][dd + 1], w[q][dd + 2], w[q][dd + 3]};
+                            }
+                            meta[npiv] = mul[q];
+                            pivcol[q] = d * 32 + bb;
+                            myrank[q] = rank + npiv;
+                        }
+                    }
+                    const unsigned int mine = 1u << npiv;
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) {
+                        const u64 tk = q == src_q ? has[q] & ~src_bit : has[q];
+                        if (__builtin_amdgcn_inverse_ballot_w64(tk)) {
+                            x[q] ^= px;
+                            mul[q] |= mine;
+                        }
+                    }
+                    unused[src_q] &= ~src_bit;
+                    npiv += 1;
+                    if (npiv == 4) flush();                         // uniform
+                }
+            }
+            if (npiv) flush();                                      // uniform: what the dword's last block has found
+        }
+        // rows out in pivot order; everything from row `rank` on is zero
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+            const int row = lane + 64 * q;
+            if (pivcol[q] >= 0) {
+                u32x4* dst = reinterpret_cast<u32x4*>(a + (int64_t)myrank[q] * LD);
+#pragma unroll
+                for (int j = 0; j < LD / 2; ++j) dst[j] = u32x4{w[q][4 * j], w[q][4 * j + 1], w[q][4 * j + 2], w[q][4 * j + 3]};
+                if (pivots_base) pivots_base[mat * cap + myrank[q]] = pivcol[q];
+            }
+            if (row >= rank && row < m) {
+                u32x4* dst = reinterpret_cast<u32x4*>(a + (int64_t)row * LD);
+#pragma unroll
+                for (int j = 0; j < LD / 2; ++j) dst[j] = u32x4{0, 0, 0, 0};
+            }
+        }
+        if (lane == 0) rank_out[mat] = rank;
+    }
+}
+
 template <int RPL, int LD>
 static int launch_rref_small(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld, int64_t* pivots_dev,
                              int64_t cap, int64_t* rank_dev) {
@@ -1398,6 +1579,20 @@ static int launch_rref_small(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m,
     // 1 = all by readlane where the registers allow (up to two rows per lane), default = half and half
     const int64_t how = ctx->opt[GF2_OPT_RREF_SMALL_BCAST];
     const dim3 grid((unsigned)blocks), block(64 * SMALL_WAVES);
+    // Four pivots at a time (rows that are contiguous whole 16-byte pieces, at most 16 words of them per lane: registers): the
+    // default for one row of 16 words per lane -- 256 MiB of 64 x 1024 matrices in 0.59 instead of 0.76 ms.  Narrower rows lose
+    // (64 x 512: 0.585 against 0.343 ms, 128 x 512: 0.70 against 0.61, 64 x 128: 0.92 against 0.74 -- profiles/r04_rref_small_m4r.log:
+    // fewer vector instructions per pivot, 22 against 30, but three LDS round trips per block in a row and 64 registers instead of
+    // 36); GF2_OPT_RREF_SMALL_BCAST = 2 takes it wherever it is built.
+    if constexpr (LD >= 2 && RPL * LD <= 16) {
+        if (((how < 0 && RPL == 1 && LD == 16) || how == 2) && ld == LD && (reinterpret_cast<uintptr_t>(a_dev) & 15) == 0) {
+            hipLaunchKernelGGL((rref_small_m4r_kernel<RPL, LD>), grid, block, 0, ctx->stream, a_dev, batch, (int)m, (int)n, pivots_dev, cap,
+                               rank_dev);
+            GF2_TRY(gf2_prof_end(ctx));
+            GF2_HIP(hipGetLastError());
+            return GF2_OK;
+        }
+    }
     if (LD < 2)                                                     // (a row of two dwords is no 16-byte piece: by readlane)
         hipLaunchKernelGGL((rref_small_kernel<RPL, LD, 2 * LD>), grid, block, 0, ctx->stream, a_dev, batch, (int)m, (int)n, ld, pivots_dev,
                            cap, rank_dev);

@@ -1785,6 +1785,18 @@ def test_rref_batch_small_matrix_kernel_every_variant(shape, ctx, route):
         want, want_piv, want_rank = c_oracle.rref(packed[b], m, n)
         assert int(ranks[b]) == want_rank and np.array_equal(piv[b][:want_rank], want_piv), (shape, b)
         assert np.array_equal(got[b], want), (shape, b)
+    # the ways the pivot rows reach the other rows (GF2_OPT_RREF_SMALL_BCAST): one at a time through LDS (0) or v_readlane (1), four
+    # at a time through a table of their sums (2: where rows are whole 16-byte pieces and the registers allow; else as the default)
+    for how in (0, 1, 2):
+        ctx.set_option(_native.OPT_RREF_SMALL_BCAST, how)
+        try:
+            other = packed.copy()
+            piv_o, ranks_o = ctx.rref_batch(other, batch, m, n)
+        finally:
+            ctx.set_option(_native.OPT_RREF_SMALL_BCAST, None)
+        assert np.array_equal(other, got) and np.array_equal(ranks_o, ranks), (shape, how)
+        for b in range(batch):
+            assert np.array_equal(piv_o[b][:int(ranks[b])], piv[b][:int(ranks[b])]), (shape, how, b)
     route.force("GF2_RREF_NO_SMALL")
     again = packed.copy()
     piv2, ranks2 = ctx.rref_batch(again, batch, m, n)
