@@ -1268,8 +1268,9 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
             // (one exit, no `continue`: the compiler turns a loop with several exits into a state machine of scalar moves and
             // compares -- forty scalar instructions and eight branches per pivot in the first form of this loop)
             const int nbits = n - d * 32 < 32 ? n - d * 32 : 32;    // uniform
+            int limit = nbits;                                      // (0 once every row is a pivot row: ONE condition for the loop to test)
 #pragma unroll 1
-            for (int bb = 0; bb < nbits && rank < m; ++bb) {
+            for (int bb = 0; bb < limit; ++bb) {
                 const int col = d * 32 + bb;
                 const unsigned int bit = 1u << bb;
                 u64 has[RPL];
@@ -1327,23 +1328,18 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
 #pragma unroll
                 for (int q = 0; q < RPL; ++q) {
                     const u64 take = q == src_q ? has[q] & ~src_bit : has[q];
-                    if (__builtin_amdgcn_inverse_ballot_w64(take)) {
+                    if (__builtin_amdgcn_inverse_ballot_w64(take)) {         // (the readlane part first: the LDS part is still on its way)
 #pragma unroll
                         for (int dd = 0; dd < DW; ++dd)
                             if (dd >= d4 && dd < split) w[q][dd] ^= pr[dd];
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < RPL; ++q) {
-                    const u64 take = q == src_q ? has[q] & ~src_bit : has[q];
-                    if (__builtin_amdgcn_inverse_ballot_w64(take)) {
 #pragma unroll
                         for (int dd = 0; dd < DW; ++dd)
                             if (dd >= split) w[q][dd] ^= pr[dd];
                     }
                 }
-                unused[src_q] &= ~src_bit;
+                unused[src_q] ^= src_bit;                          // (the bit is set: the pivot came from there)
                 rank += 1;
+                if (rank >= m) limit = 0;                           // uniform
                 __builtin_amdgcn_wave_barrier();                    // (the next pivot row is written after every lane has read this one)
                 }
             }
@@ -1542,7 +1538,7 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) __attribute__((amdgpu_waves_per_e
                             mul[q] |= mine;
                         }
                     }
-                    unused[src_q] &= ~src_bit;
+                    unused[src_q] ^= src_bit;                          // (the bit is set: the pivot came from there)
                     npiv += 1;
                     if (npiv == 4) flush();                         // uniform
                 }
