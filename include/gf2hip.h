@@ -101,7 +101,7 @@ int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
 #define GF2_OPT_COMBINE_THREADS 5   /* slab pipeline: threads per workgroup of the combine kernel, 64 / 128 / 256 / 512 / 1024 (default 1024) */
 #define GF2_OPT_GATHER_CROSS    6   /* slab pipeline: 1 = a gather step takes ranks 4k..4k+3 of four sorted tiles, 0 (default) = a quartile of one */
 #define GF2_OPT_GATHER_OVER     7   /* slab pipeline: gather workgroups per CU over a launch, 1..8 (default 1)                            */
-#define GF2_OPT_RREF_SMALL_BCAST 8  /* wavefront-per-matrix RREF: how the pivot rows reach the other rows.  One at a time: 0 = through LDS, 1 = through v_readlane; 2 = four at a time through a table of their sums in LDS (contiguous rows of whole 16-byte pieces, at most 16 words per lane; otherwise as the default).  Default: 2 for 64 rows of 16 words, half LDS half readlane for at most 64 rows of at most 8 words, else 0 */
+#define GF2_OPT_RREF_SMALL_BCAST 8  /* wavefront-per-matrix RREF: how the pivot rows reach the other rows.  One at a time: 0 = through LDS, 1 = through v_readlane; 2 = four at a time through a table of their sums in LDS (contiguous rows of whole 16-byte pieces, at most 32 words per lane; otherwise as the default).  Default: 2 for rows of 16 words, half LDS half readlane for at most 64 rows of at most 8 words, else 0 */
 #define GF2_OPT_MC_SAMPLER_WAVES 9  /* gf2_mc_run at n <= 4096, sparse rates: record-sampler wavefronts per CU, 1..9 (default 8)          */
 #define GF2_OPT_MC_TAIL_CAP     10  /* gf2_mc_run at n <= 4096, sparse rates: erroneous qubits of a 512-qubit segment that the record sampler's lanes take in step; a sample with more in a segment is finished by a lane of its own later.  0 (all in step), 2, 4, 6 or 8 (default: by the rate) */
 #define GF2_OPT_COUNT           11

@@ -24,7 +24,8 @@ def random_packed(m, n):
     return words
 
 
-for (m, n, batch) in ((64, 512, 65536), (128, 512, 32768), (256, 512, 16384), (64, 128, 262144), (64, 1024, 32768), (100, 300, 40000),
+for (m, n, batch) in ((64, 512, 65536), (128, 512, 32768), (256, 512, 16384), (64, 128, 262144), (64, 1024, 32768), (128, 1024, 16384),
+                      (100, 300, 40000),
                       (3, 7, 1000000)):
     ld = (n + 63) // 64
     some = random_packed(1024 * m, n).reshape(1024, m, ld)

@@ -1398,19 +1398,22 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
 // next to the row: no scalar bookkeeping per pivot (selecting "the masks of step i" by a counter cost twenty scalar instructions
 // per pivot in the first form, writing the four steps out as many for their flags in the second).
 template <int RPL, int LD>
-__global__ __launch_bounds__(64 * SMALL_WAVES) __attribute__((amdgpu_waves_per_eu(RPL * LD <= 8 ? 8 : 4, 8))) void rref_small_m4r_kernel(u64* __restrict__ base, int64_t batch, int m, int n,
+__global__ __launch_bounds__(64 * SMALL_WAVES) __attribute__((amdgpu_waves_per_eu(RPL * LD <= 8 ? 8 : (RPL * LD <= 16 ? 4 : 2), 8))) void rref_small_m4r_kernel(u64* __restrict__ base, int64_t batch, int m, int n,
                                                                           int64_t* __restrict__ pivots_base, int64_t cap,
                                                                           int64_t* __restrict__ rank_out) {
     constexpr int DW = 2 * LD;                                      // dwords per row (a multiple of 4)
     static_assert(DW >= 4 && DW <= 64 && (DW & (DW - 1)) == 0, "rows of 1 .. 16 whole 16-byte pieces");
     constexpr int GROUPS = 64 / DW;                                 // quarters of the sixteen sums a pass of the lanes makes
     constexpr int PASSES = GROUPS >= 4 ? 1 : 4 / GROUPS;
-    __shared__ __align__(16) unsigned int lds_all[SMALL_WAVES][20 * DW + 4];   // four pivot rows, the sixteen sums, what the four rows took
+    // per wavefront: five row slots (the block's four pivot rows as they stood when it began, written when it ends -- every lane
+    // stores its rows, a pivot's lane into the pivot's slot and everybody else into the fifth: no exec region, no one-lane stores),
+    // the sixteen sums, and per pivot of the block what its row took of the earlier ones
+    __shared__ __align__(16) unsigned int lds_all[SMALL_WAVES][5 * DW + 16 * DW + 4];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned int* const prow = lds_all[wv];
-    unsigned int* const sums = lds_all[wv] + 4 * DW;
-    unsigned int* const meta = lds_all[wv] + 20 * DW;
+    unsigned int* const sums = lds_all[wv] + 5 * DW;
+    unsigned int* const meta = lds_all[wv] + 21 * DW;
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     const int my_dd = lane & (DW - 1), my_group = lane / DW;
@@ -1447,31 +1450,41 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) __attribute__((amdgpu_waves_per_e
             const int nbits = n - d * 32 < 32 ? n - d * 32 : 32;    // uniform
             unsigned int x[RPL];                                    // the dword of the columns, ahead of the rows by the block's pivots
             unsigned int mul[RPL];                                  // which pivots of the block the row has taken (bit i: pivot i)
+            unsigned int slot[RPL];                                 // the row's slot in LDS: the pivot's number, 4 for everybody else
 #pragma unroll
-            for (int q = 0; q < RPL; ++q) x[q] = w[q][d], mul[q] = 0;
+            for (int q = 0; q < RPL; ++q) x[q] = w[q][d], mul[q] = 0, slot[q] = 4;
             int npiv = 0;                                           // pivots in the block so far (uniform)
-            // the block's pivot rows into all rows: see above.  What a pivot's row took of the block's earlier pivots is its own
-            // `mul` at the time it became one; its lane has left it next to the row (no scalar bookkeeping per pivot).
             auto flush = [&]() {
+                // the rows have not changed since the block began: its pivots' rows as the block found them
+#pragma unroll
+                for (int q = 0; q < RPL; ++q) {
+                    unsigned int* const mine = prow + slot[q] * DW;
+#pragma unroll
+                    for (int dd = 0; dd < DW; dd += 4) {
+                        if (dd < d4) continue;
+                        *reinterpret_cast<u32x4*>(mine + dd) = u32x4{w[q][dd], w[q][dd + 1], w[q][dd + 2], w[q][dd + 3]};
+                    }
+                    slot[q] = 4;
+                }
                 lds_sync();
+                const u32x4 under = *reinterpret_cast<const u32x4*>(meta);              // (one address: the same in every lane)
+                const unsigned int p0 = prow[my_dd];
+                unsigned int p1 = prow[DW + my_dd], p2 = prow[2 * DW + my_dd], p3 = prow[3 * DW + my_dd];
+                // a ^ (b & mask), mask = all ones where the bit is set (slots the block did not fill name older rows: nobody takes
+                // them, `mul` has no bit for them)
+                auto add_if = [](unsigned int acc, unsigned int row, unsigned int bits, int bit) {
+                    const unsigned int mask = 0u - ((bits >> bit) & 1u);
+                    return __builtin_amdgcn_bitop3_b32(acc, row, mask, 0x78);
+                };
+                p1 = add_if(p1, p0, under.y, 0);
+                p2 = add_if(p2, p0, under.z, 0);
+                p2 = add_if(p2, p1, under.z, 1);
+                p3 = add_if(p3, p0, under.w, 0);
+                p3 = add_if(p3, p1, under.w, 1);
+                p3 = add_if(p3, p2, under.w, 2);
 #pragma unroll
                 for (int pass = 0; pass < PASSES; ++pass) {
                     const int cg = (pass * GROUPS + my_group) & 3;
-                    const unsigned int p0 = prow[my_dd];
-                    unsigned int p1 = prow[DW + my_dd], p2 = prow[2 * DW + my_dd], p3 = prow[3 * DW + my_dd];
-                    const u32x4 under = *reinterpret_cast<const u32x4*>(meta);          // (one address: the same in every lane)
-                    // a ^ (b & mask), mask = all ones where the bit is set (slots the block did not fill hold older rows: nobody
-                    // names them, `mul` has no bit for them)
-                    auto add_if = [](unsigned int acc, unsigned int row, unsigned int bits, int bit) {
-                        const unsigned int mask = 0u - ((bits >> bit) & 1u);
-                        return __builtin_amdgcn_bitop3_b32(acc, row, mask, 0x78);
-                    };
-                    p1 = add_if(p1, p0, under.y, 0);
-                    p2 = add_if(p2, p0, under.z, 0);
-                    p2 = add_if(p2, p1, under.z, 1);
-                    p3 = add_if(p3, p0, under.w, 0);
-                    p3 = add_if(p3, p1, under.w, 1);
-                    p3 = add_if(p3, p2, under.w, 2);
                     const unsigned int high = ((cg & 1) ? p2 : 0u) ^ ((cg & 2) ? p3 : 0u);
                     unsigned int* const out = sums + (4 * cg) * DW + my_dd;
                     out[0] = high;
@@ -1496,8 +1509,9 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) __attribute__((amdgpu_waves_per_e
                 npiv = 0;
                 lds_sync();                                         // (the next block's rows and sums are written after these reads)
             };
+            int limit = nbits;                                      // (0 once every row is a pivot row: one condition for the loop)
 #pragma unroll 1
-            for (int bb = 0; bb < nbits && rank + npiv < m; ++bb) {
+            for (int bb = 0; bb < limit; ++bb) {
                 const unsigned int bit = 1u << bb;
                 u64 has[RPL];
                 int src_q = -1;
@@ -1513,22 +1527,18 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) __attribute__((amdgpu_waves_per_e
                 if (src_q >= 0) {                                   // a pivot column
                     const int src_lane = __ffsll((long long)cand) - 1;
                     const u64 src_bit = 1ull << src_lane;
-                    unsigned int px = 0;
+                    unsigned int px = 0, took = 0;
 #pragma unroll
                     for (int q = 0; q < RPL; ++q) {
                         if (q != src_q) continue;                   // uniform
                         px = (unsigned int)__builtin_amdgcn_readlane((int)x[q], src_lane);
-                        if (__builtin_amdgcn_inverse_ballot_w64(src_bit)) {          // its row as it stands and what it took, to LDS
-#pragma unroll
-                            for (int dd = 0; dd < DW; dd += 4) {
-                                if (dd < d4) continue;
-                                *reinterpret_cast<u32x4*>(prow + npiv * DW + dd) = u32x4{w[q][dd], w[q][dd + 1], w[q][dd + 2], w[q][dd + 3]};
-                            }
-                            meta[npiv] = mul[q];
-                            pivcol[q] = d * 32 + bb;
-                            myrank[q] = rank + npiv;
-                        }
+                        took = (unsigned int)__builtin_amdgcn_readlane((int)mul[q], src_lane);
+                        const bool me = lane == src_lane;
+                        pivcol[q] = me ? d * 32 + bb : pivcol[q];
+                        myrank[q] = me ? rank + npiv : myrank[q];
+                        slot[q] = me ? (unsigned int)npiv : slot[q];
                     }
+                    meta[npiv] = took;                              // (every lane the same value)
                     const unsigned int mine = 1u << npiv;
 #pragma unroll
                     for (int q = 0; q < RPL; ++q) {
@@ -1538,12 +1548,14 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) __attribute__((amdgpu_waves_per_e
                             mul[q] |= mine;
                         }
                     }
-                    unused[src_q] ^= src_bit;                          // (the bit is set: the pivot came from there)
+                    unused[src_q] ^= src_bit;                       // (the bit is set: the pivot came from there)
                     npiv += 1;
-                    if (npiv == 4) flush();                         // uniform
+                    if (rank + npiv >= m) limit = 0;                // uniform
                 }
+                // a block ends with its fourth pivot, with the dword and with the last unused row (ONE place: the code of a block's
+                // end is as long as the rest of the loop)
+                if (npiv == 4 || (npiv > 0 && bb + 1 >= limit)) flush();       // uniform
             }
-            if (npiv) flush();                                      // uniform: what the dword's last block has found
         }
         // rows out in pivot order; everything from row `rank` on is zero
 #pragma unroll
@@ -1575,13 +1587,14 @@ static int launch_rref_small(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m,
     // 1 = all by readlane where the registers allow (up to two rows per lane), default = half and half
     const int64_t how = ctx->opt[GF2_OPT_RREF_SMALL_BCAST];
     const dim3 grid((unsigned)blocks), block(64 * SMALL_WAVES);
-    // Four pivots at a time (rows that are contiguous whole 16-byte pieces, at most 16 words of them per lane: registers): the
-    // default for one row of 16 words per lane -- 256 MiB of 64 x 1024 matrices in 0.59 instead of 0.76 ms.  Narrower rows lose
-    // (64 x 512: 0.585 against 0.343 ms, 128 x 512: 0.70 against 0.61, 64 x 128: 0.92 against 0.74 -- profiles/r04_rref_small_m4r.log:
-    // fewer vector instructions per pivot, 22 against 30, but three LDS round trips per block in a row and 64 registers instead of
-    // 36); GF2_OPT_RREF_SMALL_BCAST = 2 takes it wherever it is built.
-    if constexpr (LD >= 2 && RPL * LD <= 16) {
-        if (((how < 0 && RPL == 1 && LD == 16) || how == 2) && ld == LD && (reinterpret_cast<uintptr_t>(a_dev) & 15) == 0) {
+    // Four pivots at a time (rows that are contiguous whole 16-byte pieces, at most 32 words of them per lane: registers): the
+    // default for rows of 16 words -- 256 MiB of 64 x 1024 matrices in 0.36 instead of 0.76 ms, of 128 x 1024 in 0.64 instead of
+    // 11.5 (one pivot at a time spills there).  Rows of 8 words are a draw (64 x 512: 0.346 against 0.333 ms), two or four of
+    // them per lane and narrower rows lose (128 x 512: 0.65 against 0.60, 256 x 512: 1.15 against 1.04, 64 x 128: 1.03 against
+    // 0.76 -- profiles/r04_rref_small_m4r.log: the block's fixed cost against what the row is worth);
+    // GF2_OPT_RREF_SMALL_BCAST = 2 takes it wherever it is built.
+    if constexpr (LD >= 2 && RPL * LD <= 32) {
+        if (((how < 0 && LD == 16) || how == 2) && ld == LD && (reinterpret_cast<uintptr_t>(a_dev) & 15) == 0) {
             hipLaunchKernelGGL((rref_small_m4r_kernel<RPL, LD>), grid, block, 0, ctx->stream, a_dev, batch, (int)m, (int)n, pivots_dev, cap,
                                rank_dev);
             GF2_TRY(gf2_prof_end(ctx));
