@@ -317,9 +317,9 @@ def rref_numbers(ctx):
                     "traffic": moved, "moved_GB/s": (moved / best / 1e6) if moved else None,
                     "int_op": {"lane_ops": lane_ops, "frac": lane_ops / (best / 1e3) / (256 * 64 * 2.4e9)}}
         buf.free(), piv.free(), rk.free()
-    # many small matrices (one wavefront each, rows in registers): 256 MiB of 64 x 512 and of 128 x 512 matrices, read once
-    # and written once
-    for (m, n, batch) in ((64, 512, 65536), (128, 512, 32768)):
+    # many small matrices (one wavefront each, rows in registers): 256 MiB of 64 x 512, of 128 x 512 and (four pivots at a time) of
+    # 64 x 1024 matrices, read once and written once
+    for (m, n, batch) in ((64, 512, 65536), (128, 512, 32768), (64, 1024, 32768)):
         ld = n // 64
         some = random_packed(1024 * m, n).reshape(1024, m, ld)
         host = np.ascontiguousarray(np.tile(some, (batch // 1024, 1, 1)))
