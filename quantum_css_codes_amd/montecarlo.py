@@ -137,10 +137,12 @@ def table_entries(table, r, n):
     kw = 1 if r <= 63 else 2
     keys = np.zeros((len(table), kw), dtype=np.uint64)
     mask = (1 << 64) - 1
-    for i, key in enumerate(table):
-        key = int(key)
-        keys[i, 0] = key & mask
-        if kw == 2:
+    if kw == 1:
+        keys[:, 0] = np.fromiter((int(key) for key in table), dtype=np.uint64, count=len(table))
+    else:
+        for i, key in enumerate(table):
+            key = int(key)
+            keys[i, 0] = key & mask
             keys[i, 1] = key >> 64
     errs = np.array(list(table.values()), dtype=np.uint8).reshape(len(table), n)
     corr = np.zeros((len(table), 2), dtype=np.uint64)
@@ -158,8 +160,13 @@ def decode_local(code, num_samples, p_x, p_y, p_z, seed=0, first_sample=0, hashe
     ctx = _native.default_context()
     if hashed or code.n > 63 or code.r_1 > 20 or code.r_2 > 20:      # (hashed=True: the hash-table kernel for a small code too)
         two = lambda vec: np.pad(_native.pack_rows(np.asarray(vec).reshape(1, -1))[0], (0, 2))[:2]
-        keys1, corr1 = table_entries(code._c1_syndromes, code.r_1, code.n)
-        keys2, corr2 = table_entries(code._c2_syndromes, code.r_2, code.n)
+        # (the tables as arrays: made once per code object -- 0.1 s of Python for a table of 350 000 entries)
+        cached = getattr(code, "_hashed_table_arrays", None)
+        if cached is None or cached[0] is not code._c1_syndromes or cached[1] is not code._c2_syndromes:
+            cached = (code._c1_syndromes, code._c2_syndromes, table_entries(code._c1_syndromes, code.r_1, code.n),
+                      table_entries(code._c2_syndromes, code.r_2, code.n))
+            code._hashed_table_arrays = cached
+        (keys1, corr1), (keys2, corr2) = cached[2], cached[3]
         counts = ctx.mc_decode_hashed(code.n, _native.pack_rows(code.parity_check_c1), code.r_1, keys1, corr1,
                                       _native.pack_rows(code.parity_check_c2), code.r_2, keys2, corr2,
                                       two(code.x_operator_matrix()[0]), two(code.z_operator_matrix()[0]),
