@@ -116,11 +116,10 @@ def dense_table(table, r, n):
     """A syndrome table (dict: vec_to_int(syndrome) -> error vector, css_code.py:715-735) as 2^r packed words
     indexed by the key; entries the table does not have are ~0."""
     out = np.full(1 << r, np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64)
-    for key, err in table.items():
-        word = 0
-        for j in np.flatnonzero(np.asarray(err)):
-            word |= 1 << int(j)
-        out[int(key)] = np.uint64(word)
+    if len(table):
+        keys = np.fromiter((int(key) for key in table), dtype=np.int64, count=len(table))
+        errs = np.array(list(table.values()), dtype=np.uint8).reshape(len(table), n)
+        out[keys] = _native.pack_rows(errs)[:, 0]                    # (n <= 63: one word per error)
     return out
 
 
@@ -175,8 +174,12 @@ def decode_local(code, num_samples, p_x, p_y, p_z, seed=0, first_sample=0, hashe
         out['samples'] = int(num_samples)
         return out
     chk1, chk2 = code._device_checks()
-    counts = ctx.mc_decode(chk1, chk2, dense_table(code._c1_syndromes, code.r_1, code.n),
-                           dense_table(code._c2_syndromes, code.r_2, code.n),
+    cached = getattr(code, "_dense_table_arrays", None)             # (made once per code object, like the hash tables' arrays)
+    if cached is None or cached[0] is not code._c1_syndromes or cached[1] is not code._c2_syndromes:
+        cached = (code._c1_syndromes, code._c2_syndromes, dense_table(code._c1_syndromes, code.r_1, code.n),
+                  dense_table(code._c2_syndromes, code.r_2, code.n))
+        code._dense_table_arrays = cached
+    counts = ctx.mc_decode(chk1, chk2, cached[2], cached[3],
                            packed_word(code.x_operator_matrix()[0]), packed_word(code.z_operator_matrix()[0]),
                            int(seed), int(first_sample), int(num_samples), float(p_x), float(p_y), float(p_z))
     out = {name: int(v) for name, v in zip(DECODE_FIELDS, counts)}
