@@ -1762,7 +1762,7 @@ def test_two_contexts_share_checks_and_run_concurrently(ctx):
 
 
 @pytest.mark.parametrize("shape", [(1, 1), (3, 7), (64, 64), (64, 65), (33, 128), (64, 200), (64, 512), (60, 1000), (64, 1024),
-                                   (65, 100), (128, 256), (100, 500), (128, 1024), (129, 250), (256, 256), (200, 512), (256, 512)])
+                                   (65, 100), (128, 256), (100, 500), (128, 1024), (100, 1000), (70, 1024), (129, 250), (256, 256), (200, 512), (256, 512)])
 def test_rref_batch_small_matrix_kernel_every_variant(shape, ctx, route):
     # the wavefront-per-matrix kernel (rows in registers): every (rows per lane, words per row) instantiation, batches of
     # different matrices incl. rank-deficient and zero ones; pivots, ranks and matrices against the C oracle, and the
