@@ -17,5 +17,7 @@ fi
 case "$*" in *GAT_EXP_*) patch -d $work -p0 < $root/profiles/gather_what_if_variants.patch ;; esac
 # ... and so is "every record takes 32 bytes of HBM" (REC_EXP_SHORT_ONLY: the bound on what smaller records could gain)
 case "$*" in *REC_EXP_*) patch -d $work -p1 < $root/profiles/record_bytes_what_if.patch ;; esac
+# ... and "the two halves of a row in arrays of their own" (WHATIF_HALF_PITCH: gf2_syndrome_sparse_dev takes a pitch of half a row)
+case "$*" in *WHATIF_HALF_PITCH*) patch -d $work -p1 < $root/profiles/half_pitch_what_if.patch ;; esac
 make -C $work/quantum_css_codes_amd/csrc ROOT=$work FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=default -I$work/include -Wall -Wno-unused-function $*" 2>&1 | grep -E "rror|check_isa:" || true
 mkdir -p $root/scratch_ab && cp $work/quantum_css_codes_amd/libgf2hip.so $root/scratch_ab/$name.so && ls -la $root/scratch_ab/$name.so
