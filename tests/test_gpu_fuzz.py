@@ -65,11 +65,20 @@ def test_fuzz_rref_batches(ctx):
         mats = [random_matrix(rng, m, n, float(rng.choice([0.02, 0.3, 0.5, 1.0])))[1] for _ in range(batch)]
         packed = np.stack(mats)
         want = [c_oracle.rref(mat, m, n) for mat in mats]
+        original = packed.copy()
         pivots, ranks = ctx.rref_batch(packed, batch, m, n)
         for b in range(batch):
             label = "case %d matrix %d: %d x %d" % (case, b, m, n)
             assert ranks[b] == want[b][2] and np.array_equal(packed[b], want[b][0]), label
             assert list(pivots[b, : want[b][2]]) == list(want[b][1]), label
+        # small matrices once more with four pivots at a time forced (GF2_OPT_RREF_SMALL_BCAST = 2; other sizes take their usual path)
+        ctx.set_option(_native.OPT_RREF_SMALL_BCAST, 2)
+        try:
+            again = original.copy()
+            pivots2, ranks2 = ctx.rref_batch(again, batch, m, n)
+        finally:
+            ctx.set_option(_native.OPT_RREF_SMALL_BCAST, None)
+        assert np.array_equal(again, packed) and np.array_equal(ranks2, ranks), "case %d: %d x %d, four pivots at a time" % (case, m, n)
 
 
 def test_fuzz_normalize(ctx):
