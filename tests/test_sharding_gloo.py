@@ -29,6 +29,33 @@ def test_shard_range_partitions_exactly():
         shard_range(0, 10, 2, 2)
 
 
+def test_decode_table_arrays():
+    # the syndrome tables as the arrays the decode kernels take (host only): dense tables of 2^r words (n <= 63) and the hash
+    # tables' key / error arrays, with one-word keys up to 63 checks and two-word keys beyond
+    from quantum_css_codes_amd.montecarlo import dense_table, table_entries
+    rng = np.random.default_rng(8)
+    n, r = 40, 9
+    errs = [np.zeros(n, dtype=int)] + [(rng.random(n) < 0.1).astype(int) for _ in range(30)]
+    keys = [0] + [int(k) for k in rng.choice(np.arange(1, 1 << r), 30, replace=False)]
+    table = dict(zip(keys, errs))
+    dense = dense_table(table, r, n)
+    assert dense.shape == (1 << r,) and dense.dtype == np.uint64
+    for key in range(1 << r):
+        want = sum(1 << j for j in np.flatnonzero(table[key])) if key in table else 0xFFFFFFFFFFFFFFFF
+        assert int(dense[key]) == want
+    n, r = 100, 70
+    big_keys = [0, 5, (1 << 64) + 3, (1 << 69) | 1]
+    big_errs = [(rng.random(n) < 0.05).astype(int) for _ in big_keys]
+    k, c = table_entries(dict(zip(big_keys, big_errs)), r, n)
+    assert k.shape == (4, 2) and c.shape == (4, 2)
+    for i, key in enumerate(big_keys):
+        assert int(k[i, 0]) | (int(k[i, 1]) << 64) == key
+        assert int(c[i, 0]) | (int(c[i, 1]) << 64) == sum(1 << int(j) for j in np.flatnonzero(big_errs[i]))
+    k1, c1 = table_entries({7: big_errs[0][:50], 9: big_errs[1][:50]}, 40, 50)
+    assert k1.shape == (2, 1) and [int(v) for v in k1[:, 0]] == [7, 9] and int(c1[0, 1]) == 0
+    assert table_entries({}, 30, 50)[0].shape == (0, 1)
+
+
 def test_pick_mode():
     from quantum_css_codes_amd.montecarlo import pick_mode
     assert pick_mode(3, 3) == 'full' and pick_mode(2048, 2047) == 'weight' and pick_mode(3, 3, 'weight') == 'weight'
