@@ -962,6 +962,513 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_pair_kernel(u64* base,
     }
 }
 
+// ---- blocked RREF, K panels per sweep (round 5) ------------------------------------------------------------------------------
+//
+// The pair scheme above makes one trip of the matrix through HBM per 128 columns.  The same idea with K = 4 panels (256
+// columns) per trip halves the trips; the Four-Russians lookups per trip double (their total stays), and the tables of four panels
+// fit the same 128 KiB because a workgroup then owns 16 words (128 bytes) of a row instead of 32.  Per sweep, two kernels:
+//
+//   rref_sweep_panel_kernel<K, RPT> (one workgroup per matrix): the K panel factorisations one after another in ONE launch.
+//     Panel j's column is brought up to date on the way in for what panels l < j of the sweep have found but nobody has applied yet:
+//         w ^= sum_{l<j} d_l[row] . S'_l[:, pw_j],     S'_l[q] = S_l[q] ^ sum_{l2<l} fix_{l,l2}[q] . S'_{l2}
+//     (S_l: panel l's pivot rows as they stand in memory, fix_{l,l2}[q] = d_{l2} of panel l's q-th pivot row) -- one byte-table
+//     lookup per row and earlier panel.  The K column words of every row come from a compact side buffer (32 bytes per row, written
+//     by the previous sweep's trailing pass) instead of one 128-byte line per row and word; without one (first sweep) from the rows.
+//   rref_sweep_update_kernel<K> (grid: row blocks x chunks of 64 / K words x matrices): new_i = old_i ^ sum_j d_j,i . S'_j with K
+//     Four-Russians tables, S'_j made by the table build as above; writes the next sweep's K column words of its rows to the side
+//     buffer on the way out.
+__device__ u64 g_sweep_diag[8];
+__device__ u64 g_sweep_wg[4 * 4096];                // development: per workgroup of ONE pass launch: start, tables done, end (wall ticks), hardware id                     // development: cycles / wall ticks of the trailing pass' phases (GF2_RREF_DIAG)
+struct SweepState {                                 // per matrix, in global scratch
+    int64_t rank;                                   // pivots so far
+    int64_t first_free;                             // first column seen without a pivot
+    int64_t skip_hi;                                // words wholly below this column cannot change in the current sweep
+    int64_t colw_pw;                                // the side buffer holds words colw_pw .. colw_pw + K - 1 as they stand (-1: nothing)
+    int32_t tg[4];                                  // pivots of the sweep's panels
+};
+
+__device__ __forceinline__ void byte_table(int tid, const u64* rows64, u64* T) {
+    for (int idx = tid; idx < 2048; idx += RB_THREADS) {
+        const int g = idx >> 8, vv = idx & 255;
+        u64 x = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x ^= rows64[8 * g + k] & (0ull - (u64)((vv >> k) & 1));
+        T[idx] = x;
+    }
+}
+
+template <int K, int RPT>
+__global__ __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(RPT <= 2 ? 8 : 4, 8))) void rref_sweep_panel_kernel(const u64* __restrict__ base, int64_t m, int64_t n, int64_t ld,
+                                                                     int64_t pw0, int64_t* __restrict__ pivots_base, int64_t cap,
+                                                                     int32_t* __restrict__ pivrow_base, SweepState* __restrict__ states,
+                                                                     unsigned char* __restrict__ used_base,
+                                                                     const u64* __restrict__ colw_base, u64* __restrict__ d_base,
+                                                                     int64_t dstride, u64* __restrict__ snap_base, int64_t sstride,
+                                                                     u64* __restrict__ fix_base) {
+    // d_base: [K][dstride] coefficients (dstride >= batch * m); snap_base: [K][sstride] pivot-row snapshots (batch x 64 x ld each);
+    // fix_base: [batch][K][K][64]
+    __shared__ u64 T[2048];                                             // one byte table at a time: corrections, coefficients, words
+    __shared__ u64 win_w[RB_WIN], win_d[RB_WIN], fin_w[RB_WIN], fin_d[RB_WIN], DP[64], WP[64];
+    __shared__ u64 colS[K][64], fixl[K * (K - 1) / 2][64];              // fixl[j (j - 1) / 2 + l]: panel j's pivot rows, earlier panel l
+    __shared__ int win_row[RB_WIN], win_piv[RB_WIN], pbit[64], prow_l[64], wave_tot[RB_THREADS / 64], misc[4];
+    __shared__ int prow_all[K][64], tj[K];
+
+    const int64_t mat = blockIdx.x;
+    const u64* a = base + mat * m * ld;
+    SweepState* st = states + mat;
+    unsigned char* used = used_base + mat * m;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t rank0 = st->rank;
+    int64_t first_free = st->first_free;
+    if (rank0 >= m || pw0 * 64 >= n) {                                 // nothing left to do for this matrix
+        if (tid < K) st->tg[tid] = 0;
+        return;
+    }
+    const bool have_colw = colw_base != nullptr && st->colw_pw == pw0;  // uniform
+    const u64* colw = colw_base + mat * m * K;
+    int64_t* pivots = pivots_base ? pivots_base + mat * cap : nullptr;
+    int32_t* pivrow = pivrow_base + mat * cap;
+    u64* fixg = fix_base + mat * K * K * 64;
+
+    unsigned int usedmask = 0, usedmask0;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k) {
+        const int64_t row = tid + (int64_t)RB_THREADS * k;
+        if (row < m && used[row]) usedmask |= 1u << k;
+    }
+    usedmask0 = usedmask;
+    int64_t rank = rank0;
+    const int64_t first_free_in = first_free;
+    if (tid < K) tj[tid] = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 0; j < K; ++j) {
+        const int64_t pw = pw0 + j;
+        __syncthreads();                                               // (a panel that found nothing left its last round without one)
+        u64* dout = d_base + (int64_t)j * dstride + mat * m;
+        if (rank >= m || pw * 64 >= n) {                               // uniform: nothing left for this panel
+            // (the trailing pass reads its coefficients all the same)
+            for (int64_t row = tid; row < m; row += RB_THREADS) dout[row] = 0ull;
+            continue;
+        }
+        // ---- the panel's column, brought up to date for the sweep's earlier panels ---------------------------------------------
+        u64 w[RPT], d[RPT];
+        int slot[RPT];
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int64_t row = tid + (int64_t)RB_THREADS * k;
+            w[k] = row < m ? (have_colw ? colw[row * K + j] : a[row * ld + pw]) : 0ull;
+            d[k] = 0;
+        }
+#pragma unroll 1
+        for (int l = 0; l < j; ++l) {
+            if (tj[l] == 0) continue;                                  // uniform
+            if (wave == 0) {
+                // column pw of panel l's pivot rows as the sweep's earlier panels leave them
+                u64 x = 0;
+                if (lane < tj[l]) {
+                    const int64_t prow = prow_all[l][lane];
+                    x = have_colw ? colw[prow * K + j] : a[prow * ld + pw];
+#pragma unroll 1
+                    for (int l2 = 0; l2 < l; ++l2) {
+                        const int t2 = tj[l2];
+                        const u64 f = fixl[l * (l - 1) / 2 + l2][lane];
+                        for (int p = 0; p < t2; ++p)
+                            if ((f >> p) & 1ull) x ^= colS[l2][p];
+                    }
+                }
+                colS[l][lane] = x;                                     // (one wavefront: its LDS operations are served in order)
+            }
+            __syncthreads();
+            byte_table(tid, colS[l], T);
+            __syncthreads();
+            const u64* dl = d_base + (int64_t)l * dstride + mat * m;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                const int64_t row = tid + (int64_t)RB_THREADS * k;
+                if (row < m) w[k] ^= byte_lookup(T, dl[row]);
+            }
+            __syncthreads();
+        }
+        // ---- panel factorisation (as rref_panel_kernel) ---------------------------------------------------------------------------
+        const int64_t cols_here = n - pw * 64;
+        const u64 panel_cols = cols_here >= 64 ? ~0ull : ((1ull << cols_here) - 1ull);
+        u64 unresolved = panel_cols;
+        int t = 0;
+        while (unresolved && t < 64 && rank + t < m) {
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                slot[k] = -1;
+                if (!((usedmask >> k) & 1u) && (w[k] & unresolved)) cnt += 1;
+            }
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off);
+                if (lane >= off) incl += up;
+            }
+            if (lane == 63) wave_tot[wave] = incl;
+            __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int i = 0; i < RB_THREADS / 64; ++i) {
+                const int v = wave_tot[i];
+                if (i < wave) before += v;
+                total += v;
+            }
+            if (total == 0) break;                                    // the unresolved columns have no pivot
+            int pos = before + incl - cnt;
+#pragma unroll
+            for (int k = 0; k < RPT; ++k)
+                if (!((usedmask >> k) & 1u) && (w[k] & unresolved)) {
+                    if (pos < RB_WIN) {
+                        slot[k] = pos;
+                        win_row[pos] = tid + RB_THREADS * k;
+                        win_w[pos] = w[k];
+                        win_d[pos] = d[k];
+                        win_piv[pos] = 0;
+                    }
+                    pos += 1;
+                }
+            __syncthreads();
+            const int nwin = total < RB_WIN ? total : RB_WIN;
+            if (wave == 0)
+                window_round(lane, nwin, t, rank, m, unresolved, win_w, win_d, win_row, win_piv, fin_w, fin_d, pbit, prow_l, DP, WP, misc);
+            __syncthreads();
+            const int t_new = misc[0];
+            const u64 newbits = ((u64)(unsigned int)misc[2] << 32) | (unsigned int)misc[1];
+            const bool again = (unresolved & ~newbits) != 0 && t_new < 64 && rank + t_new < m;   // uniform
+            byte_table(tid, DP, T);
+            __syncthreads();
+            unsigned int fresh = 0;                                   // rows that became pivots in this round
+#pragma unroll
+            for (int k = 0; k < RPT; ++k) {
+                if (slot[k] >= 0 && win_piv[slot[k]]) {               // a new pivot row: as the wavefront left it
+                    w[k] = fin_w[slot[k]];
+                    d[k] = fin_d[slot[k]];
+                    usedmask |= 1u << k;
+                    fresh |= 1u << k;
+                } else {                                              // every other row: linear in its word
+                    d[k] ^= byte_lookup(T, w[k]);
+                }
+            }
+            if (again) {                                              // only then are the rows' words needed again
+                __syncthreads();
+                byte_table(tid, WP, T);
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < RPT; ++k)
+                    if (!((fresh >> k) & 1u)) w[k] = byte_lookup(T, w[k]);
+            }
+            unresolved &= ~newbits;
+            t = t_new;
+            __syncthreads();                                          // the window arrays and T are reused
+        }
+        if (unresolved) {                                             // whatever is left has no pivot
+            const int64_t fc = pw * 64 + (__ffsll((long long)unresolved) - 1);
+            if (fc < first_free) first_free = fc;
+        }
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const int64_t row = tid + (int64_t)RB_THREADS * k;
+            if (row < m) dout[row] = d[k];                            // (all zero when the panel found nothing)
+        }
+        if (t == 0) continue;                                         // uniform
+        if (tid == 0) tj[j] = t;
+        if (wave == 0 && lane < t) {
+            // global pivot lists in ascending column order (a later round may have resolved an earlier column)
+            const u64 resolved = panel_cols & ~unresolved;
+            const int pos = __popcll(resolved & ((1ull << pbit[lane]) - 1ull));
+            pivrow[rank + pos] = prow_l[lane];
+            if (pivots) pivots[rank + pos] = pw * 64 + pbit[lane];
+            prow_all[j][lane] = prow_l[lane];
+        }
+        __syncthreads();                                              // d_l of this workgroup's rows are in memory, prow_all in LDS
+        // what the sweep's earlier panels add to this panel's pivot rows: their coefficients of those rows
+        if (tid < 64 * j) {
+            const int l = tid >> 6, q = tid & 63;
+            u64 f = 0;
+            if (q < t && tj[l] > 0) f = d_base[(int64_t)l * dstride + mat * m + prow_all[j][q]];
+            fixl[j * (j - 1) / 2 + l][q] = f;
+            fixg[(j * K + l) * 64 + q] = f;
+        }
+        rank += t;
+        __syncthreads();
+    }
+    __syncthreads();
+    int total_t = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) total_t += tj[j];
+    if (tid < K) st->tg[tid] = tj[tid];
+    if (tid == 0) {
+        st->rank = rank;
+        st->skip_hi = first_free_in < pw0 * 64 ? first_free_in : pw0 * 64;     // first_free as it was BEFORE this sweep
+        st->first_free = first_free;
+    }
+    if (total_t == 0) return;
+#pragma unroll
+    for (int k = 0; k < RPT; ++k)
+        if (((usedmask ^ usedmask0) >> k) & 1u) used[tid + RB_THREADS * k] = 1;
+    // snapshots of the pivot rows as they stand in memory (the trailing pass overwrites them)
+#pragma unroll 1
+    for (int j = 0; j < K; ++j) {
+        u64* snap = snap_base + (int64_t)j * sstride + mat * 64 * ld;
+        for (int64_t idx = tid; idx < (int64_t)tj[j] * ld; idx += RB_THREADS) {
+            const int p = (int)(idx / ld);
+            const int64_t wd = idx - (int64_t)p * ld;
+            snap[idx] = a[(int64_t)prow_all[j][p] * ld + wd];
+        }
+    }
+}
+
+// The trailing pass of a sweep of K panels (grid: row blocks, chunks of SW_CW = 64 / K words, matrices; block 1024; 128 KiB of
+// dynamic LDS).  Table entry (panel j, group g, nibble v) holds SW_CW words and entries are 256 bytes apart, so that a lookup stays
+// one SDWA instruction (the nibble into byte 1 of the address) + one ds_read_b128:
+//   K = 2: entries of 32 words, panel j at j * 64 KiB (the pair kernel's layout);
+//   K = 4: entries of 16 words, the two panels of a pair side by side in one 256-byte slot (panel 2i at +0, 2i+1 at +128), pair i
+//          at i * 64 KiB.  A wavefront moves eight rows per slot (eight lanes = 128 contiguous bytes each); the sixteen lanes that
+//          a ds_read_b128 serves together are {0-3, 12-15, 20-27} ..., four quarter-rows of FOUR different rows: all on one panel's
+//          half they would meet two and two on the same banks, so lanes 16-31 and 48-63 take the panels of a pair in the other
+//          order (XOR does not care) and every group covers the 64 banks once.
+template <int K, int TH>
+__device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, const int64_t chunk, const int64_t rowblock, const unsigned int unit,
+                                                  u64* base, int64_t m, int64_t ld, int64_t rows_per_wg,
+                                                  SweepState* __restrict__ states, const u64* __restrict__ d_base,
+                                                  int64_t dstride, const u64* __restrict__ snap_base,
+                                                  int64_t sstride, const u64* __restrict__ fix_base, int64_t pw0,
+                                                  u64* __restrict__ colw_base, u64* out_base) {
+    static_assert(K == 2 || K == 4, "two or four panels per sweep");
+    const u64 diag_wg0 = wall_clock64();
+    constexpr int CW = 64 / K;                                          // words of a row per workgroup
+    constexpr int LPR = CW / 2;                                         // lanes per row (16 bytes each)
+    constexpr int RPS = 64 / LPR;                                       // rows of a wavefront's slot
+    constexpr int ITER = 64 * CW / TH;                          // pivot-row words per lane and panel in the table build
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tg[K], t_all = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        tg[j] = states[mat].tg[j];
+        t_all |= tg[j];
+    }
+    const int64_t skip_hi = states[mat].skip_hi;
+    const bool moving = out_base != base;                              // uniform
+    const int64_t cw0 = chunk * CW;
+    const int wc_n = ld - cw0 < CW ? (int)(ld - cw0) : CW;
+    const int64_t r_lo = rowblock * rows_per_wg;
+    const int64_t row_end = r_lo + rows_per_wg < m ? r_lo + rows_per_wg : m;
+    u64* a = base + mat * m * ld;
+    u64* a_out = out_base + mat * m * ld;
+    // the next sweep's K column words, if this chunk holds them: they leave for the side buffer with the rows
+    const int64_t pw_next = pw0 + K;
+    const bool emits = colw_base != nullptr && pw_next < ld && pw_next >= cw0 && pw_next < cw0 + CW;     // uniform
+    u64* colw = colw_base + mat * m * K;
+    if (t_all == 0 || (cw0 + CW) * 64 <= skip_hi) {
+        // nothing to add here (no pivots, or the chunk lies left of everything that can change); `emits` implies the chunk is to
+        // the right of the sweep, so only the first reason applies to an emitting workgroup: the words go out as they stand
+        if (moving || emits) {
+            for (int64_t idx = tid; idx < (row_end - r_lo) * CW; idx += TH) {
+                const int64_t row = r_lo + idx / CW;
+                const int wd = (int)(idx % CW);
+                if (wd >= wc_n) continue;
+                const u64 v = a[row * ld + cw0 + wd];
+                if (moving) a_out[row * ld + cw0 + wd] = v;
+                if (emits && cw0 + wd >= pw_next && cw0 + wd < pw_next + K) colw[row * K + (cw0 + wd - pw_next)] = v;
+            }
+            if (emits && tid == 0 && rowblock == 0) states[mat].colw_pw = pw_next;
+        }
+        return;
+    }
+    typedef const __attribute__((address_space(3))) u64* lds_u64_ptr;
+    // byte offset of panel j's table (see above)
+    auto tbase = [](int j) -> unsigned int { return K == 2 ? (unsigned int)j * 65536u : (unsigned int)(j >> 1) * 65536u + (unsigned int)(j & 1) * 128u; };
+    // 16 lookups of one table from byte `at` (table base + word offset) on: entry (g, nibble g of d) at (g*16 + nibble)*256
+    auto lookup16 = [](unsigned int at, u64 d) -> u64 {
+        u64 x = 0;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const unsigned int nib = (unsigned int)(d >> (4 * g)) & 15u;
+            x ^= *(lds_u64_ptr)(uintptr_t)(at + nib * 256u + (unsigned int)g * 4096u);
+        }
+        return x;
+    };
+    // the 16 XOR combinations of a group's four rows (entries 1, 2, 4, 8 are the single rows): a lane takes (group, word) and the
+    // entries with bit 3 clear or set -- 32 * CW lanes
+    auto combos = [&](int j) {
+      for (int c = tid; c < 32 * CW; c += TH) {
+        const int wd = c & (CW - 1), g = (c / CW) & 15, top = c / (16 * CW);
+        u64* e = T + tbase(j) / 8 + (g * 16) * 32 + wd;                // entries are 32 words (256 bytes) apart
+        const u64 r0 = e[1 * 32], r1 = e[2 * 32], r2 = e[4 * 32], r3 = top ? e[8 * 32] : 0ull;
+        const u64 c3 = r3, c13 = r0 ^ r3, c23 = r1 ^ r3, c123 = r0 ^ r1 ^ r3;
+        u64* o = e + (top ? 8 * 32 : 0);
+        if (!top) o[0] = 0ull;
+        if (top) o[1 * 32] = c13, o[2 * 32] = c23;
+        o[3 * 32] = c123;
+        if (top) o[4 * 32] = r2 ^ c3;
+        o[5 * 32] = r2 ^ c13;
+        o[6 * 32] = r2 ^ c23;
+        o[7 * 32] = r2 ^ c123;
+      }
+    };
+    const int sub = lane / LPR, hw = (lane % LPR) * 2;                  // row of the slot, first of this lane's two words
+    const bool valid0 = hw < wc_n, valid1 = hw + 1 < wc_n;
+    auto skippable = [&](int wd) { return (cw0 + wd + 1) * 64 <= skip_hi; };
+    const bool lane_live = valid0 && (moving || !(skippable(hw) && (!valid1 || skippable(hw + 1))));
+    // lanes 16-31 and 48-63 take the panels of a pair in the other order (K = 4: see above)
+    const int swp = K == 4 ? (lane >> 3) & 1 : 0;
+    const unsigned int c0f = 0x0fu;
+    unsigned int at_first[K / 2], at_second[K / 2];
+    int64_t d_first[K / 2], d_second[K / 2];                            // offsets into d_base of the panels this lane takes first / second
+#pragma unroll
+    for (int i = 0; i < K / 2; ++i) {
+        at_first[i] = tbase(2 * i + swp) + (unsigned int)hw * 8u;
+        at_second[i] = tbase(2 * i + 1 - swp) + (unsigned int)hw * 8u;
+        d_first[i] = (int64_t)(2 * i + swp) * dstride + mat * m;
+        d_second[i] = (int64_t)(2 * i + 1 - swp) * dstride + mat * m;
+    }
+    constexpr int NW = TH / 64;
+    const int rl = RPS * wave + sub;                                   // this lane's row among the RPS * NW of a slot
+    const unsigned int lane_word = (unsigned int)rl * (unsigned int)ld + (unsigned int)hw;
+    constexpr int SROWS = RPS * NW;                                    // rows of the workgroup's slot
+    constexpr int STEP = SROWS * 2;                                    // two slots are worked on while the next two are on their way
+    const int emit_at = emits ? (int)(pw_next - cw0) : -1;             // first word of the chunk that goes to the side buffer
+    struct Two {
+        u32x4_t x[2];
+        u64 dF[K / 2][2], dS[K / 2][2];
+    };
+    auto load2 = [&](int64_t rb, Two& s) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t rs = rb + (int64_t)u * SROWS;                // uniform
+            const bool in = rs + rl < row_end;
+            const u64* au = a + rs * ld + cw0;
+#pragma unroll
+            for (int i = 0; i < K / 2; ++i) {
+                s.dF[i][u] = in ? d_base[d_first[i] + rs + rl] : 0ull;
+                s.dS[i][u] = in ? d_base[d_second[i] + rs + rl] : 0ull;
+            }
+            u32x4_t v = {0u, 0u, 0u, 0u};
+            if (in && lane_live) {
+                if (valid1) {
+                    v = *reinterpret_cast<const u32x4_t*>(au + lane_word);
+                } else {
+                    const u64 one = au[lane_word];
+                    v[0] = (unsigned int)one, v[1] = (unsigned int)(one >> 32);
+                }
+            }
+            s.x[u] = v;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    Two s0, s1;
+    const int64_t rb0 = r_lo;
+    const u64 diag_c0 = clock64(), diag_w0 = wall_clock64();
+    load2(rb0, s0);                                                    // on their way while the tables are built
+    // ---- tables: S'_j = S_j ^ sum_{l<j} fix_{j,l} . S'_l, panel after panel -----------------------------------------------------------
+    {
+        u64 sv[K][ITER], fx[K][K][ITER];
+#pragma unroll
+        for (int j = 0; j < K; ++j)
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {                        // everything the build reads from memory, now
+                const int idx = tid + TH * it, p = idx / CW, wd = idx & (CW - 1);
+                sv[j][it] = (p < tg[j] && wd < wc_n) ? snap_base[(int64_t)j * sstride + (mat * 64 + p) * ld + cw0 + wd] : 0ull;
+#pragma unroll
+                for (int l = 0; l < j; ++l)
+                    fx[j][l][it] = (p < tg[j] && tg[l] > 0) ? fix_base[((mat * K + j) * K + l) * 64 + p] : 0ull;
+            }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int idx = tid + TH * it, p = idx / CW, wd = idx & (CW - 1);
+                u64 x = sv[j][it];
+#pragma unroll
+                for (int l = 0; l < j; ++l)
+                    if (tg[l] > 0) x ^= lookup16(tbase(l) + (unsigned int)wd * 8u, fx[j][l][it]);     // uniform condition
+                T[tbase(j) / 8 + ((p >> 2) * 16 + (1 << (p & 3))) * 32 + wd] = x;
+            }
+            __syncthreads();
+            combos(j);
+            __syncthreads();
+        }
+    }
+    const u64 diag_c1 = clock64(), diag_w1 = wall_clock64();
+    auto work2 = [&](int64_t rb, Two& s) {
+        unsigned int pf[K / 2][2], ps[K / 2][2];
+#pragma unroll
+        for (int i = 0; i < K / 2; ++i) pf[i][0] = pf[i][1] = at_first[i], ps[i][0] = ps[i][1] = at_second[i];
+#define GF2_SWEEP_BYTE(B)                                                    \
+    _Pragma("unroll") for (int i = 0; i < K / 2; ++i) {                       \
+        pair_lookups2<B>(s.x, s.dF[i], s.dS[i], pf[i], ps[i], c0f);          \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+    }
+        GF2_SWEEP_BYTE(0) GF2_SWEEP_BYTE(1) GF2_SWEEP_BYTE(2) GF2_SWEEP_BYTE(3)
+        GF2_SWEEP_BYTE(4) GF2_SWEEP_BYTE(5) GF2_SWEEP_BYTE(6) GF2_SWEEP_BYTE(7)
+#undef GF2_SWEEP_BYTE
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t rs = rb + (int64_t)u * SROWS;
+            const bool in = rs + rl < row_end;
+            u64* au = a_out + rs * ld + cw0;
+            u64 any = 0;
+#pragma unroll
+            for (int i = 0; i < K / 2; ++i) any |= s.dF[i][u] | s.dS[i][u];
+            if ((any || (moving && in)) && lane_live) {
+                if (valid1)
+                    *reinterpret_cast<u32x4_t*>(au + lane_word) = s.x[u];
+                else
+                    au[lane_word] = ((u64)s.x[u][1] << 32) | s.x[u][0];
+            }
+            if (emit_at >= 0 && in && hw >= emit_at && hw < emit_at + K)
+                *reinterpret_cast<u32x4_t*>(colw + (rs + rl) * K + (hw - emit_at)) = s.x[u];
+        }
+    };
+    for (int64_t rb = rb0; rb < row_end; rb += 2 * STEP) {
+        load2(rb + STEP, s1);
+        work2(rb, s0);
+        load2(rb + 2 * STEP, s0);
+        if (rb + STEP < row_end) work2(rb + STEP, s1);                 // uniform
+    }
+    if (emits && tid == 0 && rowblock == 0) states[mat].colw_pw = pw_next;
+    if (tid == 0) {
+        const u64 diag_c2 = clock64(), diag_w2 = wall_clock64();
+        atomicAdd(&g_sweep_diag[0], diag_c1 - diag_c0);
+        atomicAdd(&g_sweep_diag[1], diag_w1 - diag_w0);
+        atomicAdd(&g_sweep_diag[2], diag_c2 - diag_c1);
+        atomicAdd(&g_sweep_diag[3], diag_w2 - diag_w1);
+        atomicAdd(&g_sweep_diag[4], 1ull);
+        if (pw0 == (int64_t)g_sweep_diag[7]) {                        // the sweep whose workgroups are logged
+            const unsigned int wg = unit;
+            if (wg < 4096) {
+                unsigned int hw, xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                g_sweep_wg[4 * wg] = diag_wg0;
+                g_sweep_wg[4 * wg + 1] = diag_w1;
+                g_sweep_wg[4 * wg + 2] = diag_w2;
+                g_sweep_wg[4 * wg + 3] = ((u64)xcc << 32) | hw;
+            }
+        }
+    }
+}
+
+// (A persistent form -- one workgroup per CU taking units off a counter -- was built and measured: 220 - 279 us per sweep of
+// 256 matrices against 195 - 223 for this grid.  The per-workgroup clocks that prompted it, profiles/r05_pass_timeline.md, had shown
+// gaps of 20 - 30 us between one workgroup's end and the next one's start on the same CU; they are the workgroup's own later
+// wavefronts -- the LDS serves the oldest wavefront first, so wavefront 0, which took the stamps, is done long before the last.)
+template <int K, int TH>
+__global__ __launch_bounds__(TH) void rref_sweep_update_kernel(u64* base, int64_t m, int64_t ld, int64_t rows_per_wg,
+                                                               SweepState* __restrict__ states, const u64* __restrict__ d_base,
+                                                               int64_t dstride, const u64* __restrict__ snap_base,
+                                                               int64_t sstride, const u64* __restrict__ fix_base, int64_t pw0,
+                                                               u64* __restrict__ colw_base, u64* out_base) {
+    extern __shared__ __attribute__((aligned(16))) u64 T[];           // (the lookups address the tables from LDS byte 0: the kernel's only LDS)
+    const unsigned int unit = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    sweep_update_unit<K, TH>(T, blockIdx.z, blockIdx.y, blockIdx.x, unit, base, m, ld, rows_per_wg, states, d_base, dstride, snap_base, sstride,
+                             fix_base, pw0, colw_base, out_base);
+}
+
 // ---- blocked normalisation (css_code.py:809-836), bit-exact ------------------------------------------------------------
 //
 // The reference adds the first odd row at or below the diagonal INTO the diagonal row (never swaps rows) and clears the
@@ -1095,11 +1602,20 @@ __global__ void rref_state_init_kernel(RrefState* __restrict__ states, int64_t b
     if (mat < batch) states[mat].first_free = n;
 }
 
+__global__ void sweep_state_init_kernel(SweepState* __restrict__ states, int64_t batch, int64_t n) {
+    const int64_t mat = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (mat < batch) {
+        states[mat].first_free = n;
+        states[mat].colw_pw = -1;
+    }
+}
+
 // out row k (k < rank) = in row pivrow[k]; rows >= rank are zero.  grid (ceil(m / 16), batch), block 256: sixteen rows per
 // workgroup, moved as 16-byte pieces when the row pitch is even (8-byte words otherwise).
 #define GATHER_ROWS 16
+template <typename State>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const u64* __restrict__ in, u64* __restrict__ out,
-                                                          const int32_t* __restrict__ pivrow, const RrefState* __restrict__ states,
+                                                          const int32_t* __restrict__ pivrow, const State* __restrict__ states,
                                                           int64_t* __restrict__ rank_out, int64_t m, int64_t ld, int64_t cap) {
     typedef unsigned int v4 __attribute__((ext_vector_type(4)));
     __shared__ int64_t src_row[GATHER_ROWS];
@@ -1641,6 +2157,148 @@ static int launch_eliminate(gf2_ctx* ctx, int mode, u64* a_dev, int64_t batch, i
     return GF2_OK;
 }
 
+// Blocked path for matrices of at most 8192 rows, K panels per sweep (rref_sweep_panel_kernel / rref_sweep_update_kernel).  A batch
+// is cut into up to four GROUPS of matrices, each on a stream of its own: the panel kernel is one workgroup per matrix and mostly
+// one wavefront of it at work (latency), the trailing pass is the whole chip streaming (bandwidth), so the panels of one group run
+// under the passes of the others -- the groups are independent problems, no events between them but the start and the end.
+// Workspace: a copy of the batch (the first pass moves the batch there, the row gather writes it back in place), pivot-row lists,
+// states, used flags, and per panel of a sweep the coefficients d and the pivot-row snapshots, `fix`, and the side buffer of the
+// next sweep's column words.
+template <int K, int TH>
+static int launch_rref_sweeps(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld, int64_t* pivots_dev,
+                              int64_t cap, int64_t* rank_dev) {
+    constexpr int CW = 64 / K;
+    const int rpt = (int)gf2_cdiv(m, RB_THREADS);
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t abytes = al((size_t)batch * m * ld * 8), pbytes = al((size_t)batch * cap * 4);
+    const size_t sbytes = al((size_t)batch * sizeof(SweepState)), ubytes = al((size_t)batch * m);
+    const size_t dbytes = al((size_t)batch * m * 8), nbytes = al((size_t)batch * 64 * ld * 8);
+    const size_t fbytes = al((size_t)batch * K * K * 64 * 8), cbytes = al((size_t)batch * m * K * 8);
+    GF2_TRY(gf2_ws_reserve(ctx, 1, abytes + pbytes + sbytes + ubytes + K * (dbytes + nbytes) + fbytes + cbytes));
+    char* q = (char*)ctx->ws[1];
+    u64* tmp = (u64*)q; q += abytes;
+    int32_t* pivrow = (int32_t*)q; q += pbytes;
+    SweepState* states = (SweepState*)q; q += sbytes;
+    unsigned char* used = (unsigned char*)q; q += ubytes;
+    u64* dco = (u64*)q; q += K * dbytes;
+    u64* snap = (u64*)q; q += K * nbytes;
+    u64* fix = (u64*)q; q += fbytes;
+    u64* colw = (u64*)q;
+    const int64_t dstride = (int64_t)(dbytes / 8), sstride = (int64_t)(nbytes / 8);
+    GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
+    GF2_HIP(hipMemsetAsync(states, 0, sbytes + ubytes, ctx->stream));          // rank = 0, used = 0 ...
+    hipLaunchKernelGGL(sweep_state_init_kernel, dim3((unsigned)gf2_cdiv(batch, 256)), dim3(256), 0, ctx->stream, states, batch, n);
+    if (!ctx->lds_optin[(K == 2 ? 5 : 7) + (TH == 512)]) {
+        GF2_HIP(hipFuncSetAttribute((const void*)rref_sweep_update_kernel<K, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ctx->lds_optin[(K == 2 ? 5 : 7) + (TH == 512)] = true;
+    }
+    // groups of matrices, each on its own stream
+    hipStream_t streams[4] = {ctx->stream, ctx->side[0], ctx->side[1], ctx->hi};
+    int groups = batch >= 16 ? 4 : (batch >= 2 ? 2 : 1);
+    if (ctx->opt[GF2_OPT_RREF_GROUPS] >= 1) groups = (int)ctx->opt[GF2_OPT_RREF_GROUPS];
+    if (groups > 4) groups = 4;
+    if (groups > batch) groups = (int)batch;
+    for (int g = 1; g < groups; ++g)
+        if (!streams[g]) groups = g;
+    int64_t g_lo[5];
+    for (int g = 0; g <= groups; ++g) g_lo[g] = batch * g / groups;
+    if (groups > 1) {
+        GF2_HIP(hipEventRecord(ctx->side_ev[0], ctx->stream));
+        for (int g = 1; g < groups; ++g) GF2_HIP(hipStreamWaitEvent(streams[g], ctx->side_ev[0], 0));
+    }
+    const int64_t panels = gf2_words(n) < ld ? gf2_words(n) : ld;
+    const int64_t chunks = gf2_cdiv(ld, CW);
+    const int64_t sweeps = gf2_cdiv(panels, K);
+    bool moved = false;                                                // the first pass has taken the batch to the workspace copy
+    auto all_done = [&](int64_t pw_last, bool* done) -> int {
+        *done = false;
+        if (!((pw_last + 1) * 64 >= m && pw_last + 1 < panels && ((pw_last + 1) * 64 - m) % 512 < 64 * K)) return GF2_OK;
+        for (int g = 1; g < groups; ++g) {
+            GF2_HIP(hipEventRecord(ctx->side_ev[g], streams[g]));
+            GF2_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_ev[g], 0));
+        }
+        std::vector<SweepState> now((size_t)batch);
+        GF2_HIP(hipMemcpyAsync(now.data(), states, (size_t)batch * sizeof(SweepState), hipMemcpyDeviceToHost, ctx->stream));
+        GF2_TRY(gf2_stream_wait(ctx->stream));
+        *done = true;
+        for (const auto& st : now) *done = *done && st.rank >= m;
+        return GF2_OK;
+    };
+    for (int64_t s = 0; s < sweeps; ++s) {
+        const int64_t pw0 = s * K;
+        u64* work = moved ? tmp : a_dev;
+        for (int g = 0; g < groups; ++g) {
+            const int64_t b0 = g_lo[g], nb = g_lo[g + 1] - b0;
+            if (nb == 0) continue;
+            hipStream_t on = streams[g];
+#define GF2_SP_LAUNCH(RPT)                                                                                                       \
+    hipLaunchKernelGGL((rref_sweep_panel_kernel<K, RPT>), dim3((unsigned)nb), dim3(RB_THREADS), 0, on, (const u64*)(work + b0 * m * ld), m, n, \
+                       ld, pw0, pivots_dev ? pivots_dev + b0 * cap : nullptr, cap, pivrow + b0 * cap, states + b0, used + b0 * m,  \
+                       (const u64*)(colw + b0 * m * K), dco + b0 * m, dstride, snap + b0 * 64 * ld, sstride, fix + b0 * K * K * 64)
+            if (rpt <= 1)
+                GF2_SP_LAUNCH(1);
+            else if (rpt <= 2)
+                GF2_SP_LAUNCH(2);
+            else if (rpt <= 4)
+                GF2_SP_LAUNCH(4);
+            else
+                GF2_SP_LAUNCH(8);
+#undef GF2_SP_LAUNCH
+            // rows per update workgroup: a lone matrix wants many workgroups, a large batch wants the table build amortised (a
+            // workgroup owns its CU -- 128 KiB of tables): about two workgroups per CU over the launch, no fewer than 256 rows each
+            int64_t rows_wg = gf2_cdiv(gf2_cdiv(m * chunks * nb, 2 * (int64_t)ctx->num_cus), 256) * 256;
+            if (rows_wg > 256) rows_wg = gf2_cdiv(m, gf2_cdiv(m, rows_wg));
+            if (rows_wg < 256) rows_wg = 256;
+            if (ctx->opt[GF2_OPT_RREF_ROWS_WG] >= 64) rows_wg = ctx->opt[GF2_OPT_RREF_ROWS_WG];
+            const dim3 grid((unsigned)gf2_cdiv(m, rows_wg), (unsigned)chunks, (unsigned)nb);
+            hipLaunchKernelGGL((rref_sweep_update_kernel<K, TH>), grid, dim3(TH), 128 * 1024, on, work + b0 * m * ld, m, ld, rows_wg,
+                               states + b0, (const u64*)(dco + b0 * m), dstride, (const u64*)(snap + b0 * 64 * ld), sstride,
+                               (const u64*)(fix + b0 * K * K * 64), pw0, colw + b0 * m * K, (moved ? tmp : tmp) + b0 * m * ld);
+        }
+        moved = true;
+        GF2_HIP(hipGetLastError());
+        bool done;
+        GF2_TRY(all_done(pw0 + K - 1, &done));
+        if (done) break;
+    }
+    for (int g = 0; g < groups; ++g) {
+        const int64_t b0 = g_lo[g], nb = g_lo[g + 1] - b0;
+        if (nb == 0) continue;
+        hipLaunchKernelGGL(gather_rows_kernel<SweepState>, dim3((unsigned)gf2_cdiv(m, GATHER_ROWS), (unsigned)nb), dim3(256), 0, streams[g],
+                           (const u64*)(tmp + b0 * m * ld), a_dev + b0 * m * ld, (const int32_t*)(pivrow + b0 * cap),
+                           (const SweepState*)(states + b0), rank_dev + b0, m, ld, cap);
+        if (g > 0) {
+            GF2_HIP(hipEventRecord(ctx->side_ev[g], streams[g]));
+            GF2_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_ev[g], 0));
+        }
+    }
+    GF2_HIP(hipGetLastError());
+    GF2_TRY(gf2_prof_end(ctx));
+    if (getenv("GF2_RREF_DIAG")) {
+        u64 dg[8];
+        GF2_HIP(hipStreamSynchronize(ctx->stream));
+        GF2_HIP(hipMemcpyFromSymbol(dg, HIP_SYMBOL(g_sweep_diag), sizeof(dg)));
+        const double n_wg = (double)(dg[4] ? dg[4] : 1);
+        fprintf(stderr, "sweep pass K=%d TH=%d: %.0f workgroups; table build %.0f cycles / %.2f us (%.2f GHz); rows %.0f cycles / %.2f us (%.2f GHz)\n",
+                K, TH, n_wg, dg[0] / n_wg, dg[1] / n_wg / 100.0, dg[1] ? dg[0] / (dg[1] * 10.0) : 0.0, dg[2] / n_wg, dg[3] / n_wg / 100.0,
+                dg[3] ? dg[2] / (dg[3] * 10.0) : 0.0);
+        if (getenv("GF2_RREF_DIAG_WG")) {
+            std::vector<u64> wg(4 * 4096);
+            GF2_HIP(hipMemcpyFromSymbol(wg.data(), HIP_SYMBOL(g_sweep_wg), wg.size() * 8));
+            FILE* f = fopen(getenv("GF2_RREF_DIAG_WG"), "w");
+            if (f) {
+                for (int i = 0; i < 4096; ++i)
+                    if (wg[4 * i]) fprintf(f, "%d %llu %llu %llu %llx\n", i, wg[4 * i], wg[4 * i + 1], wg[4 * i + 2], wg[4 * i + 3]);
+                fclose(f);
+            }
+        }
+        memset(dg, 0, sizeof(dg));
+        dg[7] = getenv("GF2_RREF_DIAG_SWEEP") ? (u64)atoll(getenv("GF2_RREF_DIAG_SWEEP")) : 8;
+        GF2_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_diag), dg, sizeof(dg)));
+    }
+    return GF2_OK;
+}
+
 extern "C" {
 
 // Blocked path.  Workspace: a copy of the batch for the row gather, pivot-row lists, per-matrix state, used flags, and per SET
@@ -1650,6 +2308,14 @@ extern "C" {
 static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld,
                                int64_t* pivots_dev, int64_t cap, int64_t* rank_dev) {
     const int rpt = (int)gf2_cdiv(m, RB_THREADS);
+    if (rpt <= 8 && ctx->opt[GF2_OPT_RREF_SWEEP_K] != 0) {             // K panels per sweep (round 5); 0: the pair kernels below
+        const bool half = ctx->opt[GF2_OPT_RREF_PASS_THREADS] == 512;
+        if (ctx->opt[GF2_OPT_RREF_SWEEP_K] == 2)
+            return half ? launch_rref_sweeps<2, 512>(ctx, a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev)
+                        : launch_rref_sweeps<2, 1024>(ctx, a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
+        return half ? launch_rref_sweeps<4, 512>(ctx, a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev)
+                    : launch_rref_sweeps<4, 1024>(ctx, a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
+    }
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t abytes = al((size_t)batch * m * ld * 8), pbytes = al((size_t)batch * cap * 4);
     const size_t sbytes = al((size_t)batch * sizeof(RrefState)), ubytes = al((size_t)batch * m);
@@ -1850,8 +2516,8 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
         }
     }
     GF2_HIP(hipGetLastError());
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)gf2_cdiv(m, GATHER_ROWS), (unsigned)batch), dim3(256), 0, ctx->stream,
-                       (const u64*)work, work == a_dev ? tmp : a_dev, pivrow, states, rank_dev, m, ld, cap);
+    hipLaunchKernelGGL(gather_rows_kernel<RrefState>, dim3((unsigned)gf2_cdiv(m, GATHER_ROWS), (unsigned)batch), dim3(256), 0, ctx->stream,
+                       (const u64*)work, work == a_dev ? tmp : a_dev, (const int32_t*)pivrow, (const RrefState*)states, rank_dev, m, ld, cap);
     GF2_HIP(hipGetLastError());
     if (work == a_dev) GF2_HIP(hipMemcpyAsync(a_dev, tmp, (size_t)batch * m * ld * 8, hipMemcpyDeviceToDevice, ctx->stream));
     GF2_TRY(gf2_prof_end(ctx));
