@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Round 5 development check of the blocked RREF with K panels per sweep: parity against the C oracle over shapes that reach every
-branch (several rounds per panel, pivot-free panels, rank-deficient, ragged chunks, batches cut into stream groups), then timings
+branch (several rounds per panel, pivot-free panels, rank-deficient, ragged chunks, small row blocks), then timings
 of bench.py's three shapes under the internal options.   python profiles/r05_rref_dev.py [check] [time]"""
 import os
 import sys
@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 from oracle import c_oracle  # noqa: E402
 from quantum_css_codes_amd import _native  # noqa: E402
 
-OPT_GROUPS, OPT_ROWS_WG, OPT_K = 11, 12, 13
+OPT_ROWS_WG, OPT_K = 12, 13
 ctx = _native.default_context()
 
 
@@ -40,11 +40,11 @@ def check():
         mats = mats_for(m, n, batch, m * 11 + n + batch)
         want = [c_oracle.rref(c_oracle.pack_rows(a), m, n) for a in mats]
         for k in (4, 2, 0):
-            for groups in (1, 2, 4):
-                if k == 0 and groups > 1:
+            for rows_wg in (-1, 128):
+                if k == 0 and rows_wg > 0:
                     continue
                 ctx.set_option(OPT_K, k)
-                ctx.set_option(OPT_GROUPS, groups)
+                ctx.set_option(OPT_ROWS_WG, rows_wg)
                 flags = ctx.get_flags()
                 ctx.set_flags(flags | (1 << 9))                       # no wavefront-per-matrix kernel: the blocked path
                 packed = np.stack([_native.pack_rows(a) for a in mats])
@@ -54,10 +54,10 @@ def check():
                 for b in range(batch):
                     ok = ok and ranks[b] == want[b][2] and np.array_equal(packed[b], want[b][0]) and \
                         list(pivots[b, :want[b][2]]) == list(want[b][1])
-                print("check %5d x %5d x %3d  K=%d groups=%d  %s" % (m, n, batch, k, groups, "ok" if ok else "MISMATCH"), flush=True)
+                print("check %5d x %5d x %3d  K=%d rows_wg=%d  %s" % (m, n, batch, k, rows_wg, "ok" if ok else "MISMATCH"), flush=True)
                 bad += 0 if ok else 1
     ctx.set_option(OPT_K, -1)
-    ctx.set_option(OPT_GROUPS, -1)
+    ctx.set_option(OPT_ROWS_WG, -1)
     print("check: %d mismatches" % bad)
     return bad
 
@@ -70,16 +70,13 @@ def timing():
         return (rng.integers(0, 2**63, (m, ld), dtype=np.int64).view(np.uint64) << np.uint64(1)) | \
             rng.integers(0, 2, (m, ld), dtype=np.int64).view(np.uint64)
 
-    for (m, n, batch) in ((2048, 4096, 1), (2048, 4096, 256), (2048, 4096, 16), (8192, 16384, 4)):
+    for (m, n, batch) in ((2048, 4096, 1), (2048, 4096, 256), (2048, 4096, 16), (4096, 8192, 8), (1024, 2048, 64), (3000, 5000, 3)):
         mats = [random_packed(m, n) for _ in range(min(batch, 64))]
         nb = mats[0].nbytes
         buf = ctx.alloc(batch * nb)
         piv, rk = ctx.alloc(batch * min(m, n) * 8), ctx.alloc(batch * 8)
-        for (k, groups) in ((0, 1), (2, 1), (2, 2), (2, 4), (4, 1), (4, 2), (4, 4)):
-            if batch == 1 and groups > 1:
-                continue
+        for k in (0, 2, 4):
             ctx.set_option(OPT_K, k)
-            ctx.set_option(OPT_GROUPS, groups)
             best = None
             for _ in range(4):
                 for b in range(batch):
@@ -89,11 +86,10 @@ def timing():
                 ms = ctx.timer_stop()
                 best = ms if best is None else min(best, ms)
             ranks = rk.download((batch,), np.int64)
-            print("time %5d x %5d x %3d  K=%d groups=%d  %.3f ms  %.1f GB/s  rank %d" %
-                  (m, n, batch, k, groups, best, batch * 2 * nb / best / 1e6, int(ranks.min())), flush=True)
+            print("time %5d x %5d x %3d  K=%d  %.3f ms  %.1f GB/s  rank %d" %
+                  (m, n, batch, k, best, batch * 2 * nb / best / 1e6, int(ranks.min())), flush=True)
         buf.free(), piv.free(), rk.free()
     ctx.set_option(OPT_K, -1)
-    ctx.set_option(OPT_GROUPS, -1)
 
 
 if __name__ == "__main__":

@@ -193,17 +193,17 @@ def check_elim(path):
             errors.add("%s line %d: `%s` uses m0 outside the inline assembly that owns it" % (name, no, text))
         spills = sum(1 for _, text, _ in stream if text.startswith("scratch_"))
         if spills and panel and "rref_sweep_panel_kernel" in name and not re.search(r"rref_sweep_panel_kernelILi\dELi8E", name):
-            # held to 64 registers (to share a CU with a trailing-pass workgroup): spills are accepted outside the pivot loop of
-            # window_round -- the innermost loop that holds its v_writelane
+            # (four rows per lane: the K column words and coefficients of a lane's rows) spills are accepted outside the pivot loop
+            # of window_round -- the innermost loop that holds its v_writelane
             hot = hot_loop_spills(stream)
             if hot is None:
                 errors.add("%s: the pivot loop (v_writelane) was not found" % name)
             elif hot > 2:
                 errors.add("%s: %d scratch (spill) operations inside the pivot loop" % (name, hot))
             elif hot:
-                notes.append("%s: %d scratch operations, %d of them in the pivot loop (64 registers)" % (name, spills, hot))
+                notes.append("%s: %d scratch operations, %d of them in the pivot loop" % (name, spills, hot))
             else:
-                notes.append("%s: %d scratch operations, none in the pivot loop (64 registers)" % (name, spills))
+                notes.append("%s: %d scratch operations, none in the pivot loop" % (name, spills))
             continue
         if spills and panel:
             if "rref_panel_kernelILi8E" in name or re.search(r"rref_sweep_panel_kernelILi\dELi8E", name):

@@ -236,7 +236,7 @@ __device__ __forceinline__ u64 transpose64(u64 x, int lane) {
 // is no faster: 0.99, 1.03, 1.13 ms for the 2048 x 4096 matrix against 0.98.)
 __device__ __forceinline__ void window_round(int lane, int nwin, int t, int64_t rank, int64_t m, u64 unresolved, const u64* win_w,
                                              const u64* win_d, const int* win_row, int* win_piv, u64* fin_w, u64* fin_d,
-                                             int* pbit, int* prow_l, u64* DP, u64* WP, int* misc) {
+                                             int* pbit, int* prow_l, u64* DP, u64* WP, int* misc, int* win_q = nullptr) {
     u64 w0 = lane < nwin ? win_w[lane] : 0ull, w1 = lane + 64 < nwin ? win_w[lane + 64] : 0ull, w2 = 1ull << lane;
     u64 d0 = (t > 0 && lane < nwin) ? win_d[lane] : 0ull;             // uniform: coefficients of earlier rounds
     u64 d1 = (t > 0 && lane + 64 < nwin) ? win_d[lane + 64] : 0ull, d2 = 0ull;
@@ -248,7 +248,8 @@ __device__ __forceinline__ void window_round(int lane, int nwin, int t, int64_t 
                (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, src);
     };
     u64 todo = unresolved;
-    while (todo && tt < 64 && rank + tt < m) {
+    const int tmax = m - rank < 64 ? (int)(m - rank) : 64;             // (a 32-bit scalar compare per pivot: `rank + tt < m` was a 64-bit vector one)
+    while (todo && tt < tmax) {
         const int b = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
         u64 c0 = __ballot((w0 >> b) & 1ull), c1 = __ballot((w1 >> b) & 1ull);                // column b: window rows 0..63, 64..127
@@ -298,6 +299,7 @@ __device__ __forceinline__ void window_round(int lane, int nwin, int t, int64_t 
     if (lane >= t && lane < tt) {
         pbit[lane] = (int)my_pbit;
         prow_l[lane] = win_row[my_prow];
+        if (win_q) win_q[my_prow] = lane;                              // (uniform) the window row's number among the panel's pivots
     }
     DP[lane] = d2;                                                     // row j: the coefficients a row takes for having bit j
     WP[lane] = w2;                                                     // row j: what becomes of bit j
@@ -968,17 +970,28 @@ __global__ __launch_bounds__(RB_THREADS) void rref_update_pair_kernel(u64* base,
 // columns) per trip halves the trips; the Four-Russians lookups per trip double (their total stays), and the tables of four panels
 // fit the same 128 KiB because a workgroup then owns 16 words (128 bytes) of a row instead of 32.  Per sweep, two kernels:
 //
-//   rref_sweep_panel_kernel<K, RPT> (one workgroup per matrix): the K panel factorisations one after another in ONE launch.
-//     Panel j's column is brought up to date on the way in for what panels l < j of the sweep have found but nobody has applied yet:
-//         w ^= sum_{l<j} d_l[row] . S'_l[:, pw_j],     S'_l[q] = S_l[q] ^ sum_{l2<l} fix_{l,l2}[q] . S'_{l2}
-//     (S_l: panel l's pivot rows as they stand in memory, fix_{l,l2}[q] = d_{l2} of panel l's q-th pivot row) -- one byte-table
-//     lookup per row and earlier panel.  The K column words of every row come from a compact side buffer (32 bytes per row, written
-//     by the previous sweep's trailing pass) instead of one 128-byte line per row and word; without one (first sweep) from the rows.
-//   rref_sweep_update_kernel<K> (grid: row blocks x chunks of 64 / K words x matrices): new_i = old_i ^ sum_j d_j,i . S'_j with K
-//     Four-Russians tables, S'_j made by the table build as above; writes the next sweep's K column words of its rows to the side
-//     buffer on the way out.
-__device__ u64 g_sweep_diag[8];
-__device__ u64 g_sweep_wg[4 * 4096];                // development: per workgroup of ONE pass launch: start, tables done, end (wall ticks), hardware id                     // development: cycles / wall ticks of the trailing pass' phases (GF2_RREF_DIAG)
+//   rref_sweep_panel_kernel<K, RPT> (one workgroup per matrix): the K panel factorisations one after another in ONE launch,
+//     RIGHT-LOOKING: a lane holds the K column words of its rows and, after panel l, brings the later columns up to date
+//     (w_j ^= d_l . column j of panel l's pivot rows as they stand -- the pivot rows' own w_j -- one byte-table lookup), and it
+//     keeps every row's coefficients FOLDED onto the pivot rows as they stand in MEMORY (e_{l2} ^= d_l . E_{l,l2}, E's rows = e_{l2}
+//     of panel l's pivot rows), so that the trailing pass needs no correction of the second to fourth panel's pivot rows.  The K
+//     column words of every row come from a compact side buffer (8 K bytes per row, written by the previous sweep's trailing pass)
+//     instead of one 128-byte line per row and word; without one (first sweep, a sweep after one without pivots) from the rows.
+//   rref_sweep_update_kernel<K> (grid: row blocks x chunks of 64 / K words x matrices): new_i = old_i ^ sum_l e_{l,i} . S_l with K
+//     Four-Russians tables made of the pivot-row snapshots as they are; writes the next sweep's K column words of its rows to the
+//     side buffer on the way out.  A sweep with at most 8 pivots (the sweeps after the one that reached full rank) takes the pivot
+//     rows one by one instead.
+//
+// Built with -DGF2_SWEEP_DIAG=1 (profiles/r05_diag.sh) the two kernels stamp their phases with the shader clock and the constant
+// 100 MHz clock; with GF2_RREF_DIAG=1 in the environment the launcher prints the averages: where the numbers in DESIGN.md come from.
+#ifndef GF2_SWEEP_DIAG
+#define GF2_SWEEP_DIAG 0
+#endif
+#if GF2_SWEEP_DIAG
+__device__ u64 g_sweep_diag[8];                     // cycles / wall ticks of the trailing pass' phases (wavefront 0 of every workgroup)
+__device__ u64 g_panel_diag[8];                     // wall ticks of the panel kernel's phases (workgroup 0)
+__device__ u64 g_sweep_wg[4 * 4096];                // per workgroup of ONE pass launch: start, tables done, end (wall ticks), hardware id
+#endif
 struct SweepState {                                 // per matrix, in global scratch
     int64_t rank;                                   // pivots so far
     int64_t first_free;                             // first column seen without a pivot
@@ -998,22 +1011,34 @@ __device__ __forceinline__ void byte_table(int tid, const u64* rows64, u64* T) {
 }
 
 template <int K, int RPT>
-__global__ __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(RPT <= 2 ? 8 : 4, 8))) void rref_sweep_panel_kernel(const u64* __restrict__ base, int64_t m, int64_t n, int64_t ld,
+__global__ __launch_bounds__(RB_THREADS) void rref_sweep_panel_kernel(const u64* __restrict__ base, int64_t m, int64_t n, int64_t ld,
                                                                      int64_t pw0, int64_t* __restrict__ pivots_base, int64_t cap,
                                                                      int32_t* __restrict__ pivrow_base, SweepState* __restrict__ states,
                                                                      unsigned char* __restrict__ used_base,
                                                                      const u64* __restrict__ colw_base, u64* __restrict__ d_base,
-                                                                     int64_t dstride, u64* __restrict__ snap_base, int64_t sstride,
-                                                                     u64* __restrict__ fix_base) {
-    // d_base: [K][dstride] coefficients (dstride >= batch * m); snap_base: [K][sstride] pivot-row snapshots (batch x 64 x ld each);
-    // fix_base: [batch][K][K][64]
-    __shared__ u64 T[2048];                                             // one byte table at a time: corrections, coefficients, words
+                                                                     int64_t dstride, u64* __restrict__ snap_base, int64_t sstride) {
+    // d_base: [K][dstride] coefficients (dstride >= batch * m); snap_base: [K][sstride] pivot-row snapshots (batch x 64 x ld each)
+    constexpr int NT = K - 1 < 2 ? 2 : K - 1;                           // byte tables held at a time
+    __shared__ u64 TT[NT * 2048];
     __shared__ u64 win_w[RB_WIN], win_d[RB_WIN], fin_w[RB_WIN], fin_d[RB_WIN], DP[64], WP[64];
-    __shared__ u64 colS[K][64], fixl[K * (K - 1) / 2][64];              // fixl[j (j - 1) / 2 + l]: panel j's pivot rows, earlier panel l
-    __shared__ int win_row[RB_WIN], win_piv[RB_WIN], pbit[64], prow_l[64], wave_tot[RB_THREADS / 64], misc[4];
+    __shared__ u64 pub[K - 1][64];                                      // what a panel's new pivot rows show the other rows (see below)
+    __shared__ int win_row[RB_WIN], win_piv[RB_WIN], win_q[RB_WIN], pbit[64], prow_l[64], wave_tot[RB_THREADS / 64], misc[4];
     __shared__ int prow_all[K][64], tj[K];
 
     const int64_t mat = blockIdx.x;
+#if GF2_SWEEP_DIAG
+    u64 stamp_prev = wall_clock64();
+#define GF2_STAMP(i)                                                  \
+    do {                                                              \
+        if (threadIdx.x == 0 && blockIdx.x == 0) {                    \
+            const u64 now_ = wall_clock64();                          \
+            atomicAdd(&g_panel_diag[i], now_ - stamp_prev);           \
+            stamp_prev = now_;                                        \
+        }                                                             \
+    } while (0)
+#else
+#define GF2_STAMP(i) do { } while (0)
+#endif
     const u64* a = base + mat * m * ld;
     SweepState* st = states + mat;
     unsigned char* used = used_base + mat * m;
@@ -1028,69 +1053,44 @@ __global__ __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(RPT 
     const u64* colw = colw_base + mat * m * K;
     int64_t* pivots = pivots_base ? pivots_base + mat * cap : nullptr;
     int32_t* pivrow = pivrow_base + mat * cap;
-    u64* fixg = fix_base + mat * K * K * 64;
 
+    // The K column words of this lane's rows, kept up to date as the sweep's panels are factorised one after another
+    // (right-looking): after panel l every row takes, for each later column j,  w_j ^= d_l . (column j of panel l's pivot rows AS
+    // THEY STAND, i.e. those rows' own w_j) -- one byte-table lookup.  The coefficients are kept FOLDED onto the pivot rows as they
+    // stand in memory: panel l's pivot row q has itself taken e_{l2,q} . S_{l2} from the earlier panels l2 < l (S: memory state), so
+    // a row that takes d_l . (current pivot rows of l) takes d_l . S_l and, for every l2 < l, (d_l . E_{l,l2}) . S_{l2}, where row q
+    // of the 64 x 64 matrix E_{l,l2} is e_{l2} of pivot row q:  e_{l2} ^= d_l . E_{l,l2}, another byte-table lookup.  The trailing
+    // pass then is  new_i = old_i ^ sum_l e_{l,i} . S_l  with tables made of pivot rows as the snapshot holds them, nothing to fix.
+    u64 w_all[K][RPT], e_all[K][RPT];
     unsigned int usedmask = 0, usedmask0;
 #pragma unroll
     for (int k = 0; k < RPT; ++k) {
         const int64_t row = tid + (int64_t)RB_THREADS * k;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            w_all[j][k] = (row < m && (pw0 + j) * 64 < n) ? (have_colw ? colw[row * K + j] : a[row * ld + pw0 + j]) : 0ull;
+            e_all[j][k] = 0;
+        }
         if (row < m && used[row]) usedmask |= 1u << k;
     }
     usedmask0 = usedmask;
+    GF2_STAMP(0);                                                      // prologue: state, column words, used flags
     int64_t rank = rank0;
     const int64_t first_free_in = first_free;
     if (tid < K) tj[tid] = 0;
-    __syncthreads();
-#pragma unroll 1
-    for (int j = 0; j < K; ++j) {
-        const int64_t pw = pw0 + j;
+    int t_sum = 0;
+#pragma unroll
+    for (int l = 0; l < K; ++l) {
+        const int64_t pw = pw0 + l;
         __syncthreads();                                               // (a panel that found nothing left its last round without one)
-        u64* dout = d_base + (int64_t)j * dstride + mat * m;
-        if (rank >= m || pw * 64 >= n) {                               // uniform: nothing left for this panel
-            // (the trailing pass reads its coefficients all the same)
-            for (int64_t row = tid; row < m; row += RB_THREADS) dout[row] = 0ull;
-            continue;
-        }
-        // ---- the panel's column, brought up to date for the sweep's earlier panels ---------------------------------------------
+        if (rank >= m || pw * 64 >= n) continue;                       // uniform: nothing left for this panel
+        if (tid < 64 * (K - 1)) pub[tid >> 6][tid & 63] = 0ull;         // (read after the rounds' barriers)
+        // ---- panel factorisation on column l (as rref_panel_kernel) ------------------------------------------------------------
         u64 w[RPT], d[RPT];
-        int slot[RPT];
+        int slot[RPT], qidx[RPT];
+        unsigned int fresh = 0;                                         // rows of this lane that became pivots of this panel
 #pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int64_t row = tid + (int64_t)RB_THREADS * k;
-            w[k] = row < m ? (have_colw ? colw[row * K + j] : a[row * ld + pw]) : 0ull;
-            d[k] = 0;
-        }
-#pragma unroll 1
-        for (int l = 0; l < j; ++l) {
-            if (tj[l] == 0) continue;                                  // uniform
-            if (wave == 0) {
-                // column pw of panel l's pivot rows as the sweep's earlier panels leave them
-                u64 x = 0;
-                if (lane < tj[l]) {
-                    const int64_t prow = prow_all[l][lane];
-                    x = have_colw ? colw[prow * K + j] : a[prow * ld + pw];
-#pragma unroll 1
-                    for (int l2 = 0; l2 < l; ++l2) {
-                        const int t2 = tj[l2];
-                        const u64 f = fixl[l * (l - 1) / 2 + l2][lane];
-                        for (int p = 0; p < t2; ++p)
-                            if ((f >> p) & 1ull) x ^= colS[l2][p];
-                    }
-                }
-                colS[l][lane] = x;                                     // (one wavefront: its LDS operations are served in order)
-            }
-            __syncthreads();
-            byte_table(tid, colS[l], T);
-            __syncthreads();
-            const u64* dl = d_base + (int64_t)l * dstride + mat * m;
-#pragma unroll
-            for (int k = 0; k < RPT; ++k) {
-                const int64_t row = tid + (int64_t)RB_THREADS * k;
-                if (row < m) w[k] ^= byte_lookup(T, dl[row]);
-            }
-            __syncthreads();
-        }
-        // ---- panel factorisation (as rref_panel_kernel) ---------------------------------------------------------------------------
+        for (int k = 0; k < RPT; ++k) w[k] = w_all[l][k], d[k] = 0, qidx[k] = 0;
         const int64_t cols_here = n - pw * 64;
         const u64 panel_cols = cols_here >= 64 ? ~0ull : ((1ull << cols_here) - 1ull);
         u64 unresolved = panel_cols;
@@ -1132,94 +1132,116 @@ __global__ __launch_bounds__(RB_THREADS) __attribute__((amdgpu_waves_per_eu(RPT 
                     pos += 1;
                 }
             __syncthreads();
+            GF2_STAMP(1);                                              // window fill
             const int nwin = total < RB_WIN ? total : RB_WIN;
             if (wave == 0)
-                window_round(lane, nwin, t, rank, m, unresolved, win_w, win_d, win_row, win_piv, fin_w, fin_d, pbit, prow_l, DP, WP, misc);
+                window_round(lane, nwin, t, rank, m, unresolved, win_w, win_d, win_row, win_piv, fin_w, fin_d, pbit, prow_l, DP, WP, misc, win_q);
             __syncthreads();
+            GF2_STAMP(2);                                              // window_round
             const int t_new = misc[0];
             const u64 newbits = ((u64)(unsigned int)misc[2] << 32) | (unsigned int)misc[1];
             const bool again = (unresolved & ~newbits) != 0 && t_new < 64 && rank + t_new < m;   // uniform
-            byte_table(tid, DP, T);
+            round_tables(tid, DP, WP, TT, TT + 2048, again);
             __syncthreads();
-            unsigned int fresh = 0;                                   // rows that became pivots in this round
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 if (slot[k] >= 0 && win_piv[slot[k]]) {               // a new pivot row: as the wavefront left it
                     w[k] = fin_w[slot[k]];
                     d[k] = fin_d[slot[k]];
+                    qidx[k] = win_q[slot[k]];
                     usedmask |= 1u << k;
                     fresh |= 1u << k;
                 } else {                                              // every other row: linear in its word
-                    d[k] ^= byte_lookup(T, w[k]);
+                    const u64 w0 = w[k];
+                    d[k] ^= byte_lookup(TT, w0);
+                    if (again) w[k] = byte_lookup(TT + 2048, w0);
                 }
-            }
-            if (again) {                                              // only then are the rows' words needed again
-                __syncthreads();
-                byte_table(tid, WP, T);
-                __syncthreads();
-#pragma unroll
-                for (int k = 0; k < RPT; ++k)
-                    if (!((fresh >> k) & 1u)) w[k] = byte_lookup(T, w[k]);
             }
             unresolved &= ~newbits;
             t = t_new;
-            __syncthreads();                                          // the window arrays and T are reused
+            __syncthreads();                                          // the window arrays and tables are reused
+            GF2_STAMP(3);                                              // round tables + every row's lookups
         }
         if (unresolved) {                                             // whatever is left has no pivot
             const int64_t fc = pw * 64 + (__ffsll((long long)unresolved) - 1);
             if (fc < first_free) first_free = fc;
         }
-#pragma unroll
-        for (int k = 0; k < RPT; ++k) {
-            const int64_t row = tid + (int64_t)RB_THREADS * k;
-            if (row < m) dout[row] = d[k];                            // (all zero when the panel found nothing)
-        }
         if (t == 0) continue;                                         // uniform
-        if (tid == 0) tj[j] = t;
+        if (tid == 0) tj[l] = t;
+        t_sum += t;
         if (wave == 0 && lane < t) {
             // global pivot lists in ascending column order (a later round may have resolved an earlier column)
             const u64 resolved = panel_cols & ~unresolved;
             const int pos = __popcll(resolved & ((1ull << pbit[lane]) - 1ull));
             pivrow[rank + pos] = prow_l[lane];
             if (pivots) pivots[rank + pos] = pw * 64 + pbit[lane];
-            prow_all[j][lane] = prow_l[lane];
-        }
-        __syncthreads();                                              // d_l of this workgroup's rows are in memory, prow_all in LDS
-        // what the sweep's earlier panels add to this panel's pivot rows: their coefficients of those rows
-        if (tid < 64 * j) {
-            const int l = tid >> 6, q = tid & 63;
-            u64 f = 0;
-            if (q < t && tj[l] > 0) f = d_base[(int64_t)l * dstride + mat * m + prow_all[j][q]];
-            fixl[j * (j - 1) / 2 + l][q] = f;
-            fixg[(j * K + l) * 64 + q] = f;
+            prow_all[l][lane] = prow_l[lane];
         }
         rank += t;
+        // ---- the new pivot rows show the other rows their later columns and their coefficients of the earlier panels ---------------
+        // pub[v]: v < K - 1 - l: column l + 1 + v;  v >= K - 1 - l: coefficients of panel v - (K - 1 - l)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+            if ((fresh >> k) & 1u) {
+#pragma unroll
+                for (int j = l + 1; j < K; ++j) pub[j - l - 1][qidx[k]] = w_all[j][k];
+#pragma unroll
+                for (int l2 = 0; l2 < l; ++l2) pub[K - 1 - l + l2][qidx[k]] = e_all[l2][k];
+            }
         __syncthreads();
+        // K - 1 byte tables at once
+        for (int idx = tid; idx < (K - 1) * 2048; idx += RB_THREADS) {
+            const int v = idx >> 11, g = (idx >> 8) & 7, vv = idx & 255;
+            u64 x = 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) x ^= pub[v][8 * g + c] & (0ull - (u64)((vv >> c) & 1));
+            TT[idx] = x;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+            const u64 dl = d[k];
+            e_all[l][k] = dl;
+#pragma unroll
+            for (int j = l + 1; j < K; ++j) w_all[j][k] ^= byte_lookup(TT + (j - l - 1) * 2048, dl);
+#pragma unroll
+            for (int l2 = 0; l2 < l; ++l2) e_all[l2][k] ^= byte_lookup(TT + (K - 1 - l + l2) * 2048, dl);
+        }
+        GF2_STAMP(4);                                                  // pivot lists, publish, K - 1 tables, lookups
     }
     __syncthreads();
-    int total_t = 0;
-#pragma unroll
-    for (int j = 0; j < K; ++j) total_t += tj[j];
     if (tid < K) st->tg[tid] = tj[tid];
     if (tid == 0) {
         st->rank = rank;
         st->skip_hi = first_free_in < pw0 * 64 ? first_free_in : pw0 * 64;     // first_free as it was BEFORE this sweep
         st->first_free = first_free;
     }
-    if (total_t == 0) return;
+    if (t_sum == 0) return;
 #pragma unroll
-    for (int k = 0; k < RPT; ++k)
-        if (((usedmask ^ usedmask0) >> k) & 1u) used[tid + RB_THREADS * k] = 1;
-    // snapshots of the pivot rows as they stand in memory (the trailing pass overwrites them)
-#pragma unroll 1
-    for (int j = 0; j < K; ++j) {
-        u64* snap = snap_base + (int64_t)j * sstride + mat * 64 * ld;
-        for (int64_t idx = tid; idx < (int64_t)tj[j] * ld; idx += RB_THREADS) {
-            const int p = (int)(idx / ld);
-            const int64_t wd = idx - (int64_t)p * ld;
-            snap[idx] = a[(int64_t)prow_all[j][p] * ld + wd];
+    for (int k = 0; k < RPT; ++k) {
+        const int64_t row = tid + (int64_t)RB_THREADS * k;
+        if (((usedmask ^ usedmask0) >> k) & 1u) used[row] = 1;
+        if (row < m) {
+#pragma unroll
+            for (int l = 0; l < K; ++l) d_base[(int64_t)l * dstride + mat * m + row] = e_all[l][k];   // (zero for a panel that found nothing)
         }
     }
+    // snapshots of the pivot rows as they stand in memory (the trailing pass overwrites them)
+#pragma unroll 1
+    for (int l = 0; l < K; ++l) {
+        u64* snap = snap_base + (int64_t)l * sstride + mat * 64 * ld;
+        const int tl = tj[l];
+        for (int64_t idx = tid; idx < (int64_t)tl * ld; idx += RB_THREADS) {
+            const int q = (int)(idx / ld);
+            const int64_t wd = idx - (int64_t)q * ld;
+            snap[idx] = a[(int64_t)prow_all[l][q] * ld + wd];
+        }
+    }
+    GF2_STAMP(5);                                                      // state, coefficients out, snapshots
+#if GF2_SWEEP_DIAG
+    if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_panel_diag[7], 1ull);
+#endif
+#undef GF2_STAMP
 }
 
 // The trailing pass of a sweep of K panels (grid: row blocks, chunks of SW_CW = 64 / K words, matrices; block 1024; 128 KiB of
@@ -1236,10 +1258,12 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
                                                   u64* base, int64_t m, int64_t ld, int64_t rows_per_wg,
                                                   SweepState* __restrict__ states, const u64* __restrict__ d_base,
                                                   int64_t dstride, const u64* __restrict__ snap_base,
-                                                  int64_t sstride, const u64* __restrict__ fix_base, int64_t pw0,
+                                                  int64_t sstride, int64_t pw0,
                                                   u64* __restrict__ colw_base, u64* out_base) {
     static_assert(K == 2 || K == 4, "two or four panels per sweep");
+#if GF2_SWEEP_DIAG
     const u64 diag_wg0 = wall_clock64();
+#endif
     constexpr int CW = 64 / K;                                          // words of a row per workgroup
     constexpr int LPR = CW / 2;                                         // lanes per row (16 bytes each)
     constexpr int RPS = 64 / LPR;                                       // rows of a wavefront's slot
@@ -1279,19 +1303,65 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
         }
         return;
     }
+    // A handful of pivots (the sweeps after the one that brought most matrices to full rank: a random 2048 x 4096 matrix lacks one
+    // to three pivots after its first 2048 columns with probability 0.71): no tables, a row takes each pivot row it has the bit for --
+    // 16 K lookups per 16-byte piece would be spent on coefficients that are zero but for a few bits.
+    int t_sum = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j) t_sum += tg[j];
+    if (t_sum <= 8) {
+        u64* P = T;                                                    // [t_sum][CW] the pivot rows' words of this chunk
+        for (int idx = tid; idx < 8 * CW; idx += TH) {
+            int p = idx / CW, j = 0;
+            const int wd = idx % CW;
+            u64 v = 0;
+            if (p < t_sum) {
+#pragma unroll
+                for (int jj = 0; jj < K - 1; ++jj)
+                    if (j == jj && p >= tg[jj]) p -= tg[jj], j = jj + 1;
+                if (wd < wc_n) v = snap_base[(int64_t)j * sstride + (mat * 64 + p) * ld + cw0 + wd];
+            }
+            P[idx] = v;
+        }
+        __syncthreads();
+        const int emit_lo = emits ? (int)(pw_next - cw0) : -1;
+        for (int64_t idx = tid; idx < (row_end - r_lo) * LPR; idx += TH) {
+            const int64_t row = r_lo + idx / LPR;
+            const int hw2 = (int)(idx % LPR) * 2;
+            if (hw2 >= wc_n) continue;
+            const bool two = hw2 + 1 < wc_n;
+            const bool dead = !moving && (cw0 + hw2 + 1) * 64 <= skip_hi && (!two || (cw0 + hw2 + 2) * 64 <= skip_hi);
+            if (dead) continue;                                        // (left of everything that can change; never a word of the next sweep)
+            u64 x0 = a[row * ld + cw0 + hw2], x1 = two ? a[row * ld + cw0 + hw2 + 1] : 0ull;
+            u64 any = 0;
+            int p0 = 0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                if (tg[j] == 0) continue;                              // uniform
+                const u64 dj = d_base[(int64_t)j * dstride + mat * m + row];
+                any |= dj;
+                for (int q = 0; q < tg[j]; ++q) {
+                    const u64 hit = 0ull - ((dj >> q) & 1ull);
+                    x0 ^= P[(p0 + q) * CW + hw2] & hit;
+                    x1 ^= P[(p0 + q) * CW + hw2 + 1] & hit;         // (hw2 + 1 < CW: CW is even)
+                }
+                p0 += tg[j];
+            }
+            if (any || moving) {
+                a_out[row * ld + cw0 + hw2] = x0;
+                if (two) a_out[row * ld + cw0 + hw2 + 1] = x1;
+            }
+            if (emit_lo >= 0 && hw2 >= emit_lo && hw2 < emit_lo + K) {
+                colw[row * K + (hw2 - emit_lo)] = x0;
+                colw[row * K + (hw2 - emit_lo) + 1] = x1;
+            }
+        }
+        if (emits && tid == 0 && rowblock == 0) states[mat].colw_pw = pw_next;
+        return;
+    }
     typedef const __attribute__((address_space(3))) u64* lds_u64_ptr;
     // byte offset of panel j's table (see above)
     auto tbase = [](int j) -> unsigned int { return K == 2 ? (unsigned int)j * 65536u : (unsigned int)(j >> 1) * 65536u + (unsigned int)(j & 1) * 128u; };
-    // 16 lookups of one table from byte `at` (table base + word offset) on: entry (g, nibble g of d) at (g*16 + nibble)*256
-    auto lookup16 = [](unsigned int at, u64 d) -> u64 {
-        u64 x = 0;
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const unsigned int nib = (unsigned int)(d >> (4 * g)) & 15u;
-            x ^= *(lds_u64_ptr)(uintptr_t)(at + nib * 256u + (unsigned int)g * 4096u);
-        }
-        return x;
-    };
     // the 16 XOR combinations of a group's four rows (entries 1, 2, 4, 8 are the single rows): a lane takes (group, word) and the
     // entries with bit 3 clear or set -- 32 * CW lanes
     auto combos = [&](int j) {
@@ -1362,38 +1432,35 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
     };
     Two s0, s1;
     const int64_t rb0 = r_lo;
+#if GF2_SWEEP_DIAG
     const u64 diag_c0 = clock64(), diag_w0 = wall_clock64();
+#endif
     load2(rb0, s0);                                                    // on their way while the tables are built
-    // ---- tables: S'_j = S_j ^ sum_{l<j} fix_{j,l} . S'_l, panel after panel -----------------------------------------------------------
+    // ---- tables: the K panels' pivot rows as the snapshot holds them (the coefficients are folded onto those: nothing to fix) -----
     {
-        u64 sv[K][ITER], fx[K][K][ITER];
+        u64 sv[K][ITER];
 #pragma unroll
         for (int j = 0; j < K; ++j)
 #pragma unroll
-            for (int it = 0; it < ITER; ++it) {                        // everything the build reads from memory, now
+            for (int it = 0; it < ITER; ++it) {
                 const int idx = tid + TH * it, p = idx / CW, wd = idx & (CW - 1);
                 sv[j][it] = (p < tg[j] && wd < wc_n) ? snap_base[(int64_t)j * sstride + (mat * 64 + p) * ld + cw0 + wd] : 0ull;
-#pragma unroll
-                for (int l = 0; l < j; ++l)
-                    fx[j][l][it] = (p < tg[j] && tg[l] > 0) ? fix_base[((mat * K + j) * K + l) * 64 + p] : 0ull;
             }
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
+        for (int j = 0; j < K; ++j)
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
                 const int idx = tid + TH * it, p = idx / CW, wd = idx & (CW - 1);
-                u64 x = sv[j][it];
-#pragma unroll
-                for (int l = 0; l < j; ++l)
-                    if (tg[l] > 0) x ^= lookup16(tbase(l) + (unsigned int)wd * 8u, fx[j][l][it]);     // uniform condition
-                T[tbase(j) / 8 + ((p >> 2) * 16 + (1 << (p & 3))) * 32 + wd] = x;
+                T[tbase(j) / 8 + ((p >> 2) * 16 + (1 << (p & 3))) * 32 + wd] = sv[j][it];
             }
-            __syncthreads();
-            combos(j);
-            __syncthreads();
-        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < K; ++j) combos(j);
+        __syncthreads();
     }
+#if GF2_SWEEP_DIAG
     const u64 diag_c1 = clock64(), diag_w1 = wall_clock64();
+#endif
     auto work2 = [&](int64_t rb, Two& s) {
         unsigned int pf[K / 2][2], ps[K / 2][2];
 #pragma unroll
@@ -1431,6 +1498,7 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
         if (rb + STEP < row_end) work2(rb + STEP, s1);                 // uniform
     }
     if (emits && tid == 0 && rowblock == 0) states[mat].colw_pw = pw_next;
+#if GF2_SWEEP_DIAG
     if (tid == 0) {
         const u64 diag_c2 = clock64(), diag_w2 = wall_clock64();
         atomicAdd(&g_sweep_diag[0], diag_c1 - diag_c0);
@@ -1451,6 +1519,7 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
             }
         }
     }
+#endif
 }
 
 // (A persistent form -- one workgroup per CU taking units off a counter -- was built and measured: 220 - 279 us per sweep of
@@ -1461,12 +1530,12 @@ template <int K, int TH>
 __global__ __launch_bounds__(TH) void rref_sweep_update_kernel(u64* base, int64_t m, int64_t ld, int64_t rows_per_wg,
                                                                SweepState* __restrict__ states, const u64* __restrict__ d_base,
                                                                int64_t dstride, const u64* __restrict__ snap_base,
-                                                               int64_t sstride, const u64* __restrict__ fix_base, int64_t pw0,
+                                                               int64_t sstride, int64_t pw0,
                                                                u64* __restrict__ colw_base, u64* out_base) {
     extern __shared__ __attribute__((aligned(16))) u64 T[];           // (the lookups address the tables from LDS byte 0: the kernel's only LDS)
     const unsigned int unit = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     sweep_update_unit<K, TH>(T, blockIdx.z, blockIdx.y, blockIdx.x, unit, base, m, ld, rows_per_wg, states, d_base, dstride, snap_base, sstride,
-                             fix_base, pw0, colw_base, out_base);
+                             pw0, colw_base, out_base);
 }
 
 // ---- blocked normalisation (css_code.py:809-836), bit-exact ------------------------------------------------------------
@@ -2157,24 +2226,26 @@ static int launch_eliminate(gf2_ctx* ctx, int mode, u64* a_dev, int64_t batch, i
     return GF2_OK;
 }
 
-// Blocked path for matrices of at most 8192 rows, K panels per sweep (rref_sweep_panel_kernel / rref_sweep_update_kernel).  A batch
-// is cut into up to four GROUPS of matrices, each on a stream of its own: the panel kernel is one workgroup per matrix and mostly
-// one wavefront of it at work (latency), the trailing pass is the whole chip streaming (bandwidth), so the panels of one group run
-// under the passes of the others -- the groups are independent problems, no events between them but the start and the end.
-// Workspace: a copy of the batch (the first pass moves the batch there, the row gather writes it back in place), pivot-row lists,
-// states, used flags, and per panel of a sweep the coefficients d and the pivot-row snapshots, `fix`, and the side buffer of the
-// next sweep's column words.
-template <int K, int TH>
+// Blocked path for matrices of at most 4096 rows, K panels per sweep (rref_sweep_panel_kernel / rref_sweep_update_kernel), all on
+// the context's stream.  Workspace: a copy of the batch (the first pass moves the batch there, the row gather writes it back in
+// place), pivot-row lists, states, used flags, per panel of a sweep the folded coefficients and the pivot-row snapshots, and the
+// side buffer of the next sweep's column words.
+// (Cutting a batch into up to four groups of matrices on streams of their own, so that the panels of one group -- one workgroup per
+// matrix, mostly one wavefront of it at work -- run under the trailing passes of the others, was built and measured, also with the
+// panel kernel held to 64 registers and the pass at 512 threads so that one of each fits a CU: 3.0 - 4.3 ms against 3.1 for 256
+// matrices of 2048 x 4096.  The pass is bound by the LDS of its CU and a panel workgroup next to it loses more than the overlap
+// gives; profiles/r05_groups.md.)
+template <int K>
 static int launch_rref_sweeps(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld, int64_t* pivots_dev,
                               int64_t cap, int64_t* rank_dev) {
-    constexpr int CW = 64 / K;
+    constexpr int CW = 64 / K, TH = RB_THREADS;
     const int rpt = (int)gf2_cdiv(m, RB_THREADS);
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t abytes = al((size_t)batch * m * ld * 8), pbytes = al((size_t)batch * cap * 4);
     const size_t sbytes = al((size_t)batch * sizeof(SweepState)), ubytes = al((size_t)batch * m);
     const size_t dbytes = al((size_t)batch * m * 8), nbytes = al((size_t)batch * 64 * ld * 8);
-    const size_t fbytes = al((size_t)batch * K * K * 64 * 8), cbytes = al((size_t)batch * m * K * 8);
-    GF2_TRY(gf2_ws_reserve(ctx, 1, abytes + pbytes + sbytes + ubytes + K * (dbytes + nbytes) + fbytes + cbytes));
+    const size_t cbytes = al((size_t)batch * m * K * 8);
+    GF2_TRY(gf2_ws_reserve(ctx, 1, abytes + pbytes + sbytes + ubytes + K * (dbytes + nbytes) + cbytes));
     char* q = (char*)ctx->ws[1];
     u64* tmp = (u64*)q; q += abytes;
     int32_t* pivrow = (int32_t*)q; q += pbytes;
@@ -2182,106 +2253,81 @@ static int launch_rref_sweeps(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m
     unsigned char* used = (unsigned char*)q; q += ubytes;
     u64* dco = (u64*)q; q += K * dbytes;
     u64* snap = (u64*)q; q += K * nbytes;
-    u64* fix = (u64*)q; q += fbytes;
     u64* colw = (u64*)q;
     const int64_t dstride = (int64_t)(dbytes / 8), sstride = (int64_t)(nbytes / 8);
+    hipStream_t on = ctx->stream;
     GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
-    GF2_HIP(hipMemsetAsync(states, 0, sbytes + ubytes, ctx->stream));          // rank = 0, used = 0 ...
-    hipLaunchKernelGGL(sweep_state_init_kernel, dim3((unsigned)gf2_cdiv(batch, 256)), dim3(256), 0, ctx->stream, states, batch, n);
-    if (!ctx->lds_optin[(K == 2 ? 5 : 7) + (TH == 512)]) {
+    GF2_HIP(hipMemsetAsync(states, 0, sbytes + ubytes, on));                  // rank = 0, used = 0 ...
+    hipLaunchKernelGGL(sweep_state_init_kernel, dim3((unsigned)gf2_cdiv(batch, 256)), dim3(256), 0, on, states, batch, n);
+    if (!ctx->lds_optin[K == 2 ? 5 : 6]) {
         GF2_HIP(hipFuncSetAttribute((const void*)rref_sweep_update_kernel<K, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        ctx->lds_optin[(K == 2 ? 5 : 7) + (TH == 512)] = true;
-    }
-    // groups of matrices, each on its own stream
-    hipStream_t streams[4] = {ctx->stream, ctx->side[0], ctx->side[1], ctx->hi};
-    int groups = batch >= 16 ? 4 : (batch >= 2 ? 2 : 1);
-    if (ctx->opt[GF2_OPT_RREF_GROUPS] >= 1) groups = (int)ctx->opt[GF2_OPT_RREF_GROUPS];
-    if (groups > 4) groups = 4;
-    if (groups > batch) groups = (int)batch;
-    for (int g = 1; g < groups; ++g)
-        if (!streams[g]) groups = g;
-    int64_t g_lo[5];
-    for (int g = 0; g <= groups; ++g) g_lo[g] = batch * g / groups;
-    if (groups > 1) {
-        GF2_HIP(hipEventRecord(ctx->side_ev[0], ctx->stream));
-        for (int g = 1; g < groups; ++g) GF2_HIP(hipStreamWaitEvent(streams[g], ctx->side_ev[0], 0));
+        ctx->lds_optin[K == 2 ? 5 : 6] = true;
     }
     const int64_t panels = gf2_words(n) < ld ? gf2_words(n) : ld;
     const int64_t chunks = gf2_cdiv(ld, CW);
     const int64_t sweeps = gf2_cdiv(panels, K);
-    bool moved = false;                                                // the first pass has taken the batch to the workspace copy
+    // rows per update workgroup: a workgroup owns its CU (128 KiB of tables) and builds the tables before it moves a row -- as long
+    // as moving 300 rows -- so: one round of the chip if the batch is small, whole matrices (2048 rows or more) if it is large
+    int64_t rows_wg = gf2_cdiv(gf2_cdiv(m * chunks * batch, (int64_t)ctx->num_cus), 256) * 256;
+    if (rows_wg > 256) rows_wg = gf2_cdiv(m, gf2_cdiv(m, rows_wg));
+    if (rows_wg < 256) rows_wg = 256;
+    if (ctx->opt[GF2_OPT_RREF_ROWS_WG] >= 64) rows_wg = ctx->opt[GF2_OPT_RREF_ROWS_WG];
+    // Every row may have its pivot once m columns have been seen, and a random matrix is done right there or a few columns later:
+    // from then on the ranks are read back after every sweep for two sweeps, then after every other one (a stream synchronisation,
+    // but it saves the launches of the sweeps that would find nothing left to do -- half of them for a 2048 x 4096 matrix).
     auto all_done = [&](int64_t pw_last, bool* done) -> int {
         *done = false;
-        if (!((pw_last + 1) * 64 >= m && pw_last + 1 < panels && ((pw_last + 1) * 64 - m) % 512 < 64 * K)) return GF2_OK;
-        for (int g = 1; g < groups; ++g) {
-            GF2_HIP(hipEventRecord(ctx->side_ev[g], streams[g]));
-            GF2_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_ev[g], 0));
-        }
+        const int64_t past = (pw_last + 1) * 64 - m;
+        if (!(past >= 0 && pw_last + 1 < panels && (past < 128 * K || past % (128 * K) < 64 * K))) return GF2_OK;
         std::vector<SweepState> now((size_t)batch);
-        GF2_HIP(hipMemcpyAsync(now.data(), states, (size_t)batch * sizeof(SweepState), hipMemcpyDeviceToHost, ctx->stream));
-        GF2_TRY(gf2_stream_wait(ctx->stream));
+        GF2_HIP(hipMemcpyAsync(now.data(), states, (size_t)batch * sizeof(SweepState), hipMemcpyDeviceToHost, on));
+        GF2_TRY(gf2_stream_wait(on));
         *done = true;
         for (const auto& st : now) *done = *done && st.rank >= m;
         return GF2_OK;
     };
     for (int64_t s = 0; s < sweeps; ++s) {
         const int64_t pw0 = s * K;
-        u64* work = moved ? tmp : a_dev;
-        for (int g = 0; g < groups; ++g) {
-            const int64_t b0 = g_lo[g], nb = g_lo[g + 1] - b0;
-            if (nb == 0) continue;
-            hipStream_t on = streams[g];
-#define GF2_SP_LAUNCH(RPT)                                                                                                       \
-    hipLaunchKernelGGL((rref_sweep_panel_kernel<K, RPT>), dim3((unsigned)nb), dim3(RB_THREADS), 0, on, (const u64*)(work + b0 * m * ld), m, n, \
-                       ld, pw0, pivots_dev ? pivots_dev + b0 * cap : nullptr, cap, pivrow + b0 * cap, states + b0, used + b0 * m,  \
-                       (const u64*)(colw + b0 * m * K), dco + b0 * m, dstride, snap + b0 * 64 * ld, sstride, fix + b0 * K * K * 64)
-            if (rpt <= 1)
-                GF2_SP_LAUNCH(1);
-            else if (rpt <= 2)
-                GF2_SP_LAUNCH(2);
-            else if (rpt <= 4)
-                GF2_SP_LAUNCH(4);
-            else
-                GF2_SP_LAUNCH(8);
+        u64* work = s == 0 ? a_dev : tmp;                              // the first pass takes the batch to the workspace copy
+#define GF2_SP_LAUNCH(RPT)                                                                                                      \
+    hipLaunchKernelGGL((rref_sweep_panel_kernel<K, RPT>), dim3((unsigned)batch), dim3(RB_THREADS), 0, on, (const u64*)work, m, n, ld, pw0, \
+                       pivots_dev, cap, pivrow, states, used, (const u64*)colw, dco, dstride, snap, sstride)
+        if (rpt <= 1)
+            GF2_SP_LAUNCH(1);
+        else if (rpt <= 2)
+            GF2_SP_LAUNCH(2);
+        else
+            GF2_SP_LAUNCH(4);
 #undef GF2_SP_LAUNCH
-            // rows per update workgroup: a lone matrix wants many workgroups, a large batch wants the table build amortised (a
-            // workgroup owns its CU -- 128 KiB of tables): about two workgroups per CU over the launch, no fewer than 256 rows each
-            int64_t rows_wg = gf2_cdiv(gf2_cdiv(m * chunks * nb, 2 * (int64_t)ctx->num_cus), 256) * 256;
-            if (rows_wg > 256) rows_wg = gf2_cdiv(m, gf2_cdiv(m, rows_wg));
-            if (rows_wg < 256) rows_wg = 256;
-            if (ctx->opt[GF2_OPT_RREF_ROWS_WG] >= 64) rows_wg = ctx->opt[GF2_OPT_RREF_ROWS_WG];
-            const dim3 grid((unsigned)gf2_cdiv(m, rows_wg), (unsigned)chunks, (unsigned)nb);
-            hipLaunchKernelGGL((rref_sweep_update_kernel<K, TH>), grid, dim3(TH), 128 * 1024, on, work + b0 * m * ld, m, ld, rows_wg,
-                               states + b0, (const u64*)(dco + b0 * m), dstride, (const u64*)(snap + b0 * 64 * ld), sstride,
-                               (const u64*)(fix + b0 * K * K * 64), pw0, colw + b0 * m * K, (moved ? tmp : tmp) + b0 * m * ld);
-        }
-        moved = true;
+        const dim3 grid((unsigned)gf2_cdiv(m, rows_wg), (unsigned)chunks, (unsigned)batch);
+        hipLaunchKernelGGL((rref_sweep_update_kernel<K, TH>), grid, dim3(TH), 128 * 1024, on, work, m, ld, rows_wg, states, (const u64*)dco,
+                           dstride, (const u64*)snap, sstride, pw0, colw, tmp);
         GF2_HIP(hipGetLastError());
         bool done;
         GF2_TRY(all_done(pw0 + K - 1, &done));
         if (done) break;
     }
-    for (int g = 0; g < groups; ++g) {
-        const int64_t b0 = g_lo[g], nb = g_lo[g + 1] - b0;
-        if (nb == 0) continue;
-        hipLaunchKernelGGL(gather_rows_kernel<SweepState>, dim3((unsigned)gf2_cdiv(m, GATHER_ROWS), (unsigned)nb), dim3(256), 0, streams[g],
-                           (const u64*)(tmp + b0 * m * ld), a_dev + b0 * m * ld, (const int32_t*)(pivrow + b0 * cap),
-                           (const SweepState*)(states + b0), rank_dev + b0, m, ld, cap);
-        if (g > 0) {
-            GF2_HIP(hipEventRecord(ctx->side_ev[g], streams[g]));
-            GF2_HIP(hipStreamWaitEvent(ctx->stream, ctx->side_ev[g], 0));
-        }
-    }
+    hipLaunchKernelGGL(gather_rows_kernel<SweepState>, dim3((unsigned)gf2_cdiv(m, GATHER_ROWS), (unsigned)batch), dim3(256), 0, on,
+                       (const u64*)tmp, a_dev, (const int32_t*)pivrow, (const SweepState*)states, rank_dev, m, ld, cap);
     GF2_HIP(hipGetLastError());
     GF2_TRY(gf2_prof_end(ctx));
+#if GF2_SWEEP_DIAG
     if (getenv("GF2_RREF_DIAG")) {
         u64 dg[8];
-        GF2_HIP(hipStreamSynchronize(ctx->stream));
+        GF2_HIP(hipStreamSynchronize(on));
         GF2_HIP(hipMemcpyFromSymbol(dg, HIP_SYMBOL(g_sweep_diag), sizeof(dg)));
         const double n_wg = (double)(dg[4] ? dg[4] : 1);
-        fprintf(stderr, "sweep pass K=%d TH=%d: %.0f workgroups; table build %.0f cycles / %.2f us (%.2f GHz); rows %.0f cycles / %.2f us (%.2f GHz)\n",
-                K, TH, n_wg, dg[0] / n_wg, dg[1] / n_wg / 100.0, dg[1] ? dg[0] / (dg[1] * 10.0) : 0.0, dg[2] / n_wg, dg[3] / n_wg / 100.0,
+        fprintf(stderr, "sweep pass K=%d: %.0f workgroups; table build %.0f cycles / %.2f us (%.2f GHz); rows %.0f cycles / %.2f us (%.2f GHz), wavefront 0\n",
+                K, n_wg, dg[0] / n_wg, dg[1] / n_wg / 100.0, dg[1] ? dg[0] / (dg[1] * 10.0) : 0.0, dg[2] / n_wg, dg[3] / n_wg / 100.0,
                 dg[3] ? dg[2] / (dg[3] * 10.0) : 0.0);
+        u64 pd[8];
+        GF2_HIP(hipMemcpyFromSymbol(pd, HIP_SYMBOL(g_panel_diag), sizeof(pd)));
+        const double np = (double)(pd[7] ? pd[7] : 1);
+        fprintf(stderr, "sweep panel K=%d: %.0f launches; us per launch: prologue %.2f, window fill %.2f, window_round %.2f, round tables %.2f, "
+                "publish + later columns %.2f, epilogue %.2f\n", K, np, pd[0] / np / 100, pd[1] / np / 100, pd[2] / np / 100, pd[3] / np / 100,
+                pd[4] / np / 100, pd[5] / np / 100);
+        memset(pd, 0, sizeof(pd));
+        GF2_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_panel_diag), pd, sizeof(pd)));
         if (getenv("GF2_RREF_DIAG_WG")) {
             std::vector<u64> wg(4 * 4096);
             GF2_HIP(hipMemcpyFromSymbol(wg.data(), HIP_SYMBOL(g_sweep_wg), wg.size() * 8));
@@ -2296,6 +2342,7 @@ static int launch_rref_sweeps(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m
         dg[7] = getenv("GF2_RREF_DIAG_SWEEP") ? (u64)atoll(getenv("GF2_RREF_DIAG_SWEEP")) : 8;
         GF2_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_diag), dg, sizeof(dg)));
     }
+#endif
     return GF2_OK;
 }
 
@@ -2308,13 +2355,17 @@ extern "C" {
 static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld,
                                int64_t* pivots_dev, int64_t cap, int64_t* rank_dev) {
     const int rpt = (int)gf2_cdiv(m, RB_THREADS);
-    if (rpt <= 8 && ctx->opt[GF2_OPT_RREF_SWEEP_K] != 0) {             // K panels per sweep (round 5); 0: the pair kernels below
-        const bool half = ctx->opt[GF2_OPT_RREF_PASS_THREADS] == 512;
-        if (ctx->opt[GF2_OPT_RREF_SWEEP_K] == 2)
-            return half ? launch_rref_sweeps<2, 512>(ctx, a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev)
-                        : launch_rref_sweeps<2, 1024>(ctx, a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
-        return half ? launch_rref_sweeps<4, 512>(ctx, a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev)
-                    : launch_rref_sweeps<4, 1024>(ctx, a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
+    // up to 4096 rows: K panels per sweep (round 5).  Eight rows per lane (up to 8192 rows): a lane's K column words and coefficients
+    // of eight rows do not fit its registers -- 15 ms against 7.8 for four 8192 x 16384 matrices -- so those keep the pair kernels below.
+    if (rpt <= 4 && ctx->opt[GF2_OPT_RREF_SWEEP_K] != 0) {
+        // Four panels per sweep where the batch streams from HBM (half the trips: 2.67 against 2.71 ms and half the traffic for 256
+        // matrices of 2048 x 4096) and a lane holds at most two rows (with four, the four panels' words and coefficients spill:
+        // 2.38 against 2.14 ms for eight matrices of 4096 x 8192); two panels per sweep otherwise (one matrix of 2048 x 4096: 0.78
+        // against 0.80 ms) -- profiles/r05_rref_dev.log
+        int64_t k = ctx->opt[GF2_OPT_RREF_SWEEP_K];
+        if (k < 0) k = (rpt <= 2 && batch * m * ld * 8 >= (64ll << 20)) ? 4 : 2;
+        if (k == 2) return launch_rref_sweeps<2>(ctx, a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
+        return launch_rref_sweeps<4>(ctx, a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
     }
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t abytes = al((size_t)batch * m * ld * 8), pbytes = al((size_t)batch * cap * 4);

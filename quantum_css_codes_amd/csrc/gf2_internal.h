@@ -39,11 +39,10 @@ void gf2_set_error(const char* fmt, ...);
 // ---- internal tunables ---------------------------------------------------------------------------
 // Set through gf2_ctx_set_option like the public ones (ids continue the public list); used by the A/B scripts under profiles/ and
 // by tests that force a route, not part of the ABI a caller of bin_matrix / CSSCode needs (value < 0 = default).
-#define GF2_OPT_RREF_GROUPS    (GF2_OPT_COUNT + 0)   // blocked RREF of a batch: groups of matrices on streams of their own, 1..4
+#define GF2_OPT_RREF_RESERVED0 (GF2_OPT_COUNT + 0)   // (was: groups of matrices on streams of their own -- measured, not kept)
 #define GF2_OPT_RREF_ROWS_WG   (GF2_OPT_COUNT + 1)   // blocked RREF: rows per workgroup of the trailing pass (>= 64)
-#define GF2_OPT_RREF_SWEEP_K   (GF2_OPT_COUNT + 2)   // blocked RREF up to 8192 rows: panels per sweep, 4 (default) or 2; 0 = the round-4 pair kernels
-#define GF2_OPT_RREF_PASS_THREADS (GF2_OPT_COUNT + 3) // blocked RREF, sweeps: threads of a trailing-pass workgroup, 1024 or 512
-#define GF2_OPT_COUNT_ALL      (GF2_OPT_COUNT + 4)
+#define GF2_OPT_RREF_SWEEP_K   (GF2_OPT_COUNT + 2)   // blocked RREF up to 4096 rows: panels per sweep, 4 (default) or 2; 0 = the round-4 pair kernels
+#define GF2_OPT_COUNT_ALL      (GF2_OPT_COUNT + 3)
 
 // ---- context -------------------------------------------------------------------------------------
 struct gf2_ctx {
@@ -68,7 +67,7 @@ struct gf2_ctx {
     size_t ws_bytes[4];
     // large dynamic-LDS opt-in (hipFuncSetAttribute) done for this context's device: [0] syndrome_tiled_kernel,
     // [1] (unused), [2] slab_gather_kernel, [3] conjugate_kernel, [4] rref_update_pair_kernel
-    bool lds_optin[9];            // ... [5] .. [8] rref_sweep_update_kernel<2 | 4, 1024 | 512>
+    bool lds_optin[7];            // ... [5], [6] rref_sweep_update_kernel<2>, <4>
     // routing flags (GF2_F_*) and tunables (GF2_OPT_*, -1 = default): gf2_ctx_set_flags / gf2_ctx_set_option
     uint32_t flags;
     int64_t opt[GF2_OPT_COUNT_ALL];
