@@ -88,26 +88,45 @@ def build_code():
     return code, c1, c2
 
 
-def cpu_baseline(code, seconds_target=20.0, sample=2048):
-    """Reference-style CPU path: np.mod(np.matmul(H, e), 2) per error vector on dense int64 arrays
-    (css_code.py:728), both Pauli components, single thread.  Bounded sample, extrapolated rate."""
+def cpu_baseline(code, c1p, c2p, seconds_numpy=12.0, sample=256, seconds_c=8.0):
+    """Two CPU legs on this host, both on a bounded sample of the same workload:
+    value / cores / kind / sample: the reference-style path, np.mod(np.matmul(H, e), 2) per error vector on dense int64 arrays
+        (css_code.py:728), both Pauli components, one core (NumPy's integer matmul is not threaded) -- 256 vectors;
+    packed_c: the same products on packed 64-bit words (oracle/gf2_oracle.c: AND, XOR, popcount parity), OpenMP over the samples
+        on every core the host gives -- the stronger baseline SURVEY.md 8d offers."""
     from oracle import cpu_ref, c_oracle
     h1 = np.array(code.parity_check_c1, dtype='int')
     h2 = np.array(code.parity_check_c2, dtype='int')
-    ex, ez = c_oracle.sample_errors(N_QUBITS, SEED, 0, sample, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3)
-    ex, ez = c_oracle.unpack_rows(ex, N_QUBITS), c_oracle.unpack_rows(ez, N_QUBITS)
+    exp, ezp = c_oracle.sample_errors(N_QUBITS, SEED, 0, sample, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3)
+    ex, ez = c_oracle.unpack_rows(exp, N_QUBITS), c_oracle.unpack_rows(ezp, N_QUBITS)
     done, t0 = 0, time.perf_counter()
     while done < sample:
         cpu_ref.syndrome_product(h1, ez[done])
         cpu_ref.syndrome_product(h2, ex[done])
         done += 1
-        if time.perf_counter() - t0 > seconds_target and done >= 16:
+        if time.perf_counter() - t0 > seconds_numpy and done >= 16:
             break
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "syndromes/s", "cores": 1, "kind": "port",
-            "sample": "%d errors of the same n=4096 code, np.mod(np.matmul(H,e),2) for H1.e_z and H2.e_x "
-                      "(oracle/cpu_ref.py restating css_code.py:728), %.1f s, host has %d cores"
-                      % (done, dt, os.cpu_count())}
+    out = {"value": done / dt, "unit": "syndromes/s", "cores": 1, "kind": "port",
+           "sample": "%d errors of the same n=4096 code, np.mod(np.matmul(H,e),2) for H1.e_z and H2.e_x "
+                     "(oracle/cpu_ref.py restating css_code.py:728), %.1f s, host has %d cores"
+                     % (done, dt, os.cpu_count())}
+    # packed words, all cores
+    count = 1 << 17
+    bx, bz = c_oracle.sample_errors(N_QUBITS, SEED, 0, count, P_TOTAL / 3, P_TOTAL / 3, P_TOTAL / 3)
+    c_oracle.syndrome_batch(c1p, R1, N_QUBITS, bz[:4096], 4096)           # threads started, pages touched
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        c_oracle.syndrome_batch(c1p, R1, N_QUBITS, bz, count)
+        c_oracle.syndrome_batch(c2p, R2, N_QUBITS, bx, count)
+        reps += 1
+        if time.perf_counter() - t0 > seconds_c or reps >= 64:
+            break
+    dt = time.perf_counter() - t0
+    out["packed_c"] = {"value": reps * count / dt, "unit": "syndromes/s", "cores": c_oracle.max_threads(), "kind": "port",
+                       "sample": "%d x %d errors of the same code, packed-word AND / XOR / popcount products for H1.e_z and H2.e_x "
+                                 "(oracle/gf2_oracle.c orc_syndrome_batch, OpenMP over the samples), %.1f s" % (reps, count, dt)}
+    return out
 
 
 class Path(object):
@@ -725,6 +744,20 @@ def main():
         hist_ms += c.profile_get(_native.K_HIST)[0]
         c.profile(False)
 
+    # every rank's shard and its own roofline figure (both components' algorithmic bytes of its steps over its stream time), for the
+    # N > 1 line: the driver computes scaling from `value`, this shows which GPU held it back
+    shards = None
+    if world > 1:
+        dev = "cuda" if args.dist_backend == "nccl" else "cpu"
+        mine = torch.tensor([float(first), float(batch), float(gpu_ms)], dtype=torch.float64, device=dev)
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        shards = []
+        for r, v in enumerate(gathered):
+            f_r, n_r, ms_r = (float(x) for x in v.tolist())
+            gbs = 2.0 * n_r * path.alg_bytes_per_sample * args.steps / (ms_r * 1e-3) / 1e9
+            shards.append({"rank": r, "first": int(f_r), "count": int(n_r), "stream_ms": ms_r,
+                           "roofline": {"achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}})
     if rank == 0:
         roof = (roofline_of_steps(path, gpu_ms / 1e3, args.steps, syn_ms / 1e3 / max(1, syn_n), syn_n)
                 if path.ctx2 is not None else roofline(path, syn_ms / 1e3 / max(1, syn_n), syn_n))
@@ -757,7 +790,14 @@ def main():
                                       + ("" if world == 1 else " (gf2_hist_allreduce over librccl)" if comm is not None else
                                          " (torch.distributed, %s)%s" % (args.dist_backend, comm_note))},
             "roofline": roof,
+            "collective": None if world == 1 else
+                          {"call": "gf2_hist_allreduce (C ABI, librccl)" if comm is not None else "torch.distributed.all_reduce",
+                           "backend": "rccl" if (comm is not None or args.dist_backend == "nccl") else args.dist_backend,
+                           "rccl_ranks": world if (comm is not None or args.dist_backend == "nccl") else 0,
+                           "bins": R1 + 1 + R2 + 1, "dtype": "uint64 sum"},
+            "shards": shards,
             "checks": {"histogram_total": int(hist_z.sum()), "expected_total": int(total),
+                       "histogram_sha256": hashlib.sha256(hist_z.tobytes() + hist_x.tobytes()).hexdigest(),
                        "oracle_prefix": "512 samples of this rank's batch through the timed path == oracle/gf2_oracle.c",
                        "inputs": "H1, H2, both standard forms and logical operators == digests of the reference's own "
                                  "constructor (tests/golden/config4_golden.npz)"},
@@ -765,7 +805,7 @@ def main():
                           "stream_total": gpu_ms},
         }
         if world == 1 and not args.no_cpu_baseline:               # timed on rank 0 at N = 1 only
-            out["cpu_baseline"] = cpu_baseline(code)
+            out["cpu_baseline"] = cpu_baseline(code, h1, h2)          # (h1, h2: the packed standard forms)
         if world == 1 and not args.no_secondary:
             single_z = (hist_z // np.uint64(args.steps)).astype(np.uint64)      # same batch every step
             # end to end: nothing resident, gf2_mc_run draws the errors itself (record sampler, then gather / combine / misfits per

@@ -26,6 +26,7 @@ def lib():
             build()
         _lib = ctypes.CDLL(_SO)
         sigs = {
+            "orc_max_threads": [],
             "orc_rref": [_p, _i64, _i64, _i64, _p, _p],
             "orc_swap_columns": [_p, _i64, _i64, _i64, _i64],
             "orc_normalize": [_p, _i64, _i64, _i64, _i64, _p, _p],
@@ -94,6 +95,11 @@ def nullspace(packed, m, n):
     rows = _i64(0)
     lib().orc_nullspace(_ptr(a), m, n, a.shape[1], _ptr(out), out.shape[1], ctypes.byref(rows))
     return out[:rows.value]
+
+
+def max_threads():
+    """OpenMP threads the batch loops of the C restatement run on."""
+    return int(lib().orc_max_threads())
 
 
 def syndrome_batch(h, r, n, e, batch):

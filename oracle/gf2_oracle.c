@@ -16,6 +16,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 typedef uint64_t u64;
 
@@ -113,6 +116,15 @@ int orc_nullspace(const u64* a, int64_t m, int64_t n, int64_t ld, u64* out, int6
     free(piv);
     free(piv_row);
     return 0;
+}
+
+/* Threads the batch loops below run on (bench.py's cpu_baseline reports it next to the rate). */
+int orc_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }
 
 /* css_code.py:728 for a batch, sample-major: s[b] bit i = parity(h[i] & e[b]). */

@@ -1709,6 +1709,50 @@ def test_bench_under_torchrun_two_ranks_share_the_gpu(tmp_path):
     assert out["checks"]["histogram_total"] == 2 * (2 << 17)   # both shards' samples arrived in the all-reduced histogram
 
 
+def test_bench_strong_scaling_line_four_ranks_share_the_gpu_same_histogram_as_one_rank(tmp_path):
+    # BASELINE.json configs[4] as the driver will launch it on the 8-GPU node (--total-samples 100000000: the global stream of 10^8
+    # samples cut into contiguous shards, one all-reduce), rehearsed with as many ranks as this pool lets one GPU carry (6 processes
+    # on the card: this test runner, the launcher and 4 ranks; the 8-rank world is rehearsed on the CPU by
+    # tests/test_sharding_gloo.py::test_eight_rank_histogram_allreduce): gloo, every rank on GPU 0.  The all-reduced histogram of
+    # the 4 ranks must be the 1-rank histogram bin for bin (key convention
+    # css_code.py:729, X <-> H2 / Z <-> H1 css_code.py:457-470), one JSON line from rank 0, the shards listed and contiguous.
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GF2_DEVICE="0")
+    tail = ["--dist-backend", "gloo", "--steps", "1", "--warmup", "0", "--total-samples", "100000000", "--no-cpu-baseline",
+            "--no-secondary", "--no-settle"]
+
+    def run(ranks):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(ranks)] + tail
+        if ranks == 1:
+            cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + tail
+        done = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
+        assert done.returncode == 0, done.stderr[-2000:]
+        lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1                                 # rank 0 prints the one line
+        return json.loads(lines[0])
+
+    one, six = run(1), run(4)
+    for out, ranks in ((one, 1), (six, 4)):
+        assert out["n_gpus"] == ranks and out["scaling"] == "strong" and out["config"]["global_samples_per_step"] == 10**8
+        assert out["checks"]["histogram_total"] == 10**8 == out["checks"]["expected_total"]
+    assert six["checks"]["histogram_sha256"] == one["checks"]["histogram_sha256"]
+    assert one["shards"] is None and one["collective"] is None
+    assert six["collective"]["rccl_ranks"] == 0 and six["collective"]["backend"] == "gloo"
+    pos = 0
+    for r, sh in enumerate(six["shards"]):
+        assert sh["rank"] == r and sh["first"] == pos and sh["count"] == 25000000 and sh["roofline"]["frac"] > 0
+        pos += sh["count"]
+    assert pos == 10**8
+
+
 def test_context_options_are_validated(ctx):
     for option, bad in ((_native.OPT_SLAB_PASS_LOG2, 11), (_native.OPT_SLAB_PASS_LOG2, 25), (_native.OPT_COMBINE_BLOCKS, 0),
                         (_native.OPT_MC_CHUNK_LOG2, 15), (_native.OPT_MC_CHUNK_LOG2, 23), (_native.OPT_COMBINE_THREADS, 96),

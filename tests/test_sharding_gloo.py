@@ -134,3 +134,22 @@ def test_two_rank_histogram_allreduce(tmp_path):
     whole_dec = _oracle_decode_local(_steane_oracle_code(), 30001, 0.05, 0.02, 0.03, seed=4, first_sample=7)
     for r in (r0, r1):
         assert list(r["decode"]) == [whole_dec[f] for f in DECODE_FIELDS]
+
+
+def test_eight_rank_histogram_allreduce(tmp_path):
+    # the world size of the target node (8 GPUs, BASELINE.json configs[4]) rehearsed on the CPU: eight gloo ranks, the same
+    # sharding arithmetic and the same collective call as on RCCL; every rank ends with the one-rank histogram bin for bin
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    rng = np.random.default_rng(1)
+    code = _Code(rng.integers(0, 2, (5, 70)), rng.integers(0, 2, (66, 70)))
+    whole = _oracle_local(code, 5001, 0.05, 0.02, 0.03, seed=9, first_sample=100, mode='weight')
+    from quantum_css_codes_amd.montecarlo import DECODE_FIELDS, shard_range
+    whole_dec = _oracle_decode_local(_steane_oracle_code(), 30001, 0.05, 0.02, 0.03, seed=4, first_sample=7)
+    for rank in range(8):
+        r = np.load(tmp_path / ("rank%d.npz" % rank))
+        assert tuple(r["shard"]) == shard_range(100, 5001, rank, 8)
+        assert np.array_equal(r["hist_z"], whole['hist_z']) and np.array_equal(r["hist_x"], whole['hist_x'])
+        assert list(r["decode"]) == [whole_dec[f] for f in DECODE_FIELDS]
