@@ -413,7 +413,7 @@ def small_code_numbers(ctx):
     return res
 
 
-COMM_TIMEOUT_EXIT = 3          # a rank leaves with this code when its RCCL communicator did not come up in time (guarded_comm)
+COMM_TIMEOUT_EXIT = 75         # (EX_TEMPFAIL: nothing else in this program or in the interpreter exits with it) a rank leaves with this code when its RCCL communicator did not come up in time (guarded_comm)
 
 
 def launch_ranks(gpus, argv=None, deadline_s=3600.0):
@@ -486,7 +486,9 @@ def launch_ranks(gpus, argv=None, deadline_s=3600.0):
 
     try:
         rc = one_round(argv)
-        if rc == COMM_TIMEOUT_EXIT and "gf2" in argv:
+        # (asked of the parsed arguments, not of the raw list: `--allreduce=gf2` is one token)
+        wants_gf2 = any(a == "gf2" and i > 0 and argv[i - 1] == "--allreduce" for i, a in enumerate(argv)) or "--allreduce=gf2" in argv
+        if rc == COMM_TIMEOUT_EXIT and wants_gf2:
             sys.stderr.write("[bench] a rank's RCCL communicator did not come up: fresh ranks with --allreduce torch\n")
             sys.stderr.flush()
             rc = one_round(argv + ["--allreduce", "torch"])
@@ -549,14 +551,24 @@ def guarded_comm(ctx, nbins, seconds=120.0):
     mine = "ok" if box.get("ok") else ("err:" + box["why"] if "why" in box else "timeout")
     verdicts = [mine]
     if grouped and world > 1:
-        store = dist.distributed_c10d._get_default_store()
-        store.set("gf2_comm/%d" % rank, mine)
-        keys = ["gf2_comm/%d" % r for r in range(world)]
-        try:
-            store.wait(keys, datetime.timedelta(seconds=seconds + 60.0))
-            verdicts = [store.get(k).decode("utf-8", "replace") for k in keys]
-        except Exception as err:                       # noqa: BLE001 -- a rank never answered: treated as stuck
-            verdicts = [mine, "timeout (%s)" % str(err)[:60]]
+        # the verdicts travel under keys of THIS call (a counter: a second call in the same process group must not read the first
+        # one's); the store is the process group's own (there is no public accessor for it: without one the ranks agree through a
+        # host-side all_gather_object instead, which a rank stuck in RCCL cannot hold up either -- gloo -- or would anyway -- nccl)
+        guarded_comm.calls = getattr(guarded_comm, "calls", 0) + 1
+        get_store = getattr(dist.distributed_c10d, "_get_default_store", None)
+        if get_store is None:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            verdicts = gathered
+        else:
+            store = dist.PrefixStore("gf2_comm/%d/" % guarded_comm.calls, get_store())
+            store.set(str(rank), mine)
+            keys = [str(r) for r in range(world)]
+            try:
+                store.wait(keys, datetime.timedelta(seconds=seconds + 60.0))
+                verdicts = [store.get(k).decode("utf-8", "replace") for k in keys]
+            except Exception as err:                   # noqa: BLE001 -- a rank never answered: treated as stuck
+                verdicts = [mine, "timeout (%s)" % str(err)[:60]]
     if any(v.startswith("timeout") for v in verdicts):
         sys.stderr.write("[bench] rank %d: gf2_comm_create / first gf2_hist_allreduce not back within %.0f s on %s: leaving with code "
                          "%d (the context cannot be used beside a thread that is inside RCCL)\n"

@@ -67,44 +67,20 @@ int gf2_ctx_create(int device, gf2_ctx** ctx_out);
 int gf2_ctx_destroy(gf2_ctx* ctx);
 int gf2_ctx_sync(gf2_ctx* ctx);
 
-/* Routing flags of a context.  Several entry points have more than one implementation behind them,
- * all bit-identical; 0 (the default) leaves the choice to the library.  Tests and bench.py force a route with these; the
- * library never reads the environment per call (gf2_ctx_create reads GF2_FLAGS once as the initial value). */
-#define GF2_F_SPARSE_GATHER        (1u << 0)   /* gf2_syndrome_sparse_dev: wavefront-per-sample column gather            */
-#define GF2_F_SPARSE_SLABS         (1u << 1)   /* gf2_syndrome_sparse_dev: LDS row-slab pipeline also for small batches  */
-#define GF2_F_NO_REDO              (1u << 2)   /* slab pipeline: no column is left to the redo pass                     */
-#define GF2_F_GATHER_GENERIC       (1u << 3)   /* slab pipeline: compiler-scheduled gather kernel                       */
-#define GF2_F_MC_UNFUSED           (1u << 4)   /* gf2_mc_run: sampler, then the syndrome calls, on one stream           */
+/* Routing flags of a context.  Several entry points have more than one implementation behind them, all bit-identical; 0 (the
+ * default) leaves the choice to the library.  The routes a caller of the bin_matrix / CSSCode surface may want to force: */
 #define GF2_F_MC_DENSE             (1u << 5)   /* gf2_mc_run: dense table kernel whatever the error rate                */
-#define GF2_F_MC_FUSED             (1u << 6)   /* gf2_mc_run: sampler fused into the column-gather kernel               */
-#define GF2_F_MC_PIPELINE          (1u << 7)   /* gf2_mc_run on small codes: sampler + syndrome + histogram kernels     */
 #define GF2_F_RREF_SEQUENTIAL      (1u << 8)   /* gf2_rref*: one pivot per step                                         */
-#define GF2_F_RREF_NO_SMALL        (1u << 9)   /* gf2_rref*: no wavefront-per-matrix kernel                             */
 #define GF2_F_NORMALIZE_SEQUENTIAL (1u << 10)  /* gf2_normalize*: one pivot per step                                    */
-#define GF2_F_SAMPLER_GENERIC      (1u << 11)  /* gf2_sample_errors_dev: lane-per-segment kernel                        */
-#define GF2_F_DIAG_CLOCKS          (1u << 12)  /* slab pipeline: print wall-clock stamps of its kernels to stderr       */
-#define GF2_F_DIAG_MC_TIMES        (1u << 13)  /* gf2_mc_run: print the host's phases to stderr                         */
-#define GF2_F_MC_ROWS              (1u << 14)  /* gf2_mc_run: packed rows from the sampler, records by the compact kernel */
-#define GF2_F_COMBINE_FOLDED       (1u << 15)  /* slab pipeline: the combine step of a pass inside the next pass' compact kernel */
-#define GF2_F_RREF_NO_LOOKAHEAD    (1u << 16)  /* gf2_rref* on more than 8192 rows: the next pair's panels after, not under, the trailing pass */
-#define GF2_F_RREF_LOOKAHEAD       (1u << 17)  /* ... under it whatever the size (default: from 128 MiB of matrix on)              */
-#define GF2_F_COMBINE_SEPARATE     (1u << 18)  /* slab pipeline: a combine kernel after every pass (default since round 4: the combine step of a pass rides in the next pass' gather kernel) */
-#define GF2_F_ALL                  ((1u << 19) - 1u)   /* every defined flag; gf2_ctx_set_flags refuses other bits              */
+/* (The other bits name routes that exist for the parity tests and the A/B scripts under profiles/ -- quantum_css_codes_amd/csrc/
+ * gf2_tuning.h lists them; gf2_ctx_set_flags refuses bits no route is defined for.  The library never reads the environment per
+ * call; gf2_ctx_create reads GF2_FLAGS once as the initial value.) */
 int gf2_ctx_set_flags(gf2_ctx* ctx, uint32_t flags);
 int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out);
-/* Tunables of a context (value < 0 restores the default). */
+/* Tunables of a context (value < 0 restores the default).  The two that size device memory: */
 #define GF2_OPT_SLAB_PASS_LOG2  0   /* slab pipeline: 2^k samples per pass through the workspace, 12 <= k <= 24 (default 22) */
-#define GF2_OPT_COMBINE_BLOCKS  1   /* slab pipeline: workgroups of the combine kernel (default 128 * 1024 / threads)        */
-#define GF2_OPT_GATHER_REVERSE   2   /* slab pipeline: 1 (default) = the gather kernel walks the records last tile first  */
-#define GF2_OPT_REDO_BLOCKS_PER_CU 3 /* slab pipeline: workgroups per CU of the redo kernel, 1..64 (default 8)                 */
 #define GF2_OPT_MC_CHUNK_LOG2   4   /* gf2_mc_run at n <= 4096, sparse rates: 2^k samples per chunk, 16 <= k <= 22 (default 22; 21 with GF2_F_MC_ROWS) */
-#define GF2_OPT_COMBINE_THREADS 5   /* slab pipeline: threads per workgroup of the combine kernel, 64 / 128 / 256 / 512 / 1024 (default 1024) */
-#define GF2_OPT_GATHER_CROSS    6   /* slab pipeline: 1 = a gather step takes ranks 4k..4k+3 of four sorted tiles, 0 (default) = a quartile of one */
-#define GF2_OPT_GATHER_OVER     7   /* slab pipeline: gather workgroups per CU over a launch, 1..8 (default 1)                            */
-#define GF2_OPT_RREF_SMALL_BCAST 8  /* wavefront-per-matrix RREF: how the pivot rows reach the other rows.  One at a time: 0 = through LDS, 1 = through v_readlane; 2 = four at a time through a table of their sums in LDS (contiguous rows of whole 16-byte pieces, at most 32 words per lane; otherwise as the default).  Default: 2 for rows of 16 words, half LDS half readlane for at most 64 rows of at most 8 words, else 0 */
-#define GF2_OPT_MC_SAMPLER_WAVES 9  /* gf2_mc_run at n <= 4096, sparse rates: record-sampler wavefronts per CU, 1..9 (default 8)          */
-#define GF2_OPT_MC_TAIL_CAP     10  /* gf2_mc_run at n <= 4096, sparse rates: erroneous qubits of a 512-qubit segment that the record sampler's lanes take in step; a sample with more in a segment is finished by a lane of its own later.  0 (all in step), 2, 4, 6 or 8 (default: by the rate) */
-#define GF2_OPT_COUNT           11
+/* (Further option numbers, used by the A/B scripts: quantum_css_codes_amd/csrc/gf2_tuning.h.) */
 int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value);
 
 /* Device memory and stream-ordered copies on the context's stream (copies are synchronous). */

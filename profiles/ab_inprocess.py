@@ -38,7 +38,7 @@ def apply(variant):
             opts[int(key[1:])] = int(value)
     for c in path.contexts():
         c.set_flags(flags)
-        for k in range(11):
+        for k in range(14):
             c.set_option(k, opts.get(k))
 
 

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 from oracle import c_oracle  # noqa: E402
 from quantum_css_codes_amd import _native  # noqa: E402
 
-OPT_ROWS_WG, OPT_K = 12, 13
+OPT_ROWS_WG, OPT_K = _native.OPT_RREF_ROWS_WG, _native.OPT_RREF_SWEEP_K
 ctx = _native.default_context()
 
 

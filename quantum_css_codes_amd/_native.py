@@ -6,6 +6,7 @@ first compute call raises GF2Error -- the product never routes through oracle/ o
 """
 import contextlib
 import ctypes
+import math
 import os
 import threading
 
@@ -19,13 +20,15 @@ COMM_ID_BYTES = 128
 LAYOUT_SAMPLE_MAJOR, LAYOUT_BIT_SLICED, LAYOUT_TILED = 0, 1, 2
 HIST_FULL, HIST_WEIGHT = 0, 1
 K_SYNDROME, K_HIST, K_SAMPLER, K_ELIM = 0, 1, 2, 3
-# routing flags of a context (GF2_F_* of include/gf2hip.h) and its tunables (GF2_OPT_*)
+# routing flags of a context and its tunables: the few a caller needs are in include/gf2hip.h (F_MC_DENSE, F_RREF_SEQUENTIAL,
+# F_NORMALIZE_SEQUENTIAL, OPT_SLAB_PASS_LOG2, OPT_MC_CHUNK_LOG2), the rest -- routes for the parity tests and the A/B scripts -- in
+# csrc/gf2_tuning.h
 (F_SPARSE_GATHER, F_SPARSE_SLABS, F_NO_REDO, F_GATHER_GENERIC, F_MC_UNFUSED, F_MC_DENSE, F_MC_FUSED, F_MC_PIPELINE,
  F_RREF_SEQUENTIAL, F_RREF_NO_SMALL, F_NORMALIZE_SEQUENTIAL, F_SAMPLER_GENERIC, F_DIAG_CLOCKS,
  F_DIAG_MC_TIMES, F_MC_ROWS, F_COMBINE_FOLDED, F_RREF_NO_LOOKAHEAD, F_RREF_LOOKAHEAD, F_COMBINE_SEPARATE) = (1 << k for k in range(19))
 (OPT_SLAB_PASS_LOG2, OPT_COMBINE_BLOCKS, OPT_GATHER_REVERSE, OPT_REDO_BLOCKS_PER_CU, OPT_MC_CHUNK_LOG2, OPT_COMBINE_THREADS,
  OPT_GATHER_CROSS, OPT_GATHER_OVER, OPT_RREF_SMALL_BCAST, OPT_MC_SAMPLER_WAVES,
- OPT_MC_TAIL_CAP) = range(11)
+ OPT_MC_TAIL_CAP, OPT_RREF_RESERVED0, OPT_RREF_ROWS_WG, OPT_RREF_SWEEP_K) = range(14)
 
 
 class GF2Error(RuntimeError):
@@ -547,7 +550,17 @@ class Context(object):
         weights and their ranks inside their weight class (unrank with unrank_supports), in no particular order."""
         rows = np.ascontiguousarray(packed, dtype="<u8")
         kw = 1 if r <= 63 else 2
-        cap = 1 << 16
+        # The C call writes the entries only into a buffer that holds them all (it counts the classes, it does not keep them), so
+        # a buffer that is too small costs a second search.  With a weight bound the table cannot exceed the classes up to it; without
+        # one, 2^22 entries (100 MB on the host) cover every table met so far -- the first collision of a code with r checks comes
+        # after some 2^((r+1)/2) errors -- and only larger tables are searched twice.
+        cap = 1 << 22
+        if max_weight is not None:
+            total, w = 0, 0
+            while w <= min(max_weight, n) and total <= (1 << 28):
+                total += math.comb(n, w)
+                w += 1
+            cap = max(1, min(total, 1 << 28))
         t, entries = _c_i64(), _c_i64()
         while True:
             keys = np.empty((cap, kw), dtype="<u8")

@@ -122,7 +122,7 @@ int gf2_ctx_create(int device, gf2_ctx** ctx_out) {
     if (!ctx) GF2_FAIL(GF2_E_NOMEM, "gf2_ctx_create: out of host memory");
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
-    for (int k = 0; k < GF2_OPT_COUNT_ALL; ++k) ctx->opt[k] = -1;
+    for (int k = 0; k < GF2_OPT_COUNT; ++k) ctx->opt[k] = -1;
     const char* env_flags = getenv("GF2_FLAGS");                    // read once, here: the initial routing flags
     ctx->flags = env_flags ? (uint32_t)strtoul(env_flags, nullptr, 0) & GF2_F_ALL : 0u;     // unknown bits are dropped
     const int rc = create_streams_and_events(ctx);
@@ -149,7 +149,7 @@ int gf2_ctx_get_flags(gf2_ctx* ctx, uint32_t* flags_out) {
 }
 
 int gf2_ctx_set_option(gf2_ctx* ctx, int option, int64_t value) {
-    if (!ctx || option < 0 || option >= GF2_OPT_COUNT_ALL) GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: bad argument");
+    if (!ctx || option < 0 || option >= GF2_OPT_COUNT) GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: bad argument");
     if (value >= 0) {
         if (option == GF2_OPT_SLAB_PASS_LOG2 && (value < 12 || value > 24))
             GF2_FAIL(GF2_E_ARG, "gf2_ctx_set_option: GF2_OPT_SLAB_PASS_LOG2 must be in 12..24");

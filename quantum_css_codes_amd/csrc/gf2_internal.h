@@ -6,6 +6,7 @@
 #include <stdio.h>
 
 #include "gf2hip.h"
+#include "gf2_tuning.h"
 
 #define GF2_VERSION_NUMBER 100
 
@@ -36,14 +37,6 @@ void gf2_set_error(const char* fmt, ...);
         if (gf2_rc_ != GF2_OK) return gf2_rc_; \
     } while (0)
 
-// ---- internal tunables ---------------------------------------------------------------------------
-// Set through gf2_ctx_set_option like the public ones (ids continue the public list); used by the A/B scripts under profiles/ and
-// by tests that force a route, not part of the ABI a caller of bin_matrix / CSSCode needs (value < 0 = default).
-#define GF2_OPT_RREF_RESERVED0 (GF2_OPT_COUNT + 0)   // (was: groups of matrices on streams of their own -- measured, not kept)
-#define GF2_OPT_RREF_ROWS_WG   (GF2_OPT_COUNT + 1)   // blocked RREF: rows per workgroup of the trailing pass (>= 64)
-#define GF2_OPT_RREF_SWEEP_K   (GF2_OPT_COUNT + 2)   // blocked RREF up to 4096 rows: panels per sweep, 4 (default) or 2; 0 = the round-4 pair kernels
-#define GF2_OPT_COUNT_ALL      (GF2_OPT_COUNT + 3)
-
 // ---- context -------------------------------------------------------------------------------------
 struct gf2_ctx {
     int device;
@@ -66,11 +59,11 @@ struct gf2_ctx {
     void* ws[4];
     size_t ws_bytes[4];
     // large dynamic-LDS opt-in (hipFuncSetAttribute) done for this context's device: [0] syndrome_tiled_kernel,
-    // [1] (unused), [2] slab_gather_kernel, [3] conjugate_kernel, [4] rref_update_pair_kernel
+    // [1] table_class_hash_kernel, [2] slab_gather_kernel, [3] conjugate_kernel, [4] rref_update_pair_kernel
     bool lds_optin[7];            // ... [5], [6] rref_sweep_update_kernel<2>, <4>
     // routing flags (GF2_F_*) and tunables (GF2_OPT_*, -1 = default): gf2_ctx_set_flags / gf2_ctx_set_option
     uint32_t flags;
-    int64_t opt[GF2_OPT_COUNT_ALL];
+    int64_t opt[GF2_OPT_COUNT];
     // the sampler's two inverse-CDF tables (whole segments, last segment) in device memory, and what they were made for
     uint64_t* seg_cdf_dev;
     uint64_t seg_key_t;

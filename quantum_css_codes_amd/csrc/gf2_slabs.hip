@@ -27,6 +27,23 @@
 #include <type_traits>
 
 #include "gf2_internal.h"
+
+// Cache policy of the streams that are read exactly once (round 5): the compact kernel's packed error rows and
+// the gather kernel's identity words.  GF2_SLAB_NT: 0 = default policy, 1 = rows non-temporal, 2 = identity words non-temporal,
+// 3 = both (profiles/r05_nt.sh builds the four libraries and alternates them on one box; profiles/r05_nt.md holds what came of it).
+#ifndef GF2_SLAB_NT
+#define GF2_SLAB_NT 0
+#endif
+#if GF2_SLAB_NT & 1
+#define GF2_ROWS_POLICY " nt"
+#else
+#define GF2_ROWS_POLICY ""
+#endif
+#if GF2_SLAB_NT & 2
+#define GF2_IDENT_POLICY " nt"
+#else
+#define GF2_IDENT_POLICY ""
+#endif
 #include "gf2_sparse_dev.h"
 #include "gf2_sampler.h"
 
@@ -206,7 +223,7 @@ __device__ __forceinline__ void load_pairs(const CompactArgs& a, int64_t s_first
         const u64* base = a.e + s_first * a.lde;
 #pragma unroll
         for (int t = 0; t < T; ++t)
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(w[t]) : "v"(pm.off[t]), "s"(base) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2" GF2_ROWS_POLICY : "=v"(w[t]) : "v"(pm.off[t]), "s"(base) : "memory");
     } else {
         // rows past the batch are clamped into it (the caller masks); offsets from the sub-pass' first row (itself clamped), so
         // that they stay small whatever the size of a pass (the lane offset is an unsigned 32-bit addend of the scalar base)
@@ -218,7 +235,7 @@ __device__ __forceinline__ void load_pairs(const CompactArgs& a, int64_t s_first
             int64_t sample = s_first + (int64_t)(pm.jw[t] >> 6);
             if (sample > last) sample = last;
             const unsigned int off = (unsigned int)(sample - first) * (unsigned int)a.lde * 8u + (pm.jw[t] & 63u) * 8u;
-            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(w[t]) : "v"(off), "s"(base) : "memory");
+            asm volatile("global_load_dwordx2 %0, %1, %2" GF2_ROWS_POLICY : "=v"(w[t]) : "v"(off), "s"(base) : "memory");
         }
     }
 }
@@ -1303,10 +1320,10 @@ __global__ __launch_bounds__(GAT_THREADS, 4) void slab_gather_fast_kernel(Gather
     auto issue_ident = [&](u32x4& I, unsigned int& E, unsigned int pos, unsigned int header) {
         const unsigned int sample = record_sample(pos, header);
         const char* p = ident_base + (u64)(sample < (unsigned int)a.batch ? sample : 0u) * row_bytes;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(I) : "v"(p) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" GF2_IDENT_POLICY : "=v"(I) : "v"(p) : "memory");
         if (EXTRA) {
             // the fifth dword is the neighbouring row part's first one; only the last part of the slab loads it
-            if (part == 3) asm volatile("global_load_dword %0, %1, off" : "=v"(E) : "v"(p + (int)fifth_off) : "memory");
+            if (part == 3) asm volatile("global_load_dword %0, %1, off" GF2_IDENT_POLICY : "=v"(E) : "v"(p + (int)fifth_off) : "memory");
         }
     };
 

@@ -659,14 +659,15 @@ static void column_keys(const uint64_t* h_rows, int64_t r, int64_t n, int64_t ld
     }
 }
 
+// (per context, like the other large-LDS opt-ins: a context is used by one thread at a time, distinct contexts may run on distinct
+// threads -- a process-wide table of devices would be written by several)
 static int hash_lds_optin(gf2_ctx* ctx) {
-    static bool done[64] = {};
-    if (ctx->device >= 0 && ctx->device < 64 && done[ctx->device]) return GF2_OK;
+    if (ctx->lds_optin[1]) return GF2_OK;
     GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(table_class_hash_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 TBL_HASH_MAX_N * 8));
     GF2_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(table_class_hash_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 TBL_HASH_MAX_N * 16));
-    if (ctx->device >= 0 && ctx->device < 64) done[ctx->device] = true;
+    ctx->lds_optin[1] = true;
     return GF2_OK;
 }
 

@@ -370,7 +370,16 @@ def syndrome_table(parity_check, max_weight=None, _packed=None):
     if ctx.TABLE_MAX_R < r <= ctx.TABLE_HASH_MAX_R and 0 < n <= ctx.TABLE_HASH_MAX_N:
         # more than 24 checks (round 4; every k = 1 CSS code from n = 51 on has such a check): an open-addressing hash table on
         # the device, sized from the weight classes it holds (gf2_syndrome_table_hashed); exact keys of up to 127 bits
-        t, keys, weight, rank = ctx.syndrome_table_hashed(packed_h, r, n, max_weight)
+        try:
+            t, keys, weight, rank = ctx.syndrome_table_hashed(packed_h, r, n, max_weight)
+        except _native.GF2Error as err:
+            if err.code != _native.GF2_E_NOMEM:
+                raise
+            # 2^28 errors enumerated and no two with one syndrome yet: where the reference's loop (css_code.py:722-733) would go on
+            # for days (the first collision of a random code with r checks is expected after some 2^((r+1)/2) errors: from about
+            # r = 56 on without a bound), this says so and names the way out
+            raise ValueError("syndrome_table: more than 2^28 errors without two of one syndrome (r = %d checks, n = %d); pass "
+                             "max_weight (CSSCode: max_table_weight) to bound the table" % (r, n)) from err
         keys = np.asarray(keys, dtype=object if r > 63 else np.uint64)
         table = {}
         for w in range(int(weight.max()) + 1 if weight.size else 0):

@@ -39,7 +39,11 @@ def test_ctypes_table_matches_header():
 
 
 def test_flag_and_option_numbers_match_the_header():
-    text = open(os.path.join(ROOT, "include", "gf2hip.h")).read()
+    # the public header names the few routes and tunables a caller needs, csrc/gf2_tuning.h the ones of the tests and A/B scripts:
+    # together they are what _native.py states, no number used twice
+    public = open(os.path.join(ROOT, "include", "gf2hip.h")).read()
+    assert len(re.findall(r"#define GF2_F_\w+", public)) == 3 and len(re.findall(r"#define GF2_OPT_\w+", public)) == 2
+    text = public + open(os.path.join(ROOT, "quantum_css_codes_amd", "csrc", "gf2_tuning.h")).read()
     flags = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define GF2_F_(\w+)\s+\(1u << (\d+)\)", text)}
     assert len(flags) >= 16
     for name, bit in flags.items():

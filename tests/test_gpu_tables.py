@@ -129,3 +129,16 @@ def test_hashed_table_refuses_a_search_without_end():
     with pytest.raises(_native.GF2Error) as err:
         css_code.syndrome_table(h)
     assert err.value.code == _native.GF2_E_NOMEM and "max_weight" in err.value.message
+
+
+def test_syndrome_table_without_a_bound_on_many_checks_says_how_to_bound_it():
+    # a random check with 60 rows finds no two errors of one syndrome among its first 2^28 (the first collision of r
+    # checks is expected after some 2^((r+1)/2) errors); the device search then stops with GF2_E_NOMEM, and css_code.syndrome_table
+    # turns that into a ValueError that names max_weight -- the reference's loop (css_code.py:722-733) would run for days.  With a
+    # bound the same check gives its table.
+    rng = np.random.default_rng(60)
+    h = rng.integers(0, 2, (60, 70))
+    with pytest.raises(ValueError, match="max_weight"):
+        css_code.syndrome_table(h)
+    t, table = css_code.syndrome_table(h, max_weight=2)
+    assert t == 2 and len(table) == 1 + 70 + 70 * 69 // 2
