@@ -267,7 +267,18 @@ def pmc_traffic(kernel):
         return None, None
     tj = json.load(open(tpath))
     return tj.get(kernel + "_bytes_per_launch"), "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, at " \
-        "commit %s (profiles/r04_evidence.sh)" % tj.get("captured_at_commit", "?")
+        "commit %s (profiles/r05_evidence.sh)" % tj.get("captured_at_commit", "?")
+
+
+def traffic_stale():
+    """True when the kernel sources are not the ones profiles/traffic.json was measured on (profiles/csrc_digest.py): the
+    `traffic` figures of this line then describe an earlier build and want a new profiles/r05_evidence.sh run."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return True
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import csrc_digest
+    return json.load(open(tpath)).get("captured_at_csrc_sha256") != csrc_digest.digest()
 
 
 def roofline(path, mean_launch_s, launches):
@@ -777,6 +788,7 @@ def main():
         # 8 TB/s specification the fraction is quoted against
         probe_bytes = min(batch * 512, 1 << 32)
         measured = ctx.membw_probe(path.ex, probe_bytes)
+        roof["traffic_stale"] = traffic_stale()
         roof["measured_read_peak_GBs"] = measured
         roof["frac_of_measured_peak"] = roof["achieved"] / measured
         # integer work of the algorithm as it is run: per sample and component (w + 2) * r / 32 32-bit XOR
