@@ -1845,3 +1845,42 @@ def test_rref_batch_small_matrix_kernel_every_variant(shape, ctx, route):
     again = packed.copy()
     piv2, ranks2 = ctx.rref_batch(again, batch, m, n)
     assert np.array_equal(again, got) and np.array_equal(ranks2, ranks)
+
+
+@pytest.mark.parametrize("k", [4, 2, 0])
+@pytest.mark.parametrize("shape", [(2048, 4096, 2), (300, 2500, 3), (1025, 1030, 3), (3000, 1000, 2), (520, 8200, 9), (129, 65, 33)])
+def test_rref_sweep_routes(shape, k, ctx):
+    # Round 5: the blocked RREF below 4097 rows with K = 4 and K = 2 panels per sweep (fused right-looking panel kernel, K-table trailing
+    # pass, side buffer of the next sweep's column words, few-pivot tail) and round 4's pair kernels (K = 0), forced through the
+    # internal option, with small row blocks too: same reduced forms, pivots and ranks as the oracle's (bin_matrix.py:8-34).  The
+    # batches hold dense and sparse matrices, leading pivot-free panels (a sweep without pivots: the side buffer is not written, the
+    # next panel kernel reads the rows), rank-deficient matrices (several rounds per panel) and every-other-column-zero matrices;
+    # 520 x 8200 has a ragged last chunk, 3000 x 1000 more rows than columns, 129 x 65 a partial only panel.
+    m, n, batch = shape
+    rng = np.random.default_rng(m * 11 + n + batch)
+    mats = []
+    for b in range(batch):
+        a = (rng.random((m, n)) < (0.5 if b % 3 != 1 else 0.03)).astype(np.uint8)
+        if b % 4 == 2:
+            a[:, :min(n, 200)] = 0
+        if b % 5 == 3 and m >= 2:
+            a[m // 2:] = a[: m - m // 2]
+        if b % 7 == 6:
+            a[:, ::2] = 0
+        mats.append(a)
+    want = [c_oracle.rref(c_oracle.pack_rows(a), m, n) for a in mats]
+    flags = ctx.get_flags()
+    try:
+        ctx.set_flags(flags | _native.F_RREF_NO_SMALL)               # (129 x 65 would take the wavefront-per-matrix kernel)
+        ctx.set_option(_native.OPT_RREF_SWEEP_K, k)
+        for rows_wg in ((None, 128) if k else (None,)):
+            ctx.set_option(_native.OPT_RREF_ROWS_WG, rows_wg)
+            packed = np.stack([_native.pack_rows(a) for a in mats])
+            pivots, ranks = ctx.rref_batch(packed, batch, m, n)
+            for b in range(batch):
+                assert ranks[b] == want[b][2] and np.array_equal(packed[b], want[b][0]), (k, rows_wg, b)
+                assert list(pivots[b, :want[b][2]]) == list(want[b][1]), (k, rows_wg, b)
+    finally:
+        ctx.set_flags(flags)
+        ctx.set_option(_native.OPT_RREF_SWEEP_K, None)
+        ctx.set_option(_native.OPT_RREF_ROWS_WG, None)
