@@ -92,11 +92,38 @@ def timing():
     ctx.set_option(OPT_K, -1)
 
 
+def check_tall():
+    """The streamed sweeps (more than 4096 rows, K = 4 forced) against the oracle, with and without look-ahead."""
+    shapes = [(4100, 700, 1), (5000, 5100, 1), (8200, 8300, 2), (9000, 2000, 1), (4500, 4600, 3)]
+    bad = 0
+    for (m, n, batch) in shapes:
+        mats = mats_for(m, n, batch, m * 11 + n + batch)
+        want = [c_oracle.rref(c_oracle.pack_rows(a), m, n) for a in mats]
+        for flag in (0, 1 << 16):                                       # GF2_F_RREF_NO_LOOKAHEAD
+            ctx.set_option(OPT_K, 4)
+            flags = ctx.get_flags()
+            ctx.set_flags(flags | flag)
+            packed = np.stack([_native.pack_rows(a) for a in mats])
+            pivots, ranks = ctx.rref_batch(packed, batch, m, n)
+            ctx.set_flags(flags)
+            ok = True
+            for b in range(batch):
+                ok = ok and ranks[b] == want[b][2] and np.array_equal(packed[b], want[b][0]) and \
+                    list(pivots[b, :want[b][2]]) == list(want[b][1])
+            print("tall %5d x %5d x %3d  streamed sweeps, flags %#x  %s" % (m, n, batch, flag, "ok" if ok else "MISMATCH"), flush=True)
+            bad += 0 if ok else 1
+    ctx.set_option(OPT_K, -1)
+    print("tall: %d mismatches" % bad)
+    return bad
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["check", "time"]
     rc = 0
     if "check" in what:
         rc = check()
+    if "tall" in what:
+        rc = rc or check_tall()
     if "time" in what and rc == 0:
         timing()
     sys.exit(1 if rc else 0)

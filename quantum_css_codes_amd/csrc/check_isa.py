@@ -186,7 +186,7 @@ def check_elim(path):
     found = kernels_in(path)
     seen = 0
     for name, stream in found.items():
-        panel = any(k in name for k in ("rref_panel_kernel", "rref_panel_stream_kernel", "norm_panel_kernel", "rref_sweep_panel_kernel"))
+        panel = any(k in name for k in ("rref_panel_kernel", "rref_panel_stream_kernel", "norm_panel_kernel", "rref_sweep_panel_kernel", "sweep_stream_panel_kernel"))
         seen += 1 if panel else 0
         outside = [(no, text) for no, text, in_asm in stream if not in_asm and re.search(r"\bm0\b", text)]
         for no, text in outside:

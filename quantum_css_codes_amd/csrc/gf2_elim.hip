@@ -998,6 +998,7 @@ struct SweepState {                                 // per matrix, in global scr
     int64_t skip_hi;                                // words wholly below this column cannot change in the current sweep
     int64_t colw_pw;                                // the side buffer holds words colw_pw .. colw_pw + K - 1 as they stand (-1: nothing)
     int32_t tg[4];                                  // pivots of the sweep's panels
+    int32_t pending, spare;                         // streamed panels: the last round's table waits in `tabs` for sweep_finish_kernel
 };
 
 __device__ __forceinline__ void byte_table(int tid, const u64* rows64, u64* T) {
@@ -1256,10 +1257,13 @@ __global__ __launch_bounds__(RB_THREADS) void rref_sweep_panel_kernel(const u64*
 template <int K, int TH>
 __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, const int64_t chunk, const int64_t rowblock, const unsigned int unit,
                                                   u64* base, int64_t m, int64_t ld, int64_t rows_per_wg,
-                                                  SweepState* __restrict__ states, const u64* __restrict__ d_base,
+                                                  const SweepState* __restrict__ states, SweepState* __restrict__ live,
+                                                  const u64* __restrict__ d_base,
                                                   int64_t dstride, const u64* __restrict__ snap_base,
                                                   int64_t sstride, int64_t pw0,
                                                   u64* __restrict__ colw_base, u64* out_base) {
+    // states: what this sweep's panels left (with look-ahead a COPY: the next sweep's panels are writing the state by now);
+    // live: the state the next panel kernel reads -- it learns from there that the side buffer holds its column words
     static_assert(K == 2 || K == 4, "two or four panels per sweep");
 #if GF2_SWEEP_DIAG
     const u64 diag_wg0 = wall_clock64();
@@ -1299,7 +1303,7 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
                 if (moving) a_out[row * ld + cw0 + wd] = v;
                 if (emits && cw0 + wd >= pw_next && cw0 + wd < pw_next + K) colw[row * K + (cw0 + wd - pw_next)] = v;
             }
-            if (emits && tid == 0 && rowblock == 0) states[mat].colw_pw = pw_next;
+            if (emits && tid == 0 && rowblock == 0) live[mat].colw_pw = pw_next;
         }
         return;
     }
@@ -1356,7 +1360,7 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
                 colw[row * K + (hw2 - emit_lo) + 1] = x1;
             }
         }
-        if (emits && tid == 0 && rowblock == 0) states[mat].colw_pw = pw_next;
+        if (emits && tid == 0 && rowblock == 0) live[mat].colw_pw = pw_next;
         return;
     }
     typedef const __attribute__((address_space(3))) u64* lds_u64_ptr;
@@ -1497,7 +1501,7 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
         load2(rb + 2 * STEP, s0);
         if (rb + STEP < row_end) work2(rb + STEP, s1);                 // uniform
     }
-    if (emits && tid == 0 && rowblock == 0) states[mat].colw_pw = pw_next;
+    if (emits && tid == 0 && rowblock == 0) live[mat].colw_pw = pw_next;
 #if GF2_SWEEP_DIAG
     if (tid == 0) {
         const u64 diag_c2 = clock64(), diag_w2 = wall_clock64();
@@ -1528,14 +1532,234 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
 // wavefronts -- the LDS serves the oldest wavefront first, so wavefront 0, which took the stamps, is done long before the last.)
 template <int K, int TH>
 __global__ __launch_bounds__(TH) void rref_sweep_update_kernel(u64* base, int64_t m, int64_t ld, int64_t rows_per_wg,
-                                                               SweepState* __restrict__ states, const u64* __restrict__ d_base,
+                                                               const SweepState* __restrict__ states, SweepState* __restrict__ live,
+                                                               const u64* __restrict__ d_base,
                                                                int64_t dstride, const u64* __restrict__ snap_base,
                                                                int64_t sstride, int64_t pw0,
-                                                               u64* __restrict__ colw_base, u64* out_base) {
+                                                               u64* __restrict__ colw_base, u64* out_base, int chunk_base, int chunk_skip) {
+    // the launch covers chunks chunk_base .. chunk_base + gridDim.y - 1 but chunk_skip (look-ahead of the streamed path: the chunk
+    // of the next sweep's columns goes first, in a launch of its own)
     extern __shared__ __attribute__((aligned(16))) u64 T[];           // (the lookups address the tables from LDS byte 0: the kernel's only LDS)
+    const int chunk = (int)blockIdx.y + chunk_base;
+    if (chunk == chunk_skip) return;
     const unsigned int unit = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    sweep_update_unit<K, TH>(T, blockIdx.z, blockIdx.y, blockIdx.x, unit, base, m, ld, rows_per_wg, states, d_base, dstride, snap_base, sstride,
-                             pw0, colw_base, out_base);
+    sweep_update_unit<K, TH>(T, blockIdx.z, chunk, blockIdx.x, unit, base, m, ld, rows_per_wg, states, live, d_base, dstride, snap_base,
+                             sstride, pw0, colw_base, out_base);
+}
+
+// ---- the same sweeps for matrices of more than 4096 rows: rows streamed, not held in registers -----------------------------------
+//
+// A lane cannot hold the K column words and coefficients of more than four of its rows, so above 4096 rows the right-looking sweep
+// keeps them in memory: `colw` (K words per row, the side buffer itself) and the folded coefficients e_l (the arrays the pass reads).
+// Per panel l of a sweep, two launches:
+//   sweep_stream_panel_kernel (one workgroup per matrix): as rref_panel_stream_kernel -- window filled through an LDS counter,
+//     window_round, the rare further rounds applied to every row by this workgroup, the last round's rows left to the chip -- on
+//     column l of colw; then it publishes, for the panel's pivot rows, their later column words and their coefficients of the
+//     sweep's earlier panels (`pub`, K - 1 vectors of 64 words).
+//   sweep_finish_kernel (the whole chip, one row per lane): d = coefficients of the last round (table lookup of the row's word);
+//     e_l = d;  w_j ^= d . pub_j for the later columns;  e_{l2} ^= d . pub_{l2} for the earlier panels (rref_sweep_panel_kernel's
+//     right-looking step); resets the per-round scratch for the next panel.
+// sweep_column_kernel fills colw from the rows when the pass has not (first sweep, a sweep after one without pivots);
+// sweep_snapshot_kernel copies the sweep's pivot rows for the pass.  launch_rref_sweeps_streamed runs the next sweep's panels on a
+// second stream UNDER this sweep's pass (look-ahead), as launch_rref_blocked does for pairs.
+__global__ __launch_bounds__(256) void sweep_column_kernel(const u64* __restrict__ base, int64_t m, int64_t ld, int64_t pw0, int K,
+                                                           const SweepState* __restrict__ states, u64* __restrict__ colw_base,
+                                                           u64* __restrict__ cco_base, int32_t* __restrict__ slot_base) {
+    const int64_t mat = blockIdx.y, row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= m) return;
+    if (states[mat].colw_pw != pw0) {                                  // uniform per matrix
+        const u64* a = base + (mat * m + row) * ld;
+        for (int j = 0; j < K; ++j) colw_base[(mat * m + row) * K + j] = pw0 + j < ld ? a[pw0 + j] : 0ull;
+    }
+    cco_base[mat * m + row] = 0;
+    slot_base[mat * m + row] = -1;
+}
+
+template <int K>
+__global__ __launch_bounds__(RB_THREADS) void sweep_stream_panel_kernel(int64_t m, int64_t n, int64_t ld, int64_t pw0, int l,
+                                                                       int64_t* __restrict__ pivots_base, int64_t cap,
+                                                                       int32_t* __restrict__ pivrow_base, SweepState* __restrict__ states,
+                                                                       unsigned char* __restrict__ used_base,
+                                                                       int32_t* __restrict__ prow_base, u64* __restrict__ colw_base,
+                                                                       u64* __restrict__ cco_base, int32_t* __restrict__ slot_base,
+                                                                       u64* __restrict__ tabs_base, const u64* __restrict__ e_base,
+                                                                       int64_t dstride, u64* __restrict__ pub_base) {
+    __shared__ u64 VT[2048], TW[2048];
+    __shared__ u64 win_w[RB_WIN], win_d[RB_WIN], fin_w[RB_WIN], fin_d[RB_WIN], DP[64], WP[64];
+    __shared__ int win_row[RB_WIN], win_piv[RB_WIN], pbit[64], prow_l[64], misc[4];
+    __shared__ int win_count;
+    const int64_t mat = blockIdx.x;
+    SweepState* st = states + mat;
+    unsigned char* used = used_base + mat * m;
+    u64* colw = colw_base + mat * m * K;                                // the panel's column: word l of every row's K
+    u64* cco = cco_base + mat * m;
+    int32_t* slot_of = slot_base + mat * m;                             // -1, or the row's window slot in this round; -2: settled here
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t pw = pw0 + l;
+    const int64_t rank = st->rank;
+    int64_t first_free = st->first_free;
+    if (l == 0 && tid == 0) {                                           // the sweep's first panel: what its pass may skip, nothing found yet
+        st->skip_hi = first_free < pw0 * 64 ? first_free : pw0 * 64;    // first_free as it was BEFORE this sweep
+        for (int j = 1; j < K; ++j) st->tg[j] = 0;
+    }
+    if (rank >= m || pw * 64 >= n) {                                    // nothing left to do for this panel
+        if (tid == 0) st->tg[l] = 0, st->pending = 0;
+        return;
+    }
+    int64_t* pivots = pivots_base ? pivots_base + mat * cap : nullptr;
+    int32_t* pivrow = pivrow_base + mat * cap;
+    const int64_t cols_here = n - pw * 64;
+    const u64 panel_cols = cols_here >= 64 ? ~0ull : ((1ull << cols_here) - 1ull);
+    u64 unresolved = panel_cols;
+    int t = 0, pending = 0;
+    while (unresolved && t < 64 && rank + t < m) {
+        if (tid == 0) win_count = 0;
+        __syncthreads();
+        for (int64_t r0 = 0; r0 < m; r0 += RB_THREADS) {                // fill the window; stop scanning once it is full
+            const int64_t row = r0 + tid;
+            if (row < m && !used[row]) {
+                const u64 wv = colw[row * K + l];
+                if (wv & unresolved) {
+                    const int pos = atomicAdd(&win_count, 1);
+                    if (pos < RB_WIN) {
+                        slot_of[row] = pos;
+                        win_row[pos] = (int)row;
+                        win_w[pos] = wv;
+                        win_d[pos] = cco[row];
+                        win_piv[pos] = 0;
+                    }
+                }
+            }
+            __syncthreads();
+            if (win_count >= RB_WIN) break;
+        }
+        const int total = win_count;
+        if (total == 0) break;
+        const int nwin = total < RB_WIN ? total : RB_WIN;
+        if (wave == 0)
+            window_round(lane, nwin, t, rank, m, unresolved, win_w, win_d, win_row, win_piv, fin_w, fin_d, pbit, prow_l, DP, WP, misc);
+        __syncthreads();
+        const int t_new = misc[0];
+        const u64 newbits = ((u64)(unsigned int)misc[2] << 32) | (unsigned int)misc[1];
+        const bool again = (unresolved & ~newbits) != 0 && t_new < 64 && rank + t_new < m;    // uniform: another round may follow
+        round_tables(tid, DP, WP, VT, TW, again);
+        __syncthreads();
+        if (!again) {
+            // the last round: only its pivot rows are settled here (coefficients final, marked -2); every other row takes its
+            // coefficients from the probe-row table in sweep_finish_kernel, on the whole chip instead of in this one workgroup
+            if (tid < nwin) {
+                const int row = win_row[tid];
+                if (win_piv[tid]) {
+                    cco[row] = fin_d[tid];
+                    used[row] = 1;
+                    slot_of[row] = -2;
+                } else {
+                    slot_of[row] = -1;
+                }
+            }
+            for (int idx = tid; idx < 2048; idx += RB_THREADS) tabs_base[mat * 2048 + idx] = VT[idx];
+            pending = 1;
+            unresolved &= ~newbits;
+            t = t_new;
+            __syncthreads();
+            break;
+        }
+        for (int64_t row = tid; row < m; row += RB_THREADS) {
+            const int sl = slot_of[row];
+            if (sl >= 0) slot_of[row] = -1;
+            if (sl >= 0 && sl < RB_WIN && win_row[sl] == (int)row && win_piv[sl]) {       // a new pivot row: as the wavefront left it
+                colw[row * K + l] = fin_w[sl];
+                cco[row] = fin_d[sl];
+                used[row] = 1;
+            } else {                                                  // every other row: linear in its word
+                const u64 w0 = colw[row * K + l];
+                cco[row] ^= byte_lookup(VT, w0);
+                colw[row * K + l] = byte_lookup(TW, w0);
+            }
+        }
+        unresolved &= ~newbits;
+        t = t_new;
+        __syncthreads();
+    }
+    if (unresolved) {
+        const int64_t fc = pw * 64 + (__ffsll((long long)unresolved) - 1);
+        if (fc < first_free) first_free = fc;
+    }
+    if (tid == 0) {
+        st->pending = pending;
+        st->tg[l] = t;
+        st->rank = rank + t;
+        st->first_free = first_free;
+    }
+    if (t == 0) return;
+    if (wave == 0 && lane < t) {
+        const u64 resolved = panel_cols & ~unresolved;
+        const int pos = __popcll(resolved & ((1ull << pbit[lane]) - 1ull));
+        pivrow[rank + pos] = prow_l[lane];
+        if (pivots) pivots[rank + pos] = pw * 64 + pbit[lane];
+        prow_base[(mat * K + l) * 64 + lane] = prow_l[lane];            // for the snapshot of the sweep's pivot rows
+    }
+    // what the panel's pivot rows show the other rows: their later column words, their coefficients of the sweep's earlier panels
+    if (tid < 64 * (K - 1)) {
+        const int v = tid >> 6, q = tid & 63;
+        u64 x = 0;
+        if (q < t) {
+            const int64_t prow = prow_l[q];
+            x = v < K - 1 - l ? colw[prow * K + (l + 1 + v)] : e_base[(int64_t)(v - (K - 1 - l)) * dstride + mat * m + prow];
+        }
+        pub_base[(mat * (K - 1) + v) * 64 + q] = x;
+    }
+}
+
+// The rest of a streamed panel, one row per lane on as many workgroups as there are rows for (see above).  Dynamic LDS: K tables.
+template <int K>
+__global__ __launch_bounds__(1024) void sweep_finish_kernel(int64_t m, int l, const SweepState* __restrict__ states,
+                                                            u64* __restrict__ colw_base, u64* __restrict__ cco_base,
+                                                            int32_t* __restrict__ slot_base, const u64* __restrict__ tabs_base,
+                                                            u64* __restrict__ e_base, int64_t dstride, const u64* __restrict__ pub_base) {
+    extern __shared__ __attribute__((aligned(16))) u64 FT[];           // [0]: the last round's table, [1 .. K - 1]: the published vectors'
+    const int64_t mat = blockIdx.y;
+    const int64_t row = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int t = states[mat].tg[l], pending = states[mat].pending;
+    u64* el = e_base + (int64_t)l * dstride + mat * m;
+    if (t == 0) {                                                       // the pass reads the panel's coefficients all the same
+        if (row < m) el[row] = 0ull;
+        return;
+    }
+    __shared__ u64 pv_s[(K - 1) * 64];
+    if (threadIdx.x < (K - 1) * 64) pv_s[threadIdx.x] = pub_base[mat * (K - 1) * 64 + threadIdx.x];
+    for (int idx = threadIdx.x; idx < 2048; idx += 1024) FT[idx] = pending ? tabs_base[mat * 2048 + idx] : 0ull;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < (K - 1) * 2048; idx += 1024) {
+        const int v = idx >> 11, g = (idx >> 8) & 7, vv = idx & 255;
+        const u64* pv = pv_s + v * 64 + 8 * g;
+        u64 x = 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x ^= pv[c] & (0ull - (u64)((vv >> c) & 1));
+        FT[2048 + idx] = x;
+    }
+    __syncthreads();
+    if (row >= m) return;
+    u64* w = colw_base + (mat * m + row) * K;
+    u64 d = cco_base[mat * m + row];
+    if (pending && slot_base[mat * m + row] != -2) d ^= byte_lookup(FT, w[l]);
+    el[row] = d;
+    for (int j = l + 1; j < K; ++j) w[j] ^= byte_lookup(FT + 2048 * (j - l), d);
+    for (int l2 = 0; l2 < l; ++l2) e_base[(int64_t)l2 * dstride + mat * m + row] ^= byte_lookup(FT + 2048 * (K - l + l2), d);
+    cco_base[mat * m + row] = 0;
+    slot_base[mat * m + row] = -1;
+}
+
+// The sweep's pivot rows as they stand in memory, for the pass: workgroup (64 l + q, matrix) copies pivot row q of panel l.
+__global__ __launch_bounds__(1024) void sweep_snapshot_kernel(const u64* __restrict__ base, int64_t m, int64_t ld, int K,
+                                                              const SweepState* __restrict__ states, const int32_t* __restrict__ prow_base,
+                                                              u64* __restrict__ snap_base, int64_t sstride) {
+    const int64_t mat = blockIdx.y;
+    const int l = (int)blockIdx.x >> 6, q = (int)blockIdx.x & 63;
+    if (q >= states[mat].tg[l]) return;
+    const u64* src = base + (mat * m + prow_base[(mat * K + l) * 64 + q]) * ld;
+    u64* dst = snap_base + (int64_t)l * sstride + (mat * 64 + q) * ld;
+    for (int64_t wd = threadIdx.x; wd < ld; wd += blockDim.x) dst[wd] = src[wd];
 }
 
 // ---- blocked normalisation (css_code.py:809-836), bit-exact ------------------------------------------------------------
@@ -2300,8 +2524,8 @@ static int launch_rref_sweeps(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m
             GF2_SP_LAUNCH(4);
 #undef GF2_SP_LAUNCH
         const dim3 grid((unsigned)gf2_cdiv(m, rows_wg), (unsigned)chunks, (unsigned)batch);
-        hipLaunchKernelGGL((rref_sweep_update_kernel<K, TH>), grid, dim3(TH), 128 * 1024, on, work, m, ld, rows_wg, states, (const u64*)dco,
-                           dstride, (const u64*)snap, sstride, pw0, colw, tmp);
+        hipLaunchKernelGGL((rref_sweep_update_kernel<K, TH>), grid, dim3(TH), 128 * 1024, on, work, m, ld, rows_wg, (const SweepState*)states,
+                           states, (const u64*)dco, dstride, (const u64*)snap, sstride, pw0, colw, tmp, 0, -1);
         GF2_HIP(hipGetLastError());
         bool done;
         GF2_TRY(all_done(pw0 + K - 1, &done));
@@ -2346,6 +2570,156 @@ static int launch_rref_sweeps(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m
     return GF2_OK;
 }
 
+// Blocked path for matrices of more than 4096 rows, four panels per sweep, rows streamed (sweep_stream_panel_kernel & co. above),
+// with LOOK-AHEAD: the next sweep's panels run on the high-priority side stream under this sweep's trailing pass.
+//   main | snapshot s | pass s, chunk c only (128-row workgroups) |  pass s, every other chunk                       | snapshot s+1 ...
+//   side |                                        wait . . . . . . | column, (panel, finish) x 4 of sweep s+1, state copy |
+// c = the chunk of 16 words that holds the next sweep's four columns: the pass writes them to the side buffer on the way, and they
+// are all the panels need of the matrix.  The pass reads a COPY of the state taken after its sweep's panels, and the two sweeps in
+// flight use two sets of coefficients, snapshots and pivot-row lists.
+static int launch_rref_sweeps_streamed(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld, int64_t* pivots_dev,
+                                       int64_t cap, int64_t* rank_dev) {
+    constexpr int K = 4, CW = 64 / K, TH = RB_THREADS;
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t abytes = al((size_t)batch * m * ld * 8), pbytes = al((size_t)batch * cap * 4);
+    const size_t sbytes = al((size_t)batch * sizeof(SweepState)), ubytes = al((size_t)batch * m);
+    const size_t dbytes = al((size_t)batch * m * 8), nbytes = al((size_t)batch * 64 * ld * 8);
+    const size_t cbytes = al((size_t)batch * m * K * 8), lbytes = al((size_t)batch * m * 4);
+    const size_t tbytes = al((size_t)batch * 2048 * 8), ubbytes = al((size_t)batch * (K - 1) * 64 * 8), rbytes = al((size_t)batch * K * 64 * 4);
+    const size_t set_bytes = K * (dbytes + nbytes) + rbytes + sbytes;
+    GF2_TRY(gf2_ws_reserve(ctx, 1, abytes + pbytes + sbytes + ubytes + cbytes + dbytes + lbytes + tbytes + ubbytes + 2 * set_bytes));
+    char* q = (char*)ctx->ws[1];
+    u64* tmp = (u64*)q; q += abytes;
+    int32_t* pivrow = (int32_t*)q; q += pbytes;
+    SweepState* states = (SweepState*)q; q += sbytes;
+    unsigned char* used = (unsigned char*)q; q += ubytes;
+    u64* colw = (u64*)q; q += cbytes;
+    u64* cco = (u64*)q; q += dbytes;
+    int32_t* slot_of = (int32_t*)q; q += lbytes;
+    u64* tabs = (u64*)q; q += tbytes;
+    u64* pub = (u64*)q; q += ubbytes;
+    struct SweepSet {
+        u64* e;                                                        // [K][dstride] folded coefficients
+        u64* snap;                                                     // [K][sstride] pivot-row snapshots
+        int32_t* prow;                                                 // [batch][K][64]
+        SweepState* state_copy;                                        // the state after the sweep's last panel
+    } sets[2];
+    for (int k = 0; k < 2; ++k) {
+        sets[k].e = (u64*)q; q += K * dbytes;
+        sets[k].snap = (u64*)q; q += K * nbytes;
+        sets[k].prow = (int32_t*)q; q += rbytes;
+        sets[k].state_copy = (SweepState*)q; q += sbytes;
+    }
+    const int64_t dstride = (int64_t)(dbytes / 8), sstride = (int64_t)(nbytes / 8);
+    hipStream_t s1 = ctx->stream, s2 = ctx->hi;
+    hipEvent_t e_first = ctx->side_ev[0], e_ready = ctx->side_ev[1], e_panels = ctx->side_ev[2];
+    GF2_TRY(gf2_prof_begin(ctx, GF2_K_ELIM));
+    GF2_HIP(hipMemsetAsync(states, 0, sbytes + ubytes, s1));                  // rank = 0, used = 0 ...
+    hipLaunchKernelGGL(sweep_state_init_kernel, dim3((unsigned)gf2_cdiv(batch, 256)), dim3(256), 0, s1, states, batch, n);
+    if (!ctx->lds_optin[6]) {
+        GF2_HIP(hipFuncSetAttribute((const void*)rref_sweep_update_kernel<K, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ctx->lds_optin[6] = true;
+    }
+    if (!ctx->lds_optin[7]) {
+        GF2_HIP(hipFuncSetAttribute((const void*)sweep_finish_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, K * 2048 * 8));
+        ctx->lds_optin[7] = true;
+    }
+    const int64_t panels = gf2_words(n) < ld ? gf2_words(n) : ld;
+    const int64_t chunks = gf2_cdiv(ld, CW);
+    const int64_t sweeps = gf2_cdiv(panels, K);
+    // Rows per update workgroup of a sweep's big launch: ONE round of the chip less some CUs, over the chunks that are still live
+    // (a pass workgroup owns its CU -- 128 KiB of LDS, every register -- so the panel and finish kernels of the next sweep, on the
+    // side stream, run only where no pass workgroup sits: with two rounds of workgroups of 4096 rows on every CU the look-ahead
+    // gained nothing, 30.6 ms with it and 30.8 without).  The chunks left of
+    // the sweep return at once while no pivot-free column has been seen, so the count of live chunks falls as the sweeps go on.
+    const bool ahead = !gf2_flag(ctx, GF2_F_RREF_NO_LOOKAHEAD) && chunks >= 2 && s2 != nullptr;
+    const bool ahead_on = ahead;
+    auto rows_for = [&](int64_t s) -> int64_t {
+        if (ctx->opt[GF2_OPT_RREF_ROWS_WG] >= 64) return ctx->opt[GF2_OPT_RREF_ROWS_WG];
+        // (CUs left to the side stream: 4 / 12 / 24 / 40 / 56 / 72 / 96 of 256 gave 31.5 / 30.1 / 28.0 / 26.4 / 27.5 / 28.7 / 32.2 ms for
+        // the 256 MiB matrix -- profiles/r05_streamed_sweeps.md)
+        const int reserve = ahead_on ? ctx->num_cus * 5 / 32 : 0;
+        const int64_t live = (chunks - s * K / CW - (ahead_on ? 1 : 0)) * batch, cus = (int64_t)ctx->num_cus - reserve;
+        int64_t blocks = live > 0 && cus > live ? cus / live : 1;       // row blocks per chunk: blocks x live workgroups <= cus
+        if (blocks > gf2_cdiv(m, 1024)) blocks = gf2_cdiv(m, 1024);    // (no fewer than 1024 rows each: the tables are built per workgroup)
+        return gf2_cdiv(m, blocks);
+    };
+    // the K panels of sweep `s` into set `ps`, on stream `on`; `work`: where the batch lives (only read when the side buffer is stale)
+    // (The column kernel runs for the first sweep only: afterwards the pass of sweep s always leaves the column words of sweep
+    // s + 1 in the side buffer -- also for a matrix whose sweep found no pivot -- and sweep_finish_kernel resets the scratch.)
+    auto launch_panels = [&](const SweepSet& ps, int64_t s, const u64* work, hipStream_t on) {
+        const int64_t pw0 = s * K;
+        if (s == 0)
+            hipLaunchKernelGGL(sweep_column_kernel, dim3((unsigned)gf2_cdiv(m, 256), (unsigned)batch), dim3(256), 0, on, work, m, ld, pw0, K,
+                               (const SweepState*)states, colw, cco, slot_of);
+        for (int l = 0; l < K; ++l) {
+            hipLaunchKernelGGL(sweep_stream_panel_kernel<K>, dim3((unsigned)batch), dim3(RB_THREADS), 0, on, m, n, ld, pw0, l, pivots_dev, cap,
+                               pivrow, states, used, ps.prow, colw, cco, slot_of, tabs, (const u64*)ps.e, dstride, pub);
+            hipLaunchKernelGGL(sweep_finish_kernel<K>, dim3((unsigned)gf2_cdiv(m, 1024), (unsigned)batch), dim3(1024), K * 2048 * 8, on, m, l,
+                               (const SweepState*)states, colw, cco, slot_of, (const u64*)tabs, ps.e, dstride, (const u64*)pub);
+        }
+        return hipMemcpyAsync(ps.state_copy, states, (size_t)batch * sizeof(SweepState), hipMemcpyDeviceToDevice, on);
+    };
+    auto launch_pass = [&](const SweepSet& ps, int64_t s, u64* work, int64_t c_lo, int64_t c_hi, int64_t skip, int64_t rows, hipStream_t on) {
+        if (c_hi <= c_lo || (c_hi - c_lo == 1 && skip == c_lo)) return;
+        const dim3 grid((unsigned)gf2_cdiv(m, rows), (unsigned)(c_hi - c_lo), (unsigned)batch);
+        hipLaunchKernelGGL((rref_sweep_update_kernel<K, TH>), grid, dim3(TH), 128 * 1024, on, work, m, ld, rows, (const SweepState*)ps.state_copy,
+                           states, (const u64*)ps.e, dstride, (const u64*)ps.snap, sstride, s * K, colw, tmp, (int)c_lo, (int)skip);
+    };
+    auto all_done = [&](int64_t pw_last, bool* done) -> int {
+        *done = false;
+        const int64_t past = (pw_last + 1) * 64 - m;
+        if (!(past >= 0 && pw_last + 1 < panels && (past < 128 * K || past % (128 * K) < 64 * K))) return GF2_OK;
+        std::vector<SweepState> now((size_t)batch);
+        GF2_HIP(hipMemcpyAsync(now.data(), states, (size_t)batch * sizeof(SweepState), hipMemcpyDeviceToHost, s1));
+        GF2_TRY(gf2_stream_wait(s1));
+        *done = true;
+        for (const auto& st : now) *done = *done && st.rank >= m;
+        return GF2_OK;
+    };
+    // sweep 0: nothing to overlap with
+    GF2_HIP(launch_panels(sets[0], 0, a_dev, s1));
+    int64_t last = sweeps - 1;                                          // the last sweep that has work (lowered once every rank is m)
+    for (int64_t s = 0; s <= last; ++s) {
+        const SweepSet& cur = sets[s & 1];
+        const SweepSet& nxt = sets[(s + 1) & 1];
+        u64* work = s == 0 ? a_dev : tmp;                              // the first pass takes the batch to the workspace copy
+        hipLaunchKernelGGL(sweep_snapshot_kernel, dim3((unsigned)(K * 64), (unsigned)batch), dim3(1024), 0, s1, (const u64*)work, m, ld, K,
+                           (const SweepState*)cur.state_copy, (const int32_t*)cur.prow, cur.snap, sstride);
+        if (s == last) {
+            launch_pass(cur, s, work, 0, chunks, -1, rows_for(s), s1);
+            break;
+        }
+        const int64_t cnext = (s + 1) * K / CW;                        // the chunk of the next sweep's columns
+        if (ahead) {
+            launch_pass(cur, s, work, cnext, cnext + 1, -1, 128, s1);
+            GF2_HIP(hipEventRecord(e_first, s1));
+            GF2_HIP(hipStreamWaitEvent(s2, e_first, 0));
+            // the big launch becomes ready together with the first panel kernel, not before it: that one-workgroup kernel cannot
+            // share a CU with a pass workgroup, the side stream has the higher priority and so it finds a CU first
+            GF2_HIP(hipEventRecord(e_ready, s2));
+            GF2_HIP(launch_panels(nxt, s + 1, tmp, s2));
+            GF2_HIP(hipEventRecord(e_panels, s2));
+            GF2_HIP(hipStreamWaitEvent(s1, e_ready, 0));
+            launch_pass(cur, s, work, 0, chunks, cnext, rows_for(s), s1);
+            GF2_HIP(hipStreamWaitEvent(s1, e_panels, 0));
+        } else {
+            launch_pass(cur, s, work, 0, chunks, -1, rows_for(s), s1);
+            GF2_HIP(launch_panels(nxt, s + 1, tmp, s1));
+        }
+        GF2_HIP(hipGetLastError());
+        // (the next sweep's panels have run when the ranks are read: the read-back waits for s1, which has waited for them)
+        bool done;
+        GF2_TRY(all_done((s + 1) * K + K - 1, &done));
+        if (done) last = s + 1;                                        // its panels found the last pivots (or nothing): its pass is still due
+    }
+    hipLaunchKernelGGL(gather_rows_kernel<SweepState>, dim3((unsigned)gf2_cdiv(m, GATHER_ROWS), (unsigned)batch), dim3(256), 0, s1,
+                       (const u64*)tmp, a_dev, (const int32_t*)pivrow, (const SweepState*)states, rank_dev, m, ld, cap);
+    GF2_HIP(hipGetLastError());
+    GF2_TRY(gf2_prof_end(ctx));
+    return GF2_OK;
+}
+
 extern "C" {
 
 // Blocked path.  Workspace: a copy of the batch for the row gather, pivot-row lists, per-matrix state, used flags, and per SET
@@ -2355,8 +2729,12 @@ extern "C" {
 static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m, int64_t n, int64_t ld,
                                int64_t* pivots_dev, int64_t cap, int64_t* rank_dev) {
     const int rpt = (int)gf2_cdiv(m, RB_THREADS);
-    // up to 4096 rows: K panels per sweep (round 5).  Eight rows per lane (up to 8192 rows): a lane's K column words and coefficients
-    // of eight rows do not fit its registers -- 15 ms against 7.8 for four 8192 x 16384 matrices -- so those keep the pair kernels below.
+    // up to 4096 rows: K panels per sweep with the rows' column words and coefficients in registers (round 5; eight rows per lane do
+    // not fit: 15 ms against 7.8 for four 8192 x 16384 matrices, hence the streamed form above)
+    // more than 4096 rows: four panels per sweep with the rows streamed (32768 x 65536: 26.4 ms and half the traffic against the
+    // pair kernels' 39.3; 8192 x 16384 x 4: 5.3 against 7.5); GF2_OPT_RREF_SWEEP_K = 0 keeps the pair kernels below
+    if (rpt > 4 && ctx->opt[GF2_OPT_RREF_SWEEP_K] != 0)
+        return launch_rref_sweeps_streamed(ctx, a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
     if (rpt <= 4 && ctx->opt[GF2_OPT_RREF_SWEEP_K] != 0) {
         // Four panels per sweep where the batch streams from HBM (half the trips: 2.67 against 2.71 ms and half the traffic for 256
         // matrices of 2048 x 4096) and a lane holds at most two rows (with four, the four panels' words and coefficients spill:
