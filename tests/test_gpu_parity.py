@@ -46,6 +46,18 @@ def route():
     context.set_flags(0)
 
 
+@pytest.fixture
+def sweep_k(ctx, request):
+    """Route of the blocked RREF above 4096 rows: None = the default (round 5: four panels per sweep, rows streamed,
+    launch_rref_sweeps_streamed), 0 = round 4's pair kernels (launch_rref_blocked)."""
+    ctx.set_option(_native.OPT_RREF_SWEEP_K, request.param)
+    yield request.param
+    ctx.set_option(_native.OPT_RREF_SWEEP_K, None)
+
+
+TALL_ROUTES = pytest.mark.parametrize("sweep_k", [None, 0], indirect=True, ids=["streamed-sweeps", "pair-kernels"])
+
+
 def test_native_library_is_loaded(ctx):
     assert _native.lib().gf2_version() >= 100
     assert _native.device_count() >= 1
@@ -890,8 +902,9 @@ def test_small_code_fused_and_pipeline_agree(rm15, steane_h, route):
             assert int(fused['hist_z'].sum()) == 200000
 
 
-def test_rref_more_than_8192_rows_streaming_panel_kernel(ctx):
-    # m > 8192 takes the streamed panel kernel; dependent rows and pivot-free column stripes force extra rounds
+@TALL_ROUTES
+def test_rref_more_than_8192_rows_streaming_panel_kernel(ctx, sweep_k):
+    # m > 8192 takes the streamed panel kernels; dependent rows and pivot-free column stripes force extra rounds
     m, n = 8300, 9100
     rng = np.random.default_rng(83)
     a = rng.integers(0, 2, (m, n), dtype=np.uint8)
@@ -907,10 +920,12 @@ def test_rref_more_than_8192_rows_streaming_panel_kernel(ctx):
     assert np.array_equal(packed, want)
 
 
+@TALL_ROUTES
 @pytest.mark.parametrize("case", ["dependent rows, odd number of panels", "full rank, done half way"])
-def test_rref_streamed_panels_with_look_ahead(case, ctx, route):
-    # more than 8192 rows and several column chunks of 32 words: the next pair's panels run on a side stream under the trailing
-    # pass of this pair (launch_rref_blocked); same matrix, pivots and rank as the oracle and as the run without look-ahead
+def test_rref_streamed_panels_with_look_ahead(case, ctx, route, sweep_k):
+    # more than 8192 rows and several column chunks: the next sweep's (pair's) panels run on a side stream under the trailing
+    # pass of this one (launch_rref_sweeps_streamed / launch_rref_blocked); same matrix, pivots and rank as the oracle and as
+    # the run without look-ahead
     rng = np.random.default_rng(8400)
     if case.startswith("dependent"):
         m, n = 8300, 16400                       # 257 panels: the last pair has one; the rank never reaches m, every panel runs
@@ -939,7 +954,8 @@ def test_rref_streamed_panels_with_look_ahead(case, ctx, route):
     assert rank2 == want_rank and list(pivots2) == list(want_piv) and np.array_equal(plain, want)
 
 
-def test_rref_look_ahead_on_a_batch_of_two_tall_matrices(ctx, route):
+@TALL_ROUTES
+def test_rref_look_ahead_on_a_batch_of_two_tall_matrices(ctx, route, sweep_k):
     # the look-ahead's state copies, coefficient sets and snapshots are per matrix: two different 8300-row matrices in one call
     m, n, batch = 8300, 8200, 2
     rng = np.random.default_rng(2)
@@ -958,7 +974,8 @@ def test_rref_look_ahead_on_a_batch_of_two_tall_matrices(ctx, route):
         assert np.array_equal(got[b], want[b][0])
 
 
-def test_rref_256_mib_matrix_with_and_without_look_ahead(ctx, route):
+@TALL_ROUTES
+def test_rref_256_mib_matrix_with_and_without_look_ahead(ctx, route, sweep_k):
     # bench.py's 32768 x 65536 matrix: too large for the CPU oracle, so the size-independent properties -- the run with look-ahead
     # (the default at this size) and the run without it return the same bytes, the rank is full, the pivot columns ascend, the
     # pivot columns of the result form an identity, and rows of the input lie in the row space of the result (spot-checked
@@ -1884,3 +1901,39 @@ def test_rref_sweep_routes(shape, k, ctx):
         ctx.set_flags(flags)
         ctx.set_option(_native.OPT_RREF_SWEEP_K, None)
         ctx.set_option(_native.OPT_RREF_ROWS_WG, None)
+
+
+@pytest.mark.parametrize("shape", [(4100, 700, 2), (5000, 5100, 3), (8200, 8300, 2), (9000, 2000, 1), (4500, 4600, 7), (4097, 65, 2)])
+def test_rref_streamed_sweeps_on_tall_matrices(shape, ctx, route):
+    # Round 5: more than 4096 rows take four panels per sweep with the rows STREAMED (sweep_column / sweep_stream_panel / sweep_finish /
+    # sweep_snapshot kernels + the K = 4 trailing pass), the next sweep's panels on a side stream under the pass.  Mixed batches as in
+    # test_rref_sweep_routes -- dense, sparse (several window rounds per panel), leading pivot-free panels (a sweep without pivots:
+    # sweep_column_kernel refills the side buffer), duplicated halves (rank deficient: every sweep runs), every other column zero --
+    # with and without look-ahead, and with the pair kernels (K = 0) beside them: oracle's matrices, pivots, ranks (bin_matrix.py:8-34).
+    m, n, batch = shape
+    rng = np.random.default_rng(m * 13 + n + batch)
+    mats = []
+    for b in range(batch):
+        a = (rng.random((m, n)) < (0.5 if b % 3 != 1 else 0.02)).astype(np.uint8)
+        if b % 4 == 2:
+            a[:, :min(n, 300)] = 0
+        if b % 5 == 3:
+            a[m // 2:] = a[: m - m // 2]
+        if b % 7 == 6:
+            a[:, ::2] = 0
+        mats.append(a)
+    want = [c_oracle.rref(c_oracle.pack_rows(a), m, n) for a in mats]
+    try:
+        for k, flag in ((None, None), (None, "GF2_RREF_NO_LOOKAHEAD"), (0, None)):
+            ctx.set_option(_native.OPT_RREF_SWEEP_K, k)
+            if flag:
+                route.force(flag)
+            packed = np.stack([_native.pack_rows(a) for a in mats])
+            pivots, ranks = ctx.rref_batch(packed, batch, m, n)
+            if flag:
+                route.release(flag)
+            for b in range(batch):
+                assert ranks[b] == want[b][2] and np.array_equal(packed[b], want[b][0]), (k, flag, b)
+                assert list(pivots[b, :want[b][2]]) == list(want[b][1]), (k, flag, b)
+    finally:
+        ctx.set_option(_native.OPT_RREF_SWEEP_K, None)
