@@ -28,7 +28,7 @@ K_SYNDROME, K_HIST, K_SAMPLER, K_ELIM = 0, 1, 2, 3
  F_DIAG_MC_TIMES, F_MC_ROWS, F_COMBINE_FOLDED, F_RREF_NO_LOOKAHEAD, F_RREF_LOOKAHEAD, F_COMBINE_SEPARATE) = (1 << k for k in range(19))
 (OPT_SLAB_PASS_LOG2, OPT_COMBINE_BLOCKS, OPT_GATHER_REVERSE, OPT_REDO_BLOCKS_PER_CU, OPT_MC_CHUNK_LOG2, OPT_COMBINE_THREADS,
  OPT_GATHER_CROSS, OPT_GATHER_OVER, OPT_RREF_SMALL_BCAST, OPT_MC_SAMPLER_WAVES,
- OPT_MC_TAIL_CAP, OPT_RREF_RESERVED0, OPT_RREF_ROWS_WG, OPT_RREF_SWEEP_K) = range(14)
+ OPT_MC_TAIL_CAP, OPT_RREF_STREAM_VARIANT, OPT_RREF_ROWS_WG, OPT_RREF_SWEEP_K) = range(14)
 
 
 class GF2Error(RuntimeError):

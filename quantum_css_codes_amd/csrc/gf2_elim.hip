@@ -1255,8 +1255,8 @@ __global__ __launch_bounds__(RB_THREADS) void rref_sweep_panel_kernel(const u64*
 //          half they would meet two and two on the same banks, so lanes 16-31 and 48-63 take the panels of a pair in the other
 //          order (XOR does not care) and every group covers the 64 banks once.
 template <int K, int TH>
-__device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, const int64_t chunk, const int64_t rowblock, const unsigned int unit,
-                                                  u64* base, int64_t m, int64_t ld, int64_t rows_per_wg,
+__device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, const int64_t chunk, const int64_t r_lo, const int64_t row_end,
+                                                  const unsigned int unit, u64* base, int64_t m, int64_t ld,
                                                   const SweepState* __restrict__ states, SweepState* __restrict__ live,
                                                   const u64* __restrict__ d_base,
                                                   int64_t dstride, const u64* __restrict__ snap_base,
@@ -1283,8 +1283,6 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
     const bool moving = out_base != base;                              // uniform
     const int64_t cw0 = chunk * CW;
     const int wc_n = ld - cw0 < CW ? (int)(ld - cw0) : CW;
-    const int64_t r_lo = rowblock * rows_per_wg;
-    const int64_t row_end = r_lo + rows_per_wg < m ? r_lo + rows_per_wg : m;
     u64* a = base + mat * m * ld;
     u64* a_out = out_base + mat * m * ld;
     // the next sweep's K column words, if this chunk holds them: they leave for the side buffer with the rows
@@ -1303,7 +1301,7 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
                 if (moving) a_out[row * ld + cw0 + wd] = v;
                 if (emits && cw0 + wd >= pw_next && cw0 + wd < pw_next + K) colw[row * K + (cw0 + wd - pw_next)] = v;
             }
-            if (emits && tid == 0 && rowblock == 0) live[mat].colw_pw = pw_next;
+            if (emits && tid == 0 && r_lo == 0) live[mat].colw_pw = pw_next;
         }
         return;
     }
@@ -1360,10 +1358,9 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
                 colw[row * K + (hw2 - emit_lo) + 1] = x1;
             }
         }
-        if (emits && tid == 0 && rowblock == 0) live[mat].colw_pw = pw_next;
+        if (emits && tid == 0 && r_lo == 0) live[mat].colw_pw = pw_next;
         return;
     }
-    typedef const __attribute__((address_space(3))) u64* lds_u64_ptr;
     // byte offset of panel j's table (see above)
     auto tbase = [](int j) -> unsigned int { return K == 2 ? (unsigned int)j * 65536u : (unsigned int)(j >> 1) * 65536u + (unsigned int)(j & 1) * 128u; };
     // the 16 XOR combinations of a group's four rows (entries 1, 2, 4, 8 are the single rows): a lane takes (group, word) and the
@@ -1501,7 +1498,7 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
         load2(rb + 2 * STEP, s0);
         if (rb + STEP < row_end) work2(rb + STEP, s1);                 // uniform
     }
-    if (emits && tid == 0 && rowblock == 0) live[mat].colw_pw = pw_next;
+    if (emits && tid == 0 && r_lo == 0) live[mat].colw_pw = pw_next;
 #if GF2_SWEEP_DIAG
     if (tid == 0) {
         const u64 diag_c2 = clock64(), diag_w2 = wall_clock64();
@@ -1543,8 +1540,9 @@ __global__ __launch_bounds__(TH) void rref_sweep_update_kernel(u64* base, int64_
     const int chunk = (int)blockIdx.y + chunk_base;
     if (chunk == chunk_skip) return;
     const unsigned int unit = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    sweep_update_unit<K, TH>(T, blockIdx.z, chunk, blockIdx.x, unit, base, m, ld, rows_per_wg, states, live, d_base, dstride, snap_base,
-                             sstride, pw0, colw_base, out_base);
+    const int64_t r_lo = (int64_t)blockIdx.x * rows_per_wg;
+    sweep_update_unit<K, TH>(T, blockIdx.z, chunk, r_lo, r_lo + rows_per_wg < m ? r_lo + rows_per_wg : m, unit, base, m, ld, states, live, d_base,
+                             dstride, snap_base, sstride, pw0, colw_base, out_base);
 }
 
 // ---- the same sweeps for matrices of more than 4096 rows: rows streamed, not held in registers -----------------------------------
@@ -2634,11 +2632,17 @@ static int launch_rref_sweeps_streamed(gf2_ctx* ctx, u64* a_dev, int64_t batch, 
     // the sweep return at once while no pivot-free column has been seen, so the count of live chunks falls as the sweeps go on.
     const bool ahead = !gf2_flag(ctx, GF2_F_RREF_NO_LOOKAHEAD) && chunks >= 2 && s2 != nullptr;
     const bool ahead_on = ahead;
+    // development switches (GF2_OPT_RREF_STREAM_VARIANT): bit 0 = the big launch waits until the side stream has started (as first
+    // built: 27.0 ms for the 256 MiB matrix against 25.8 without the wait -- with CUs left free the one-workgroup panel kernel finds
+    // its place anyway, and the wait is a second cross-queue hand-over of ~20 us per sweep), bits 8.. = CUs left to the side stream + 1
+    const int64_t variant = ctx->opt[GF2_OPT_RREF_STREAM_VARIANT] < 0 ? 0 : ctx->opt[GF2_OPT_RREF_STREAM_VARIANT];
+    const bool wait_ready = (variant & 1) != 0;
+    const int reserve_cus = (variant >> 8) > 0 ? (int)(variant >> 8) - 1 : ctx->num_cus * 5 / 32;
     auto rows_for = [&](int64_t s) -> int64_t {
         if (ctx->opt[GF2_OPT_RREF_ROWS_WG] >= 64) return ctx->opt[GF2_OPT_RREF_ROWS_WG];
         // (CUs left to the side stream: 4 / 12 / 24 / 40 / 56 / 72 / 96 of 256 gave 31.5 / 30.1 / 28.0 / 26.4 / 27.5 / 28.7 / 32.2 ms for
         // the 256 MiB matrix -- profiles/r05_streamed_sweeps.md)
-        const int reserve = ahead_on ? ctx->num_cus * 5 / 32 : 0;
+        const int reserve = ahead_on ? reserve_cus : 0;
         const int64_t live = (chunks - s * K / CW - (ahead_on ? 1 : 0)) * batch, cus = (int64_t)ctx->num_cus - reserve;
         int64_t blocks = live > 0 && cus > live ? cus / live : 1;       // row blocks per chunk: blocks x live workgroups <= cus
         if (blocks > gf2_cdiv(m, 1024)) blocks = gf2_cdiv(m, 1024);    // (no fewer than 1024 rows each: the tables are built per workgroup)
@@ -2697,10 +2701,10 @@ static int launch_rref_sweeps_streamed(gf2_ctx* ctx, u64* a_dev, int64_t batch, 
             GF2_HIP(hipStreamWaitEvent(s2, e_first, 0));
             // the big launch becomes ready together with the first panel kernel, not before it: that one-workgroup kernel cannot
             // share a CU with a pass workgroup, the side stream has the higher priority and so it finds a CU first
-            GF2_HIP(hipEventRecord(e_ready, s2));
+            if (wait_ready) GF2_HIP(hipEventRecord(e_ready, s2));
             GF2_HIP(launch_panels(nxt, s + 1, tmp, s2));
             GF2_HIP(hipEventRecord(e_panels, s2));
-            GF2_HIP(hipStreamWaitEvent(s1, e_ready, 0));
+            if (wait_ready) GF2_HIP(hipStreamWaitEvent(s1, e_ready, 0));
             launch_pass(cur, s, work, 0, chunks, cnext, rows_for(s), s1);
             GF2_HIP(hipStreamWaitEvent(s1, e_panels, 0));
         } else {
