@@ -1227,15 +1227,40 @@ __global__ __launch_bounds__(RB_THREADS) void rref_sweep_panel_kernel(const u64*
             for (int l = 0; l < K; ++l) d_base[(int64_t)l * dstride + mat * m + row] = e_all[l][k];   // (zero for a panel that found nothing)
         }
     }
-    // snapshots of the pivot rows as they stand in memory (the trailing pass overwrites them)
+    // snapshots of the pivot rows as they stand in memory (the trailing pass overwrites them).  The K panels' rows as ONE list of
+    // 16-byte pieces, four loads in flight per lane before the first store: written as a load-store loop per panel this was sixteen
+    // dependent round trips to memory for a 2048 x 4096 matrix (17 of the launch's 104 us with 256 matrices in flight, 4 of 36 alone).
+    if ((ld & 1) == 0 && (int64_t)K * 64 * (ld >> 1) < (1ll << 31)) {
+        const unsigned int pl = (unsigned int)(ld >> 1), per_panel = 64u * pl, total = (unsigned int)K * per_panel;
+        for (unsigned int base = tid; base < total; base += 4 * RB_THREADS) {
+            u32x4_t v[4];
+            unsigned int dst[4];
+            bool on[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned int idx = base + (unsigned int)u * RB_THREADS;
+                const unsigned int l = idx / per_panel, rest = idx - l * per_panel, q = rest / pl, pc = rest - q * pl;
+                on[u] = idx < total && (int)q < tj[l < (unsigned int)K ? l : 0];
+                dst[u] = idx;
+                if (on[u]) v[u] = *reinterpret_cast<const u32x4_t*>(a + (int64_t)prow_all[l][q] * ld + 2 * pc);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!on[u]) continue;
+                const unsigned int l = dst[u] / per_panel, rest = dst[u] - l * per_panel;
+                *reinterpret_cast<u32x4_t*>(snap_base + (int64_t)l * sstride + mat * 64 * ld + 2 * (int64_t)rest) = v[u];
+            }
+        }
+    } else {
 #pragma unroll 1
-    for (int l = 0; l < K; ++l) {
-        u64* snap = snap_base + (int64_t)l * sstride + mat * 64 * ld;
-        const int tl = tj[l];
-        for (int64_t idx = tid; idx < (int64_t)tl * ld; idx += RB_THREADS) {
-            const int q = (int)(idx / ld);
-            const int64_t wd = idx - (int64_t)q * ld;
-            snap[idx] = a[(int64_t)prow_all[l][q] * ld + wd];
+        for (int l = 0; l < K; ++l) {
+            u64* snap = snap_base + (int64_t)l * sstride + mat * 64 * ld;
+            const int tl = tj[l];
+            for (int64_t idx = tid; idx < (int64_t)tl * ld; idx += RB_THREADS) {
+                const int q = (int)(idx / ld);
+                const int64_t wd = idx - (int64_t)q * ld;
+                snap[idx] = a[(int64_t)prow_all[l][q] * ld + wd];
+            }
         }
     }
     GF2_STAMP(5);                                                      // state, coefficients out, snapshots
@@ -2508,6 +2533,8 @@ static int launch_rref_sweeps(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m
         for (const auto& st : now) *done = *done && st.rank >= m;
         return GF2_OK;
     };
+    // (A panel workgroup alone on its CU -- 40 or 90 KiB of unused dynamic LDS so that no second one fits -- changes nothing: 2.61 -
+    // 2.65 ms against 2.64 - 2.66 for 256 matrices of 2048 x 4096; the panel kernel's phases are latency, not contention.)
     for (int64_t s = 0; s < sweeps; ++s) {
         const int64_t pw0 = s * K;
         u64* work = s == 0 ? a_dev : tmp;                              // the first pass takes the batch to the workspace copy
