@@ -81,6 +81,26 @@ def test_fuzz_rref_batches(ctx):
         assert np.array_equal(again, packed) and np.array_equal(ranks2, ranks), "case %d: %d x %d, four pivots at a time" % (case, m, n)
 
 
+def test_fuzz_rref_tall_matrices(ctx):
+    # more than 4096 rows: the streamed K = 4 sweeps with look-ahead (round 5), batches of unequal matrices, padded leading
+    # dimensions, column counts around the word, the panel, the sweep of four panels and the 16-word chunk of the trailing pass
+    rng = np.random.default_rng(20265)
+    cols = (1, 63, 64, 65, 255, 256, 257, 300, 1023, 1024, 1025, 1100, 2100)
+    for case in range(14):
+        m = int(rng.choice([4097, 4100, 5000, 6143, 8192, 8193, 9001]))
+        n = int(rng.choice(cols))
+        batch = int(rng.integers(1, 4))
+        pad = int(rng.integers(0, 3))
+        mats = [random_matrix(rng, m, n, float(rng.choice([0.003, 0.3, 0.5, 1.0])), pad_words=pad)[1] for _ in range(batch)]
+        packed = np.stack(mats)
+        want = [c_oracle.rref(mat, m, n) for mat in mats]
+        pivots, ranks = ctx.rref_batch(packed, batch, m, n)
+        for b in range(batch):
+            label = "case %d matrix %d: %d x %d, ld %d" % (case, b, m, n, packed.shape[2])
+            assert ranks[b] == want[b][2] and np.array_equal(packed[b], want[b][0]), label
+            assert list(pivots[b, : want[b][2]]) == list(want[b][1]), label
+
+
 def test_fuzz_normalize(ctx):
     rng = np.random.default_rng(20262)
     done = 0
