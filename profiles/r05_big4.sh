@@ -1,0 +1,4 @@
+root=$(pwd); out=$root/gpurun_out/r05; mkdir -p $out
+bash profiles/r05_trace.sh "32768 65536 1 -1" big_head2 > /dev/null || exit 1
+python3 profiles/r05_timeline.py $(find $out/tr_big_head2 -name '*kernel_trace.csv') 100000 > $out/big_head2_timeline.txt
+tail -1 $out/big_head2_timeline.txt
