@@ -2684,9 +2684,11 @@ static int launch_rref_sweeps_streamed(gf2_ctx* ctx, u64* a_dev, int64_t batch, 
     const bool ahead_on = ahead;
     // development switches (GF2_OPT_RREF_STREAM_VARIANT): bit 0 = the big launch waits until the side stream has started (as first
     // built: 27.0 ms for the 256 MiB matrix against 25.8 without the wait -- with CUs left free the one-workgroup panel kernel finds
-    // its place anyway, and the wait is a second cross-queue hand-over of ~20 us per sweep), bits 8.. = CUs left to the side stream + 1
+    // its place anyway, and the wait is a second cross-queue hand-over of ~20 us per sweep), bits 1-2 = which of the two takes the
+    // side stream (below), bits 8.. = CUs left to the side stream + 1
     const int64_t variant = ctx->opt[GF2_OPT_RREF_STREAM_VARIANT] < 0 ? 0 : ctx->opt[GF2_OPT_RREF_STREAM_VARIANT];
     const bool wait_ready = (variant & 1) != 0;
+    const int swap_mode = (int)((variant >> 1) & 3);                  // 0: by the estimate, 1: panels always on the side stream, 2: the pass always
     const int reserve_cus = (variant >> 8) > 0 ? (int)(variant >> 8) - 1 : ctx->num_cus * 5 / 32;
     auto rows_for = [&](int64_t s) -> int64_t {
         if (ctx->opt[GF2_OPT_RREF_ROWS_WG] >= 64) return ctx->opt[GF2_OPT_RREF_ROWS_WG];
@@ -2749,13 +2751,18 @@ static int launch_rref_sweeps_streamed(gf2_ctx* ctx, u64* a_dev, int64_t batch, 
             launch_pass(cur, s, work, cnext, cnext + 1, -1, 128, s1);
             GF2_HIP(hipEventRecord(e_first, s1));
             GF2_HIP(hipStreamWaitEvent(s2, e_first, 0));
-            // the big launch becomes ready together with the first panel kernel, not before it: that one-workgroup kernel cannot
-            // share a CU with a pass workgroup, the side stream has the higher priority and so it finds a CU first
-            if (wait_ready) GF2_HIP(hipEventRecord(e_ready, s2));
-            GF2_HIP(launch_panels(nxt, s + 1, tmp, s2));
-            GF2_HIP(hipEventRecord(e_panels, s2));
-            if (wait_ready) GF2_HIP(hipStreamWaitEvent(s1, e_ready, 0));
-            launch_pass(cur, s, work, 0, chunks, cnext, rows_for(s), s1);
+            // Whatever goes to the other queue starts ~20 us late (the hand-over).  While the pass is the longer of the two, that is the
+            // panels; once the panels' chain (K x (panel + finish) ~ 110 us) outlasts the pass -- the later sweeps of a big matrix, every
+            // sweep of a batch of matrices of 8192 rows -- the chain stays on this stream and the big launch takes the hand-over.
+            const int64_t rows_big = rows_for(s);
+            const bool chain_here = swap_mode == 2 || (swap_mode == 0 && rows_big * 18 / 1000 + 22 < K * 26 + 24);   // (18 ns per row, 26 us per panel)
+            hipStream_t s_chain = chain_here ? s1 : s2, s_pass = chain_here ? s2 : s1;
+            if (wait_ready && !chain_here) GF2_HIP(hipEventRecord(e_ready, s2));
+            GF2_HIP(launch_panels(nxt, s + 1, tmp, s_chain));
+            if (!chain_here) GF2_HIP(hipEventRecord(e_panels, s2));
+            if (wait_ready && !chain_here) GF2_HIP(hipStreamWaitEvent(s1, e_ready, 0));
+            launch_pass(cur, s, work, 0, chunks, cnext, rows_big, s_pass);
+            if (chain_here) GF2_HIP(hipEventRecord(e_panels, s2));
             GF2_HIP(hipStreamWaitEvent(s1, e_panels, 0));
         } else {
             launch_pass(cur, s, work, 0, chunks, -1, rows_for(s), s1);
