@@ -16,6 +16,8 @@ ctx.set_option(13, k)
 ctx.set_option(12, rows_wg)
 variant = int(sys.argv[6]) if len(sys.argv) > 6 else -1
 ctx.set_option(11, variant)
+if len(sys.argv) > 7:
+    ctx.set_flags(ctx.get_flags() | int(sys.argv[7], 0))        # e.g. 0x10000 = GF2_F_RREF_NO_LOOKAHEAD
 rng = np.random.default_rng(4096)
 ld = (n + 63) // 64
 mats = [(rng.integers(0, 2**63, (m, ld), dtype=np.int64).view(np.uint64) << np.uint64(1)) |

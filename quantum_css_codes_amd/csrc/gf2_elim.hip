@@ -1571,6 +1571,43 @@ __global__ __launch_bounds__(TH) void rref_sweep_update_kernel(u64* base, int64_
                              dstride, snap_base, sstride, pw0, colw_base, out_base);
 }
 
+// The streamed path's big launch as a ONE-dimensional grid: workgroups 0 .. blocks * n_live * batch - 1 are the live ones (chunks from
+// c_first on, but chunk_skip), the chunks left of c_first -- which return at once unless their matrix has seen a pivot-free
+// column -- come after them.  Workgroups go to the XCDs in turn, in grid order: with the live ones first and in one run every XCD
+// holds at most ceil(live workgroups / 8) of them, and the launcher can count the CUs each XCD has left for the next sweep's panels.
+// (As a grid of row blocks x all chunks x matrices, the dead chunks' workgroups took part in the rotation: with four row blocks the
+// even chunks' workgroups all went to XCDs 0-3, and a finish workgroup sent to a full XCD waited for the whole pass, 143 us.)
+template <int K, int TH>
+__global__ __launch_bounds__(TH) void rref_sweep_update_flat_kernel(u64* base, int64_t m, int64_t ld, int64_t rows_per_wg, int blocks,
+                                                                    int chunks, int c_first, int chunk_skip,
+                                                                    const SweepState* __restrict__ states, SweepState* __restrict__ live,
+                                                                    const u64* __restrict__ d_base, int64_t dstride,
+                                                                    const u64* __restrict__ snap_base, int64_t sstride, int64_t pw0,
+                                                                    u64* __restrict__ colw_base, u64* out_base, int batch) {
+    extern __shared__ __attribute__((aligned(16))) u64 T[];
+    const int n_live = chunks - c_first - 1;                           // (chunk_skip lies in [c_first, chunks))
+    const unsigned int live_wgs = (unsigned int)(blocks * n_live * batch);
+    unsigned int id = blockIdx.x;
+    int x, chunk, mat;
+    if (id < live_wgs) {
+        x = (int)(id % (unsigned int)blocks);
+        const unsigned int yz = id / (unsigned int)blocks;
+        chunk = c_first + (int)(yz % (unsigned int)n_live);
+        if (chunk >= chunk_skip) ++chunk;
+        mat = (int)(yz / (unsigned int)n_live);
+    } else {
+        id -= live_wgs;
+        x = (int)(id % (unsigned int)blocks);
+        const unsigned int yz = id / (unsigned int)blocks;
+        chunk = (int)(yz % (unsigned int)c_first);
+        mat = (int)(yz / (unsigned int)c_first);
+    }
+    const int64_t r_lo = (int64_t)x * rows_per_wg;
+    if (r_lo >= m) return;
+    sweep_update_unit<K, TH>(T, mat, chunk, r_lo, r_lo + rows_per_wg < m ? r_lo + rows_per_wg : m, blockIdx.x, base, m, ld, states, live, d_base,
+                             dstride, snap_base, sstride, pw0, colw_base, out_base);
+}
+
 // ---- the same sweeps for matrices of more than 4096 rows: rows streamed, not held in registers -----------------------------------
 //
 // A lane cannot hold the K column words and coefficients of more than four of its rows, so above 4096 rows the right-looking sweep
@@ -1757,7 +1794,7 @@ __global__ __launch_bounds__(RB_THREADS) void sweep_stream_panel_kernel(int64_t 
     }
 }
 
-// The rest of a streamed panel, one row per lane on as many workgroups as there are rows for (see above).  Dynamic LDS: K tables.
+// The rest of a streamed panel, a row per lane and trip, on as many workgroups as the launcher finds CUs for (see above).  Dynamic LDS: K tables.
 template <int K>
 __global__ __launch_bounds__(1024) void sweep_finish_kernel(int64_t m, int l, const SweepState* __restrict__ states,
                                                             u64* __restrict__ colw_base, u64* __restrict__ cco_base,
@@ -1765,11 +1802,11 @@ __global__ __launch_bounds__(1024) void sweep_finish_kernel(int64_t m, int l, co
                                                             u64* __restrict__ e_base, int64_t dstride, const u64* __restrict__ pub_base) {
     extern __shared__ __attribute__((aligned(16))) u64 FT[];           // [0]: the last round's table, [1 .. K - 1]: the published vectors'
     const int64_t mat = blockIdx.y;
-    const int64_t row = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * 1024 + threadIdx.x, stride = (int64_t)gridDim.x * 1024;   // rows row0, row0 + stride, ...
     const int t = states[mat].tg[l], pending = states[mat].pending;
     u64* el = e_base + (int64_t)l * dstride + mat * m;
     if (t == 0) {                                                       // the pass reads the panel's coefficients all the same
-        if (row < m) el[row] = 0ull;
+        for (int64_t row = row0; row < m; row += stride) el[row] = 0ull;
         return;
     }
     __shared__ u64 pv_s[(K - 1) * 64];
@@ -1785,15 +1822,16 @@ __global__ __launch_bounds__(1024) void sweep_finish_kernel(int64_t m, int l, co
         FT[2048 + idx] = x;
     }
     __syncthreads();
-    if (row >= m) return;
-    u64* w = colw_base + (mat * m + row) * K;
-    u64 d = cco_base[mat * m + row];
-    if (pending && slot_base[mat * m + row] != -2) d ^= byte_lookup(FT, w[l]);
-    el[row] = d;
-    for (int j = l + 1; j < K; ++j) w[j] ^= byte_lookup(FT + 2048 * (j - l), d);
-    for (int l2 = 0; l2 < l; ++l2) e_base[(int64_t)l2 * dstride + mat * m + row] ^= byte_lookup(FT + 2048 * (K - l + l2), d);
-    cco_base[mat * m + row] = 0;
-    slot_base[mat * m + row] = -1;
+    for (int64_t row = row0; row < m; row += stride) {
+        u64* w = colw_base + (mat * m + row) * K;
+        u64 d = cco_base[mat * m + row];
+        if (pending && slot_base[mat * m + row] != -2) d ^= byte_lookup(FT, w[l]);
+        el[row] = d;
+        for (int j = l + 1; j < K; ++j) w[j] ^= byte_lookup(FT + 2048 * (j - l), d);
+        for (int l2 = 0; l2 < l; ++l2) e_base[(int64_t)l2 * dstride + mat * m + row] ^= byte_lookup(FT + 2048 * (K - l + l2), d);
+        cco_base[mat * m + row] = 0;
+        slot_base[mat * m + row] = -1;
+    }
 }
 
 // The sweep's pivot rows as they stand in memory, for the pass: workgroup (64 l + q, matrix) copies pivot row q of panel l.
@@ -2689,29 +2727,86 @@ static int launch_rref_sweeps_streamed(gf2_ctx* ctx, u64* a_dev, int64_t batch, 
     const int64_t variant = ctx->opt[GF2_OPT_RREF_STREAM_VARIANT] < 0 ? 0 : ctx->opt[GF2_OPT_RREF_STREAM_VARIANT];
     const bool wait_ready = (variant & 1) != 0;
     const int swap_mode = (int)((variant >> 1) & 3);                  // 0: by the estimate, 1: panels always on the side stream, 2: the pass always
-    const int reserve_cus = (variant >> 8) > 0 ? (int)(variant >> 8) - 1 : ctx->num_cus * 5 / 32;
-    auto rows_for = [&](int64_t s) -> int64_t {
-        if (ctx->opt[GF2_OPT_RREF_ROWS_WG] >= 64) return ctx->opt[GF2_OPT_RREF_ROWS_WG];
-        // (CUs left to the side stream: 4 / 12 / 24 / 40 / 56 / 72 / 96 of 256 gave 31.5 / 30.1 / 28.0 / 26.4 / 27.5 / 28.7 / 32.2 ms for
-        // the 256 MiB matrix -- profiles/r05_streamed_sweeps.md)
-        const int reserve = ahead_on ? reserve_cus : 0;
-        const int64_t live = (chunks - s * K / CW - (ahead_on ? 1 : 0)) * batch, cus = (int64_t)ctx->num_cus - reserve;
-        int64_t blocks = live > 0 && cus > live ? cus / live : 1;       // row blocks per chunk: blocks x live workgroups <= cus
-        if (blocks > gf2_cdiv(m, 1024)) blocks = gf2_cdiv(m, 1024);    // (no fewer than 1024 rows each: the tables are built per workgroup)
-        return gf2_cdiv(m, blocks);
+    const int reserve_forced = (variant >> 8) > 0 ? (int)(variant >> 8) - 1 : -1;
+    // The big launch of sweep s: ONE round of workgroups of whole row blocks (every workgroup of a row block walks the same rows at the
+    // same time: HBM sees whole rows), each owning its CU, on all CUs but `reserve`; the next sweep's panels run on the CUs it leaves.
+    // The reserve is chosen per sweep from a small model (18 ns per row and workgroup + 10 us of tables; a panel 17 us; a finish
+    // launch 6 us + 2.5 us per trip of its lanes over the rows; 20 us for whichever of the two waits on the other queue): few CUs
+    // left free mean fewer, longer finish workgroups, and pay while the pass is the longer of the two.  (First build, 40 CUs fixed
+    // and 32 finish workgroups: 4 / 12 / 24 / 40 / 56 / 72 / 96 CUs gave 31.5 / 30.1 / 28.0 / 26.4 / 27.5 / 28.7 / 32.2 ms for the
+    // 256 MiB matrix -- profiles/r05_streamed_sweeps.md.)
+    struct Plan {
+        int64_t rows, blocks;
+        int64_t finish_wgs;                                            // per matrix; 0: as many as there are rows for
+        bool chain_here;                                               // the panels' chain stays on the main stream, the big launch goes aside
+        bool flat;                                                     // the big launch as rref_sweep_update_flat_kernel
     };
+    const int xcds = ctx->num_cus % 8 == 0 ? 8 : 1, cus_xcd = ctx->num_cus / xcds;
+    auto plan_for = [&](int64_t s) -> Plan {
+        Plan best{m, 1, 0, false, false};
+        const int64_t max_blocks = gf2_cdiv(m, 1024);                  // (no fewer than 1024 rows each: the tables are built per workgroup)
+        const int64_t live = (chunks - s * K / CW - (ahead_on ? 1 : 0)) * batch;
+        if (ctx->opt[GF2_OPT_RREF_ROWS_WG] >= 64 || !ahead_on || live <= 0) {
+            int64_t blocks = live > 0 && ctx->num_cus > live ? ctx->num_cus / live : 1;
+            if (blocks > max_blocks) blocks = max_blocks;
+            best.rows = ctx->opt[GF2_OPT_RREF_ROWS_WG] >= 64 ? ctx->opt[GF2_OPT_RREF_ROWS_WG] : gf2_cdiv(m, blocks);
+            best.blocks = gf2_cdiv(m, best.rows);
+            best.chain_here = swap_mode == 2;
+            return best;
+        }
+        int64_t best_cost = -1;
+        // CUs every XCD keeps for the other stream: 5 of 32.  Fewer lose although the pass gets shorter (252 workgroups: 158 us against
+        // 200 with 189): the panel kernel or a finish workgroup then finds no CU on its XCD and waits for the whole pass (150 us) --
+        // 1 / 2 / 3 / 5 / 7 per XCD: 27.6 / 26.9 / 25.7 / 23.7 / 25.1 ms for the 256 MiB matrix, also with the live workgroups first
+        // in a one-dimensional grid (the flat kernel) and finish launches cut to the CUs left.
+        for (int left = 5; left <= 5; ++left) {
+            if (reserve_forced >= 0) left = reserve_forced / xcds > 0 ? reserve_forced / xcds : 1;
+            const int64_t cap_wgs = (int64_t)xcds * (cus_xcd - left);
+            int64_t blocks = cap_wgs > live ? cap_wgs / live : 1;
+            if (blocks > max_blocks) blocks = max_blocks;
+            const int64_t rows = gf2_cdiv(m, blocks);
+            blocks = gf2_cdiv(m, rows);
+            const int64_t wgs = blocks * live, per_xcd = gf2_cdiv(wgs, (int64_t)xcds);
+            const int64_t left_now = per_xcd < cus_xcd ? cus_xcd - per_xcd : 0;     // free CUs of the fullest XCD
+            const int64_t rounds = left_now > 0 ? 1 : gf2_cdiv(wgs, (int64_t)ctx->num_cus);
+            const int64_t pass_us = rounds * (10 + rows * 18 / 1000);
+            const int64_t fin_all = gf2_cdiv(m, 1024) * batch;
+            int64_t fin_wgs = fin_all, trips = 1;
+            if (left_now > 0) {
+                if (fin_wgs > 2 * left_now * xcds) fin_wgs = 2 * left_now * xcds;       // (1024 lanes, 66 KiB of LDS: two to a CU)
+                trips = gf2_cdiv(fin_all, fin_wgs);
+            } else {
+                trips = 8;                                              // (they wait for pass workgroups to leave)
+            }
+            const int64_t chain_us = K * (17 + 6 + 5 * trips / 2) + 5;
+            const int64_t aside = pass_us + 7 > chain_us + 20 ? pass_us + 7 : chain_us + 20;       // panels on the side stream
+            const int64_t here = pass_us + 20 > chain_us ? pass_us + 20 : chain_us;               // panels on the main stream
+            const bool chain_here = swap_mode == 2 || (swap_mode == 0 && here < aside);
+            const int64_t cost = chain_here ? here : aside;
+            if (best_cost < 0 || cost <= best_cost)
+                best_cost = cost, best = Plan{rows, blocks, left_now > 0 ? (fin_wgs / batch > 0 ? fin_wgs / batch : 1) : 0, chain_here, true};
+            if (reserve_forced >= 0) break;
+        }
+        return best;
+    };
+    if (!ctx->lds_optin[8]) {
+        GF2_HIP(hipFuncSetAttribute((const void*)rref_sweep_update_flat_kernel<K, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        ctx->lds_optin[8] = true;
+    }
     // the K panels of sweep `s` into set `ps`, on stream `on`; `work`: where the batch lives (only read when the side buffer is stale)
     // (The column kernel runs for the first sweep only: afterwards the pass of sweep s always leaves the column words of sweep
     // s + 1 in the side buffer -- also for a matrix whose sweep found no pivot -- and sweep_finish_kernel resets the scratch.)
-    auto launch_panels = [&](const SweepSet& ps, int64_t s, const u64* work, hipStream_t on) {
+    auto launch_panels = [&](const SweepSet& ps, int64_t s, const u64* work, hipStream_t on, int64_t finish_plan) {
         const int64_t pw0 = s * K;
+        // finish workgroups per matrix: one round on the CUs the pass leaves (the plan), or one per 1024 rows
+        const int64_t finish_wgs = finish_plan > 0 && finish_plan < gf2_cdiv(m, 1024) ? finish_plan : gf2_cdiv(m, 1024);
         if (s == 0)
             hipLaunchKernelGGL(sweep_column_kernel, dim3((unsigned)gf2_cdiv(m, 256), (unsigned)batch), dim3(256), 0, on, work, m, ld, pw0, K,
                                (const SweepState*)states, colw, cco, slot_of);
         for (int l = 0; l < K; ++l) {
             hipLaunchKernelGGL(sweep_stream_panel_kernel<K>, dim3((unsigned)batch), dim3(RB_THREADS), 0, on, m, n, ld, pw0, l, pivots_dev, cap,
                                pivrow, states, used, ps.prow, colw, cco, slot_of, tabs, (const u64*)ps.e, dstride, pub);
-            hipLaunchKernelGGL(sweep_finish_kernel<K>, dim3((unsigned)gf2_cdiv(m, 1024), (unsigned)batch), dim3(1024), K * 2048 * 8, on, m, l,
+            hipLaunchKernelGGL(sweep_finish_kernel<K>, dim3((unsigned)finish_wgs, (unsigned)batch), dim3(1024), K * 2048 * 8, on, m, l,
                                (const SweepState*)states, colw, cco, slot_of, (const u64*)tabs, ps.e, dstride, (const u64*)pub);
         }
         return hipMemcpyAsync(ps.state_copy, states, (size_t)batch * sizeof(SweepState), hipMemcpyDeviceToDevice, on);
@@ -2734,7 +2829,7 @@ static int launch_rref_sweeps_streamed(gf2_ctx* ctx, u64* a_dev, int64_t batch, 
         return GF2_OK;
     };
     // sweep 0: nothing to overlap with
-    GF2_HIP(launch_panels(sets[0], 0, a_dev, s1));
+    GF2_HIP(launch_panels(sets[0], 0, a_dev, s1, 0));
     int64_t last = sweeps - 1;                                          // the last sweep that has work (lowered once every rank is m)
     for (int64_t s = 0; s <= last; ++s) {
         const SweepSet& cur = sets[s & 1];
@@ -2742,8 +2837,9 @@ static int launch_rref_sweeps_streamed(gf2_ctx* ctx, u64* a_dev, int64_t batch, 
         u64* work = s == 0 ? a_dev : tmp;                              // the first pass takes the batch to the workspace copy
         hipLaunchKernelGGL(sweep_snapshot_kernel, dim3((unsigned)(K * 64), (unsigned)batch), dim3(1024), 0, s1, (const u64*)work, m, ld, K,
                            (const SweepState*)cur.state_copy, (const int32_t*)cur.prow, cur.snap, sstride);
+        const Plan plan = plan_for(s);
         if (s == last) {
-            launch_pass(cur, s, work, 0, chunks, -1, rows_for(s), s1);
+            launch_pass(cur, s, work, 0, chunks, -1, plan.rows, s1);
             break;
         }
         const int64_t cnext = (s + 1) * K / CW;                        // the chunk of the next sweep's columns
@@ -2754,19 +2850,27 @@ static int launch_rref_sweeps_streamed(gf2_ctx* ctx, u64* a_dev, int64_t batch, 
             // Whatever goes to the other queue starts ~20 us late (the hand-over).  While the pass is the longer of the two, that is the
             // panels; once the panels' chain (K x (panel + finish) ~ 110 us) outlasts the pass -- the later sweeps of a big matrix, every
             // sweep of a batch of matrices of 8192 rows -- the chain stays on this stream and the big launch takes the hand-over.
-            const int64_t rows_big = rows_for(s);
-            const bool chain_here = swap_mode == 2 || (swap_mode == 0 && rows_big * 18 / 1000 + 22 < K * 26 + 24);   // (18 ns per row, 26 us per panel)
+            const int64_t rows_big = plan.rows;
+            const bool chain_here = plan.chain_here;
             hipStream_t s_chain = chain_here ? s1 : s2, s_pass = chain_here ? s2 : s1;
             if (wait_ready && !chain_here) GF2_HIP(hipEventRecord(e_ready, s2));
-            GF2_HIP(launch_panels(nxt, s + 1, tmp, s_chain));
+            GF2_HIP(launch_panels(nxt, s + 1, tmp, s_chain, plan.finish_wgs));
             if (!chain_here) GF2_HIP(hipEventRecord(e_panels, s2));
             if (wait_ready && !chain_here) GF2_HIP(hipStreamWaitEvent(s1, e_ready, 0));
-            launch_pass(cur, s, work, 0, chunks, cnext, rows_big, s_pass);
+            if (plan.flat && s * K / CW <= cnext) {
+                const int c_first = (int)(s * K / CW);                  // chunks left of it return at once (no pivot-free column so far)
+                const int64_t wgs = plan.blocks * (chunks - 1) * batch;
+                hipLaunchKernelGGL((rref_sweep_update_flat_kernel<K, TH>), dim3((unsigned)wgs), dim3(TH), 128 * 1024, s_pass, work, m, ld, rows_big,
+                                   (int)plan.blocks, (int)chunks, c_first, (int)cnext, (const SweepState*)cur.state_copy, states, (const u64*)cur.e,
+                                   dstride, (const u64*)cur.snap, sstride, s * K, colw, tmp, (int)batch);
+            } else {
+                launch_pass(cur, s, work, 0, chunks, cnext, rows_big, s_pass);
+            }
             if (chain_here) GF2_HIP(hipEventRecord(e_panels, s2));
             GF2_HIP(hipStreamWaitEvent(s1, e_panels, 0));
         } else {
-            launch_pass(cur, s, work, 0, chunks, -1, rows_for(s), s1);
-            GF2_HIP(launch_panels(nxt, s + 1, tmp, s1));
+            launch_pass(cur, s, work, 0, chunks, -1, plan.rows, s1);
+            GF2_HIP(launch_panels(nxt, s + 1, tmp, s1, 0));
         }
         GF2_HIP(hipGetLastError());
         // (the next sweep's panels have run when the ranks are read: the read-back waits for s1, which has waited for them)

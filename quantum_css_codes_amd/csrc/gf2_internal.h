@@ -60,7 +60,7 @@ struct gf2_ctx {
     size_t ws_bytes[4];
     // large dynamic-LDS opt-in (hipFuncSetAttribute) done for this context's device: [0] syndrome_tiled_kernel,
     // [1] table_class_hash_kernel, [2] slab_gather_kernel, [3] conjugate_kernel, [4] rref_update_pair_kernel
-    bool lds_optin[8];            // ... [5], [6] rref_sweep_update_kernel<2>, <4>, [7] sweep_finish_kernel
+    bool lds_optin[9];            // ... [5], [6] rref_sweep_update_kernel<2>, <4>, [7] sweep_finish_kernel, [8] rref_sweep_update_flat_kernel
     // routing flags (GF2_F_*) and tunables (GF2_OPT_*, -1 = default): gf2_ctx_set_flags / gf2_ctx_set_option
     uint32_t flags;
     int64_t opt[GF2_OPT_COUNT];
