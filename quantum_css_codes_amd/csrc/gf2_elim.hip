@@ -2106,6 +2106,7 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
                                                                       int64_t* __restrict__ pivots_base, int64_t cap,
                                                                       int64_t* __restrict__ rank_out) {
     constexpr int DW = 2 * LD;                                      // dwords per row
+    constexpr bool LANE_PRED = RPL >= 2;                            // see the column loop
     constexpr bool PIECES = LD >= 2;                                // rows of whole 16-byte pieces
     __shared__ __align__(16) unsigned int bcast_all[SMALL_WAVES][DW < 4 ? 4 : DW];
     const int lane = threadIdx.x & 63;
@@ -2120,11 +2121,13 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
         int pivcol[RPL];                                            // >= 0 once this row has become a pivot row: its column
         int myrank[RPL];
         u64 unused[RPL];                                            // lane masks (scalar): rows that exist and are not pivot rows yet
+        unsigned int live[RPL];                                     // LANE_PRED: the same per lane, all ones or zero
 #pragma unroll
         for (int q = 0; q < RPL; ++q) {
             pivcol[q] = -1;
             myrank[q] = 0;
             unused[q] = __ballot(lane + 64 * q < m);
+            live[q] = lane + 64 * q < m ? 0xFFFFFFFFu : 0u;
         }
         if (contiguous) {
             // every lane its own rows, 16 bytes per load
@@ -2167,14 +2170,30 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
                 const int col = d * 32 + bb;
                 const unsigned int bit = 1u << bb;
                 u64 has[RPL];
+                unsigned int t[RPL];                                // LANE_PRED: the row's bit of the column (zero: the row takes nothing)
                 int src_q = -1;
                 u64 cand = 0;
+                if constexpr (LANE_PRED) {
+                    // Two or more rows per lane: which rows have the column and which are still unused stay per-lane values.  As
+                    // 64-bit scalar masks (one ballot, its AND with `unused` and a place in the pick-the-first chain per register row,
+                    // inverse ballots for the XORs) the walk took 54 / 115 scalar instructions per pivot at two / four rows per lane,
+                    // and the CU's ONE scalar unit bound the kernel (profiles/r05_rref_small_floor.md).
 #pragma unroll
-                for (int q = 0; q < RPL; ++q) {
-                    has[q] = __ballot((w[q][d] & bit) != 0);
-                    if (src_q < 0 && (has[q] & unused[q])) {
-                        src_q = q;
-                        cand = has[q] & unused[q];
+                    for (int q = 0; q < RPL; ++q) t[q] = w[q][d] & bit;
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q)
+                        if (src_q < 0) {                            // uniform; the lowest register row that has an unused row with the bit
+                            const u64 c = __ballot((t[q] & live[q]) != 0);
+                            if (c) src_q = q, cand = c;
+                        }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) {
+                        has[q] = __ballot((w[q][d] & bit) != 0);
+                        if (src_q < 0 && (has[q] & unused[q])) {
+                            src_q = q;
+                            cand = has[q] & unused[q];
+                        }
                     }
                 }
                 if (src_q >= 0) {                                   // (else: no unused row has this column: not a pivot column)
@@ -2200,6 +2219,10 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
                         }
                         pivcol[q] = col;
                         myrank[q] = rank;
+                        if constexpr (LANE_PRED) {
+                            live[q] = 0;                            // a pivot row from here on ...
+                            t[q] = 0;                               // ... which does not take itself
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -2220,8 +2243,14 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
                 }
 #pragma unroll
                 for (int q = 0; q < RPL; ++q) {
-                    const u64 take = q == src_q ? has[q] & ~src_bit : has[q];
-                    if (__builtin_amdgcn_inverse_ballot_w64(take)) {         // (the readlane part first: the LDS part is still on its way)
+                    bool takes;
+                    if constexpr (LANE_PRED) {
+                        takes = t[q] != 0;
+                    } else {
+                        const u64 take = q == src_q ? has[q] & ~src_bit : has[q];
+                        takes = __builtin_amdgcn_inverse_ballot_w64(take);
+                    }
+                    if (takes) {                                             // (the readlane part first: the LDS part is still on its way)
 #pragma unroll
                         for (int dd = 0; dd < DW; ++dd)
                             if (dd >= d4 && dd < split) w[q][dd] ^= pr[dd];
@@ -2230,7 +2259,7 @@ __global__ __launch_bounds__(64 * SMALL_WAVES) void rref_small_kernel(u64* __res
                             if (dd >= split) w[q][dd] ^= pr[dd];
                     }
                 }
-                unused[src_q] ^= src_bit;                          // (the bit is set: the pivot came from there)
+                if constexpr (!LANE_PRED) unused[src_q] ^= src_bit; // (the bit is set: the pivot came from there)
                 rank += 1;
                 if (rank >= m) limit = 0;                           // uniform
                 __builtin_amdgcn_wave_barrier();                    // (the next pivot row is written after every lane has read this one)
