@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "gf2_internal.h"
@@ -243,48 +244,68 @@ __device__ __forceinline__ void window_round(int lane, int nwin, int t, int64_t 
     u64 piv0 = 0, piv1 = 0, newbits = 0;                               // (uniform) window rows that are pivots; columns resolved here
     unsigned int my_pbit = 0, my_prow = 0;                             // lane p: pivot p's column and window row
     int tt = t;
-    auto rl64 = [](u64 v, int src) {
-        return ((u64)(unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), src) << 32) |
-               (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, src);
-    };
-    u64 todo = unresolved;
     const int tmax = m - rank < 64 ? (int)(m - rank) : 64;             // (a 32-bit scalar compare per pivot: `rank + tt < m` was a 64-bit vector one)
-    while (todo && tt < tmax) {
-        const int b = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        u64 c0 = __ballot((w0 >> b) & 1ull), c1 = __ballot((w1 >> b) & 1ull);                // column b: window rows 0..63, 64..127
-        const u64 cand0 = c0 & ~piv0, cand1 = c1 & ~piv1;
-        if (!(cand0 | cand1)) continue;                               // no pivot for this column inside the window
-        const u64 c2 = __ballot((w2 >> b) & 1ull);                     // ... and the probe rows
-        int r;
-        u64 P, V;
-        if (cand0) {                                                   // uniform; the usual case: a pivot among the first 64 window rows
-            r = __ffsll((long long)cand0) - 1;
-            piv0 |= 1ull << r;
-            c0 &= ~(1ull << r);                                        // the pivot row does not take itself
-            P = rl64(w0, r);
-            V = rl64(d0, r);
-        } else {
-            r = __ffsll((long long)cand1) - 1;
-            piv1 |= 1ull << r;
-            c1 &= ~(1ull << r);
-            P = rl64(w1, r);
-            V = rl64(d1, r);
-            r += 64;
+    // The pivot step on 32-bit halves, with the rows that take the pivot row as a per-lane MASK (all ones / zero: one v_bfe_i32 of
+    // the half that holds the column), so that a row's update is  x ^= P & mask  -- one v_bitop3 per dword with the pivot row's dword
+    // in a scalar register -- and only the two ballots of the candidate search are left.  (Written as `if (inverse_ballot(c)) w ^= P`
+    // the compiler selected 0 or P per lane first -- v_cndmask + v_xor, and a v_mov per scalar value: 44 vector instructions per pivot,
+    // ~170 ns; now 24.)  The columns of the low half first, then those of the high half: the half is a compile-time constant.
+    unsigned int w0l = (unsigned int)w0, w0h = (unsigned int)(w0 >> 32), w1l = (unsigned int)w1, w1h = (unsigned int)(w1 >> 32);
+    unsigned int w2l = (unsigned int)w2, w2h = (unsigned int)(w2 >> 32);
+    unsigned int d0l = (unsigned int)d0, d0h = (unsigned int)(d0 >> 32), d1l = (unsigned int)d1, d1h = (unsigned int)(d1 >> 32);
+    unsigned int d2l = 0, d2h = 0;
+    auto half_steps = [&](auto half_constant, unsigned int todo32) {
+        constexpr int HALF = decltype(half_constant)::value;
+        if (tt >= tmax) todo32 = 0;                                    // (uniform; ONE loop condition: every branch costs the lone wavefront ~10 ns)
+        while (todo32) {
+            const int b5 = __ffs((int)todo32) - 1;
+            todo32 &= todo32 - 1;
+            int m0 = __builtin_amdgcn_sbfe((int)(HALF ? w0h : w0l), b5, 1);          // all ones: the row has the column
+            int m1 = __builtin_amdgcn_sbfe((int)(HALF ? w1h : w1l), b5, 1);
+            const int m2 = __builtin_amdgcn_sbfe((int)(HALF ? w2h : w2l), b5, 1);
+            const u64 cand0 = __ballot(m0 != 0) & ~piv0, cand1 = __ballot(m1 != 0) & ~piv1;
+            if (!(cand0 | cand1)) continue;                           // no pivot for this column inside the window
+            int r;
+            unsigned int Pl, Ph, Vl, Vh;
+            if (__builtin_expect(cand0 != 0, 1)) {                     // uniform; the usual case: a pivot among the first 64 window rows
+                r = __ffsll((long long)cand0) - 1;
+                piv0 |= 1ull << r;
+                asm("v_writelane_b32 %0, 0, %1" : "+v"(m0) : "s"(r));     // the pivot row does not take itself (no builtin for v_writelane)
+                Pl = (unsigned int)__builtin_amdgcn_readlane((int)w0l, r), Ph = (unsigned int)__builtin_amdgcn_readlane((int)w0h, r);
+                Vl = (unsigned int)__builtin_amdgcn_readlane((int)d0l, r), Vh = (unsigned int)__builtin_amdgcn_readlane((int)d0h, r);
+            } else {
+                r = __ffsll((long long)cand1) - 1;
+                piv1 |= 1ull << r;
+                asm("v_writelane_b32 %0, 0, %1" : "+v"(m1) : "s"(r));
+                Pl = (unsigned int)__builtin_amdgcn_readlane((int)w1l, r), Ph = (unsigned int)__builtin_amdgcn_readlane((int)w1h, r);
+                Vl = (unsigned int)__builtin_amdgcn_readlane((int)d1l, r), Vh = (unsigned int)__builtin_amdgcn_readlane((int)d1h, r);
+                r += 64;
+            }
+            {
+                const u64 V = (((u64)Vh << 32) | Vl) ^ (1ull << tt);     // (scalar: a shift and an XOR of 64 bits)
+                Vl = (unsigned int)V, Vh = (unsigned int)(V >> 32);
+            }
+            // x ^= P & m: bitop3 truth table 0x78 = a ^ (b & c)
+            w0l = __builtin_amdgcn_bitop3_b32(w0l, Pl, (unsigned int)m0, 0x78), w0h = __builtin_amdgcn_bitop3_b32(w0h, Ph, (unsigned int)m0, 0x78);
+            d0l = __builtin_amdgcn_bitop3_b32(d0l, Vl, (unsigned int)m0, 0x78), d0h = __builtin_amdgcn_bitop3_b32(d0h, Vh, (unsigned int)m0, 0x78);
+            w1l = __builtin_amdgcn_bitop3_b32(w1l, Pl, (unsigned int)m1, 0x78), w1h = __builtin_amdgcn_bitop3_b32(w1h, Ph, (unsigned int)m1, 0x78);
+            d1l = __builtin_amdgcn_bitop3_b32(d1l, Vl, (unsigned int)m1, 0x78), d1h = __builtin_amdgcn_bitop3_b32(d1h, Vh, (unsigned int)m1, 0x78);
+            w2l = __builtin_amdgcn_bitop3_b32(w2l, Pl, (unsigned int)m2, 0x78), w2h = __builtin_amdgcn_bitop3_b32(w2h, Ph, (unsigned int)m2, 0x78);
+            d2l = __builtin_amdgcn_bitop3_b32(d2l, Vl, (unsigned int)m2, 0x78), d2h = __builtin_amdgcn_bitop3_b32(d2h, Vh, (unsigned int)m2, 0x78);
+            // lane tt keeps the pivot's column and window row (v_writelane_b32 with the lane in M0)
+            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0"
+                         : "+v"(my_pbit), "+v"(my_prow)
+                         : "s"(tt), "s"((unsigned int)(b5 + 32 * HALF)), "s"((unsigned int)r)
+                         : "m0");
+            newbits |= 1ull << (b5 + 32 * HALF);
+            tt += 1;
+            if (tt >= tmax) todo32 = 0;                                // (a scalar select)
         }
-        V ^= 1ull << tt;
-        if (__builtin_amdgcn_inverse_ballot_w64(c0)) w0 ^= P, d0 ^= V;
-        if (__builtin_amdgcn_inverse_ballot_w64(c1)) w1 ^= P, d1 ^= V;
-        if (__builtin_amdgcn_inverse_ballot_w64(c2)) w2 ^= P, d2 ^= V;
-        // lane tt keeps the pivot's column and window row (v_writelane_b32 with the lane in M0: the compiler has no builtin for
-        // it and does not use M0 in these kernels)
-        asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0"
-                     : "+v"(my_pbit), "+v"(my_prow)
-                     : "s"(tt), "s"((unsigned int)b), "s"((unsigned int)r)
-                     : "m0");
-        newbits |= 1ull << b;
-        tt += 1;
-    }
+    };
+    half_steps(std::integral_constant<int, 0>{}, (unsigned int)unresolved);
+    half_steps(std::integral_constant<int, 1>{}, (unsigned int)(unresolved >> 32));
+    w0 = ((u64)w0h << 32) | w0l, w1 = ((u64)w1h << 32) | w1l, w2 = ((u64)w2h << 32) | w2l;
+    d0 = ((u64)d0h << 32) | d0l, d1 = ((u64)d1h << 32) | d1l, d2 = ((u64)d2h << 32) | d2l;
     // the new pivot rows as they stand at the end of the round
     if ((piv0 >> lane) & 1ull) {
         fin_w[lane] = w0;
