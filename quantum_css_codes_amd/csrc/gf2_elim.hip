@@ -256,50 +256,105 @@ __device__ __forceinline__ void window_round(int lane, int nwin, int t, int64_t 
     unsigned int d2l = 0, d2h = 0;
     auto half_steps = [&](auto half_constant, unsigned int todo32) {
         constexpr int HALF = decltype(half_constant)::value;
-        if (tt >= tmax) todo32 = 0;                                    // (uniform; ONE loop condition: every branch costs the lone wavefront ~10 ns)
-        while (todo32) {
-            const int b5 = __ffs((int)todo32) - 1;
-            todo32 &= todo32 - 1;
-            int m0 = __builtin_amdgcn_sbfe((int)(HALF ? w0h : w0l), b5, 1);          // all ones: the row has the column
-            int m1 = __builtin_amdgcn_sbfe((int)(HALF ? w1h : w1l), b5, 1);
-            const int m2 = __builtin_amdgcn_sbfe((int)(HALF ? w2h : w2l), b5, 1);
-            const u64 cand0 = __ballot(m0 != 0) & ~piv0, cand1 = __ballot(m1 != 0) & ~piv1;
-            if (!(cand0 | cand1)) continue;                           // no pivot for this column inside the window
-            int r;
-            unsigned int Pl, Ph, Vl, Vh;
-            if (__builtin_expect(cand0 != 0, 1)) {                     // uniform; the usual case: a pivot among the first 64 window rows
-                r = __ffsll((long long)cand0) - 1;
-                piv0 |= 1ull << r;
-                asm("v_writelane_b32 %0, 0, %1" : "+v"(m0) : "s"(r));     // the pivot row does not take itself (no builtin for v_writelane)
-                Pl = (unsigned int)__builtin_amdgcn_readlane((int)w0l, r), Ph = (unsigned int)__builtin_amdgcn_readlane((int)w0h, r);
-                Vl = (unsigned int)__builtin_amdgcn_readlane((int)d0l, r), Vh = (unsigned int)__builtin_amdgcn_readlane((int)d0h, r);
-            } else {
-                r = __ffsll((long long)cand1) - 1;
-                piv1 |= 1ull << r;
-                asm("v_writelane_b32 %0, 0, %1" : "+v"(m1) : "s"(r));
-                Pl = (unsigned int)__builtin_amdgcn_readlane((int)w1l, r), Ph = (unsigned int)__builtin_amdgcn_readlane((int)w1h, r);
-                Vl = (unsigned int)__builtin_amdgcn_readlane((int)d1l, r), Vh = (unsigned int)__builtin_amdgcn_readlane((int)d1h, r);
-                r += 64;
-            }
-            {
-                const u64 V = (((u64)Vh << 32) | Vl) ^ (1ull << tt);     // (scalar: a shift and an XOR of 64 bits)
-                Vl = (unsigned int)V, Vh = (unsigned int)(V >> 32);
-            }
-            // x ^= P & m: bitop3 truth table 0x78 = a ^ (b & c)
-            w0l = __builtin_amdgcn_bitop3_b32(w0l, Pl, (unsigned int)m0, 0x78), w0h = __builtin_amdgcn_bitop3_b32(w0h, Ph, (unsigned int)m0, 0x78);
-            d0l = __builtin_amdgcn_bitop3_b32(d0l, Vl, (unsigned int)m0, 0x78), d0h = __builtin_amdgcn_bitop3_b32(d0h, Vh, (unsigned int)m0, 0x78);
-            w1l = __builtin_amdgcn_bitop3_b32(w1l, Pl, (unsigned int)m1, 0x78), w1h = __builtin_amdgcn_bitop3_b32(w1h, Ph, (unsigned int)m1, 0x78);
-            d1l = __builtin_amdgcn_bitop3_b32(d1l, Vl, (unsigned int)m1, 0x78), d1h = __builtin_amdgcn_bitop3_b32(d1h, Vh, (unsigned int)m1, 0x78);
-            w2l = __builtin_amdgcn_bitop3_b32(w2l, Pl, (unsigned int)m2, 0x78), w2h = __builtin_amdgcn_bitop3_b32(w2h, Ph, (unsigned int)m2, 0x78);
-            d2l = __builtin_amdgcn_bitop3_b32(d2l, Vl, (unsigned int)m2, 0x78), d2h = __builtin_amdgcn_bitop3_b32(d2h, Vh, (unsigned int)m2, 0x78);
+        // W: the halves that hold this half's columns, X: the other halves
+        unsigned int &W0 = HALF ? w0h : w0l, &W1 = HALF ? w1h : w1l, &W2 = HALF ? w2h : w2l;
+        unsigned int &X0 = HALF ? w0l : w0h, &X1 = HALF ? w1l : w1h, &X2 = HALF ? w2l : w2h;
+        auto note_pivot = [&](int b5, int r) {
             // lane tt keeps the pivot's column and window row (v_writelane_b32 with the lane in M0)
             asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0"
                          : "+v"(my_pbit), "+v"(my_prow)
                          : "s"(tt), "s"((unsigned int)(b5 + 32 * HALF)), "s"((unsigned int)r)
                          : "m0");
             newbits |= 1ull << (b5 + 32 * HALF);
-            tt += 1;
-            if (tt >= tmax) todo32 = 0;                                // (a scalar select)
+        };
+        todo32 = (unsigned int)__builtin_amdgcn_readfirstlane((int)todo32);     // (uniform, and now the compiler knows)
+        if (tt >= tmax) todo32 = 0;                                    // (uniform)
+        while (todo32) {
+            int b5 = __ffs((int)todo32) - 1;
+            todo32 &= todo32 - 1;
+            int m0 = __builtin_amdgcn_sbfe((int)W0, b5, 1);            // all ones: the row has the column
+            u64 cand0 = __ballot(m0 != 0) & ~piv0;
+            if (__builtin_expect(cand0 != 0, 1)) {
+                // The usual case, a pivot among the first 64 window rows, as a loop of its own with ONE branch per pivot (a branch
+                // costs the lone wavefront ~10 ns): the halves that hold the columns are updated first, then the NEXT column's test
+                // and ballot are issued, and the other nine updates run while that ballot is on its way to the scalar unit.
+                unsigned int rest;
+                int b5n, m0n;
+                u64 cand0n;
+                bool go;
+                auto step = [&]() {
+                    const int r = __ffsll((long long)cand0) - 1;
+                    piv0 |= 1ull << r;
+                    asm("v_writelane_b32 %0, 0, %1" : "+v"(m0) : "s"(r));           // the pivot row does not take itself (no builtin for v_writelane)
+                    unsigned int Pl = (unsigned int)__builtin_amdgcn_readlane((int)w0l, r), Ph = (unsigned int)__builtin_amdgcn_readlane((int)w0h, r);
+                    unsigned int Vl = (unsigned int)__builtin_amdgcn_readlane((int)d0l, r), Vh = (unsigned int)__builtin_amdgcn_readlane((int)d0h, r);
+                    {
+                        const u64 V = (((u64)Vh << 32) | Vl) ^ (1ull << tt);     // (scalar: a shift and an XOR of 64 bits)
+                        Vl = (unsigned int)V, Vh = (unsigned int)(V >> 32);
+                    }
+                    const int m1 = __builtin_amdgcn_sbfe((int)W1, b5, 1), m2 = __builtin_amdgcn_sbfe((int)W2, b5, 1);
+                    const unsigned int PW = HALF ? Ph : Pl, PX = HALF ? Pl : Ph;
+                    // x ^= P & m: bitop3 truth table 0x78 = a ^ (b & c)
+                    W0 = __builtin_amdgcn_bitop3_b32(W0, PW, (unsigned int)m0, 0x78);
+                    W1 = __builtin_amdgcn_bitop3_b32(W1, PW, (unsigned int)m1, 0x78);
+                    W2 = __builtin_amdgcn_bitop3_b32(W2, PW, (unsigned int)m2, 0x78);
+                    __builtin_amdgcn_sched_barrier(0);
+                    note_pivot(b5, r);
+                    tt += 1;
+                    rest = tt < tmax ? todo32 : 0u;                    // (a scalar select)
+                    b5n = __builtin_ctz(rest | 0x80000000u);           // (no column left: any offset will do, `go` is false)
+                    m0n = __builtin_amdgcn_sbfe((int)W0, b5n, 1);
+                    cand0n = __ballot(m0n != 0) & ~piv0;
+                    __builtin_amdgcn_sched_barrier(0);                 // (the next column's test stays ahead of the other nine updates)
+                    X0 = __builtin_amdgcn_bitop3_b32(X0, PX, (unsigned int)m0, 0x78);
+                    d0l = __builtin_amdgcn_bitop3_b32(d0l, Vl, (unsigned int)m0, 0x78), d0h = __builtin_amdgcn_bitop3_b32(d0h, Vh, (unsigned int)m0, 0x78);
+                    X1 = __builtin_amdgcn_bitop3_b32(X1, PX, (unsigned int)m1, 0x78);
+                    d1l = __builtin_amdgcn_bitop3_b32(d1l, Vl, (unsigned int)m1, 0x78), d1h = __builtin_amdgcn_bitop3_b32(d1h, Vh, (unsigned int)m1, 0x78);
+                    X2 = __builtin_amdgcn_bitop3_b32(X2, PX, (unsigned int)m2, 0x78);
+                    d2l = __builtin_amdgcn_bitop3_b32(d2l, Vl, (unsigned int)m2, 0x78), d2h = __builtin_amdgcn_bitop3_b32(d2h, Vh, (unsigned int)m2, 0x78);
+                    todo32 = rest & (rest - 1u);
+                    go = rest != 0 && cand0n != 0;
+                    b5 = b5n, m0 = m0n, cand0 = cand0n;
+                };
+                // (four steps per backward branch: a TAKEN branch costs the lone wavefront ~15 ns, one that falls through next to nothing)
+                for (;;) {
+                    step();
+                    if (!go) break;
+                    step();
+                    if (!go) break;
+                    step();
+                    if (!go) break;
+                    step();
+                    if (!go) break;
+                }
+                if (rest == 0) break;                                 // no column left (or no row)
+                // column b5 has no pivot among the first 64 window rows: below
+            }
+            // the second half of the window (rare)
+            const int m1 = __builtin_amdgcn_sbfe((int)W1, b5, 1);
+            const u64 cand1 = __ballot(m1 != 0) & ~piv1;
+            if (cand1) {
+                int m1c = m1;
+                int r = __ffsll((long long)cand1) - 1;
+                piv1 |= 1ull << r;
+                asm("v_writelane_b32 %0, 0, %1" : "+v"(m1c) : "s"(r));
+                unsigned int Pl = (unsigned int)__builtin_amdgcn_readlane((int)w1l, r), Ph = (unsigned int)__builtin_amdgcn_readlane((int)w1h, r);
+                unsigned int Vl = (unsigned int)__builtin_amdgcn_readlane((int)d1l, r), Vh = (unsigned int)__builtin_amdgcn_readlane((int)d1h, r);
+                {
+                    const u64 V = (((u64)Vh << 32) | Vl) ^ (1ull << tt);
+                    Vl = (unsigned int)V, Vh = (unsigned int)(V >> 32);
+                }
+                const int m2 = __builtin_amdgcn_sbfe((int)W2, b5, 1);
+                w0l = __builtin_amdgcn_bitop3_b32(w0l, Pl, (unsigned int)m0, 0x78), w0h = __builtin_amdgcn_bitop3_b32(w0h, Ph, (unsigned int)m0, 0x78);
+                d0l = __builtin_amdgcn_bitop3_b32(d0l, Vl, (unsigned int)m0, 0x78), d0h = __builtin_amdgcn_bitop3_b32(d0h, Vh, (unsigned int)m0, 0x78);
+                w1l = __builtin_amdgcn_bitop3_b32(w1l, Pl, (unsigned int)m1c, 0x78), w1h = __builtin_amdgcn_bitop3_b32(w1h, Ph, (unsigned int)m1c, 0x78);
+                d1l = __builtin_amdgcn_bitop3_b32(d1l, Vl, (unsigned int)m1c, 0x78), d1h = __builtin_amdgcn_bitop3_b32(d1h, Vh, (unsigned int)m1c, 0x78);
+                w2l = __builtin_amdgcn_bitop3_b32(w2l, Pl, (unsigned int)m2, 0x78), w2h = __builtin_amdgcn_bitop3_b32(w2h, Ph, (unsigned int)m2, 0x78);
+                d2l = __builtin_amdgcn_bitop3_b32(d2l, Vl, (unsigned int)m2, 0x78), d2h = __builtin_amdgcn_bitop3_b32(d2h, Vh, (unsigned int)m2, 0x78);
+                note_pivot(b5, r + 64);
+                tt += 1;
+                if (tt >= tmax) todo32 = 0;
+            }
         }
     };
     half_steps(std::integral_constant<int, 0>{}, (unsigned int)unresolved);
