@@ -386,20 +386,35 @@ __device__ __forceinline__ void window_round(int lane, int nwin, int t, int64_t 
     }
 }
 
+// One byte table, T[g * 256 + v] = XOR of rows64[8 g + c] over the bits c of v (8 groups of 256 entries from 64 rows), by 128 lanes:
+// lane q = (g, low nibble l) makes the combination of the group's low four rows that l names once and then walks the sixteen high
+// nibbles in Gray-code order, one XOR and one store per entry -- 16 lanes of a group store 128 contiguous bytes, so the
+// ds_write_b64 groups are conflict-free.  (Every entry made from scratch -- eight selects and XORs each, 2048 entries over the
+// workgroup -- was 1.4 us per table in the panel kernels: more than the lookups it serves.)
+__device__ __forceinline__ void gray_byte_table(int q, const u64* rows64, u64* T) {
+    const int g = q >> 4, l = q & 15;
+    const u64* r = rows64 + 8 * g;
+    u64 cur = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) cur ^= r[c] & (0ull - (u64)((l >> c) & 1));
+    u64 hi[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) hi[c] = r[4 + c];
+    u64* out = T + g * 256 + l;
+    out[0] = cur;
+#pragma unroll
+    for (int i = 1; i < 16; ++i) {
+        cur ^= hi[__builtin_ctz(i)];                                   // (compile-time index: the loop is unrolled)
+        out[(i ^ (i >> 1)) * 16] = cur;                                // entry (high nibble = Gray(i), low nibble l)
+    }
+}
+
 // Byte tables of the probe rows: VT of their coefficients (DP), TW of their words (only when another round follows).
 __device__ __forceinline__ void round_tables(int tid, const u64* CP, const u64* WP, u64* VT, u64* TW, bool again) {
-    for (int idx = tid; idx < 2048; idx += RB_THREADS) {
-        const int g = idx >> 8, vv = idx & 255;
-        u64 x = 0, y = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const u64 hit = 0ull - (u64)((vv >> k) & 1);
-            x ^= CP[8 * g + k] & hit;
-            y ^= WP[8 * g + k] & hit;
-        }
-        VT[idx] = x;
-        if (again) TW[idx] = y;
-    }
+    if (tid < 128)
+        gray_byte_table(tid, CP, VT);
+    else if (tid < 256 && again)
+        gray_byte_table(tid - 128, WP, TW);
 }
 
 __device__ __forceinline__ u64 byte_lookup(const u64* T, u64 w) {
@@ -1079,13 +1094,7 @@ struct SweepState {                                 // per matrix, in global scr
 };
 
 __device__ __forceinline__ void byte_table(int tid, const u64* rows64, u64* T) {
-    for (int idx = tid; idx < 2048; idx += RB_THREADS) {
-        const int g = idx >> 8, vv = idx & 255;
-        u64 x = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) x ^= rows64[8 * g + k] & (0ull - (u64)((vv >> k) & 1));
-        T[idx] = x;
-    }
+    if (tid < 128) gray_byte_table(tid, rows64, T);
 }
 
 template <int K, int RPT>
@@ -1267,14 +1276,8 @@ __global__ __launch_bounds__(RB_THREADS) void rref_sweep_panel_kernel(const u64*
                 for (int l2 = 0; l2 < l; ++l2) pub[K - 1 - l + l2][qidx[k]] = e_all[l2][k];
             }
         __syncthreads();
-        // K - 1 byte tables at once
-        for (int idx = tid; idx < (K - 1) * 2048; idx += RB_THREADS) {
-            const int v = idx >> 11, g = (idx >> 8) & 7, vv = idx & 255;
-            u64 x = 0;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) x ^= pub[v][8 * g + c] & (0ull - (u64)((vv >> c) & 1));
-            TT[idx] = x;
-        }
+        // K - 1 byte tables at once, 128 lanes each
+        if (tid < (K - 1) * 128) gray_byte_table(tid & 127, pub[tid >> 7], TT + (tid >> 7) * 2048);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < RPT; ++k) {
@@ -1889,14 +1892,7 @@ __global__ __launch_bounds__(1024) void sweep_finish_kernel(int64_t m, int l, co
     if (threadIdx.x < (K - 1) * 64) pv_s[threadIdx.x] = pub_base[mat * (K - 1) * 64 + threadIdx.x];
     for (int idx = threadIdx.x; idx < 2048; idx += 1024) FT[idx] = pending ? tabs_base[mat * 2048 + idx] : 0ull;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < (K - 1) * 2048; idx += 1024) {
-        const int v = idx >> 11, g = (idx >> 8) & 7, vv = idx & 255;
-        const u64* pv = pv_s + v * 64 + 8 * g;
-        u64 x = 0;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) x ^= pv[c] & (0ull - (u64)((vv >> c) & 1));
-        FT[2048 + idx] = x;
-    }
+    if (threadIdx.x < (K - 1) * 128) gray_byte_table(threadIdx.x & 127, pv_s + (threadIdx.x >> 7) * 64, FT + 2048 + (threadIdx.x >> 7) * 2048);
     __syncthreads();
     for (int64_t row = row0; row < m; row += stride) {
         u64* w = colw_base + (mat * m + row) * K;
