@@ -1974,35 +1974,64 @@ __global__ __launch_bounds__(RB_THREADS) void norm_panel_kernel(u64* __restrict_
         // (e_p ^ d_diag ^ [diagonal even] d_donor) . B from zero, a row that takes it takes those coefficients, and 64 probe rows
         // e_j, eliminated along, give every row outside the window its coefficients by table lookup (such a row is never a
         // diagonal row or a donor of this panel, so what happens to it is linear in its word).
-        u64 ew[3] = {win_w[lane], win_w[lane + 64], 1ull << lane}, ed[3] = {0ull, 0ull, 0ull};
+        // (The step on 32-bit halves with the rows that take P as per-lane masks -- x ^= P & mask, one v_bitop3 per dword -- and the
+        // diagonal row written by v_writelane, as in window_round: the form with 64-bit shifts, ballots for every row set and
+        // `if (bit) x ^= P` compiled to selects was ~2x the vector instructions.)
+        const u64 ww0 = win_w[lane], ww1 = win_w[lane + 64];
+        unsigned int e0l = (unsigned int)ww0, e0h = (unsigned int)(ww0 >> 32), e1l = (unsigned int)ww1, e1h = (unsigned int)(ww1 >> 32);
+        unsigned int e2l = lane < 32 ? 1u << lane : 0u, e2h = lane >= 32 ? 1u << (lane - 32) : 0u;
+        unsigned int f0l = 0, f0h = 0, f1l = 0, f1h = 0, f2l = 0, f2h = 0;            // the coefficients
         int tt = 0;
-        for (int sidx = 0; sidx < steps; ++sidx) {
-            const u64 bal0 = __ballot(lane >= sidx && ((ew[0] >> sidx) & 1ull));
-            const u64 bal1 = __ballot((ew[1] >> sidx) & 1ull);
-            if (!(bal0 | bal1)) break;                                 // no donor inside the window
-            const int h = bal0 ? 0 : 1;
-            const int src = __ffsll((long long)(bal0 ? bal0 : bal1)) - 1;
-            u64 pwd = readlane64(ew[0], sidx), pd = readlane64(ed[0], sidx);
-            int dn = -1;
-            if (!(h == 0 && src == sidx)) {                             // diagonal entry is even: add the donor
-                pwd ^= readlane64(h ? ew[1] : ew[0], src);
-                pd ^= readlane64(h ? ed[1] : ed[0], src);
-                dn = (int)(i0 + src + 64 * h);
-            }
-            pd ^= 1ull << sidx;
-#pragma unroll
-            for (int hh = 0; hh < 3; ++hh) {
-                if (hh == 0 && lane == sidx) {
-                    ew[0] = pwd;
-                    ed[0] = pd;
-                } else if ((ew[hh] >> sidx) & 1ull) {
-                    ew[hh] ^= pwd;
-                    ed[hh] ^= pd;
+        auto half_steps = [&](auto half_constant, int s_lo, int s_hi) {
+            constexpr int HALF = decltype(half_constant)::value;
+            for (int sidx = s_lo; sidx < s_hi; ++sidx) {
+                const int s5 = sidx - 32 * HALF;
+                int m0 = __builtin_amdgcn_sbfe((int)(HALF ? e0h : e0l), s5, 1);      // all ones: the row has the step's column
+                const int m1 = __builtin_amdgcn_sbfe((int)(HALF ? e1h : e1l), s5, 1);
+                const int m2 = __builtin_amdgcn_sbfe((int)(HALF ? e2h : e2l), s5, 1);
+                const u64 bal0 = __ballot(m0 != 0) & (~0ull << sidx);                // at or below the diagonal
+                u64 bal1 = 0;
+                if (__builtin_expect(bal0 == 0, 0)) {
+                    bal1 = __ballot(m1 != 0);
+                    if (!bal1) return false;                               // no donor inside the window
                 }
+                const int h = bal0 ? 0 : 1;
+                const int src = __ffsll((long long)(bal0 ? bal0 : bal1)) - 1;
+                unsigned int pwl = (unsigned int)__builtin_amdgcn_readlane((int)e0l, sidx), pwh = (unsigned int)__builtin_amdgcn_readlane((int)e0h, sidx);
+                unsigned int pdl = (unsigned int)__builtin_amdgcn_readlane((int)f0l, sidx), pdh = (unsigned int)__builtin_amdgcn_readlane((int)f0h, sidx);
+                int dn = -1;
+                if (!(h == 0 && src == sidx)) {                             // diagonal entry is even: add the donor
+                    if (h == 0) {
+                        pwl ^= (unsigned int)__builtin_amdgcn_readlane((int)e0l, src), pwh ^= (unsigned int)__builtin_amdgcn_readlane((int)e0h, src);
+                        pdl ^= (unsigned int)__builtin_amdgcn_readlane((int)f0l, src), pdh ^= (unsigned int)__builtin_amdgcn_readlane((int)f0h, src);
+                    } else {
+                        pwl ^= (unsigned int)__builtin_amdgcn_readlane((int)e1l, src), pwh ^= (unsigned int)__builtin_amdgcn_readlane((int)e1h, src);
+                        pdl ^= (unsigned int)__builtin_amdgcn_readlane((int)f1l, src), pdh ^= (unsigned int)__builtin_amdgcn_readlane((int)f1h, src);
+                    }
+                    dn = (int)(i0 + src + 64 * h);
+                }
+                if (sidx < 32) pdl ^= 1u << sidx; else pdh ^= 1u << (sidx - 32);      // (sidx's half is the loop's: a constant condition)
+                asm("v_writelane_b32 %0, 0, %1" : "+v"(m0) : "s"(sidx));              // the diagonal row is written, not added to
+                e0l = __builtin_amdgcn_bitop3_b32(e0l, pwl, (unsigned int)m0, 0x78), e0h = __builtin_amdgcn_bitop3_b32(e0h, pwh, (unsigned int)m0, 0x78);
+                f0l = __builtin_amdgcn_bitop3_b32(f0l, pdl, (unsigned int)m0, 0x78), f0h = __builtin_amdgcn_bitop3_b32(f0h, pdh, (unsigned int)m0, 0x78);
+                e1l = __builtin_amdgcn_bitop3_b32(e1l, pwl, (unsigned int)m1, 0x78), e1h = __builtin_amdgcn_bitop3_b32(e1h, pwh, (unsigned int)m1, 0x78);
+                f1l = __builtin_amdgcn_bitop3_b32(f1l, pdl, (unsigned int)m1, 0x78), f1h = __builtin_amdgcn_bitop3_b32(f1h, pdh, (unsigned int)m1, 0x78);
+                e2l = __builtin_amdgcn_bitop3_b32(e2l, pwl, (unsigned int)m2, 0x78), e2h = __builtin_amdgcn_bitop3_b32(e2h, pwh, (unsigned int)m2, 0x78);
+                f2l = __builtin_amdgcn_bitop3_b32(f2l, pdl, (unsigned int)m2, 0x78), f2h = __builtin_amdgcn_bitop3_b32(f2h, pdh, (unsigned int)m2, 0x78);
+                // (the lane in M0: a scalar value and a scalar lane select in one instruction are one constant-bus operand too many)
+                asm volatile("s_mov_b32 m0, %8\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\tv_writelane_b32 %2, %6, m0\n\t"
+                             "v_writelane_b32 %3, %7, m0"
+                             : "+v"(e0l), "+v"(e0h), "+v"(f0l), "+v"(f0h)
+                             : "s"(pwl), "s"(pwh), "s"(pdl), "s"(pdh), "s"(sidx)
+                             : "m0");
+                if (lane == 0) donor[sidx] = dn;
+                tt += 1;
             }
-            if (lane == 0) donor[sidx] = dn;
-            tt += 1;
-        }
+            return true;
+        };
+        if (half_steps(std::integral_constant<int, 0>{}, 0, steps < 32 ? steps : 32) && steps > 32)
+            (void)half_steps(std::integral_constant<int, 1>{}, 32, steps);
+        u64 ed[3] = {((u64)f0h << 32) | f0l, ((u64)f1h << 32) | f1l, ((u64)f2h << 32) | f2l};
         win_d[lane] = ed[0];
         win_d[lane + 64] = ed[1];
         DP[lane] = ed[2];
