@@ -1109,7 +1109,8 @@ __global__ __launch_bounds__(RB_THREADS) void rref_sweep_panel_kernel(const u64*
     __shared__ u64 TT[NT * 2048];
     __shared__ u64 win_w[RB_WIN], win_d[RB_WIN], fin_w[RB_WIN], fin_d[RB_WIN], DP[64], WP[64];
     __shared__ u64 pub[K - 1][64];                                      // what a panel's new pivot rows show the other rows (see below)
-    __shared__ int win_row[RB_WIN], win_piv[RB_WIN], win_q[RB_WIN], pbit[64], prow_l[64], wave_tot[RB_THREADS / 64], misc[4];
+    __shared__ int win_row[RB_WIN], win_piv[RB_WIN], win_q[RB_WIN], pbit[64], prow_l[64], misc[4];
+    __shared__ int win_count;
     __shared__ int prow_all[K][64], tj[K];
 
     const int64_t mat = blockIdx.x;
@@ -1165,6 +1166,7 @@ __global__ __launch_bounds__(RB_THREADS) void rref_sweep_panel_kernel(const u64*
     int64_t rank = rank0;
     const int64_t first_free_in = first_free;
     if (tid < K) tj[tid] = 0;
+    if (tid == 0) win_count = 0;
     int t_sum = 0;
 #pragma unroll
     for (int l = 0; l < K; ++l) {
@@ -1183,32 +1185,27 @@ __global__ __launch_bounds__(RB_THREADS) void rref_sweep_panel_kernel(const u64*
         u64 unresolved = panel_cols;
         int t = 0;
         while (unresolved && t < 64 && rank + t < m) {
-            int cnt = 0;
+            // window: up to RB_WIN unused rows with a bit in an unresolved column, in any order (the RREF does not depend on which rows
+            // become the pivots).  A wavefront counts its candidates with one ballot per register row and reserves its places with
+            // ONE LDS atomic: the inclusive scan over the lanes and the sum of the wavefronts' totals behind a barrier that this
+            // replaces were six ds_bpermute and a barrier per round.
+            u64 cb[RPT];
+            int wave_cnt = 0;
 #pragma unroll
             for (int k = 0; k < RPT; ++k) {
                 slot[k] = -1;
-                if (!((usedmask >> k) & 1u) && (w[k] & unresolved)) cnt += 1;
+                cb[k] = __ballot(!((usedmask >> k) & 1u) && (w[k] & unresolved) != 0);
+                wave_cnt += __popcll(cb[k]);
             }
-            int incl = cnt;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int up = __shfl_up(incl, off);
-                if (lane >= off) incl += up;
+            int base_pos = 0;
+            if (wave_cnt > 0) {                                        // uniform per wavefront
+                if (lane == 0) base_pos = atomicAdd(&win_count, wave_cnt);
+                base_pos = __builtin_amdgcn_readfirstlane(base_pos);
             }
-            if (lane == 63) wave_tot[wave] = incl;
-            __syncthreads();
-            int before = 0, total = 0;
 #pragma unroll
-            for (int i = 0; i < RB_THREADS / 64; ++i) {
-                const int v = wave_tot[i];
-                if (i < wave) before += v;
-                total += v;
-            }
-            if (total == 0) break;                                    // the unresolved columns have no pivot
-            int pos = before + incl - cnt;
-#pragma unroll
-            for (int k = 0; k < RPT; ++k)
-                if (!((usedmask >> k) & 1u) && (w[k] & unresolved)) {
+            for (int k = 0; k < RPT; ++k) {
+                if ((cb[k] >> lane) & 1ull) {
+                    const int pos = base_pos + __builtin_amdgcn_mbcnt_hi((unsigned int)(cb[k] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)cb[k], 0u));
                     if (pos < RB_WIN) {
                         slot[k] = pos;
                         win_row[pos] = tid + RB_THREADS * k;
@@ -1216,14 +1213,19 @@ __global__ __launch_bounds__(RB_THREADS) void rref_sweep_panel_kernel(const u64*
                         win_d[pos] = d[k];
                         win_piv[pos] = 0;
                     }
-                    pos += 1;
                 }
+                base_pos += __popcll(cb[k]);
+            }
+            __syncthreads();
+            const int total = win_count;
+            if (total == 0) break;                                    // the unresolved columns have no pivot (nobody added: the counter stays 0)
             __syncthreads();
             GF2_STAMP(1);                                              // window fill
             const int nwin = total < RB_WIN ? total : RB_WIN;
             if (wave == 0)
                 window_round(lane, nwin, t, rank, m, unresolved, win_w, win_d, win_row, win_piv, fin_w, fin_d, pbit, prow_l, DP, WP, misc, win_q);
             __syncthreads();
+            if (tid == 0) win_count = 0;                               // (everyone has read the total; the next round's atomics come two barriers later)
             GF2_STAMP(2);                                              // window_round
             const int t_new = misc[0];
             const u64 newbits = ((u64)(unsigned int)misc[2] << 32) | (unsigned int)misc[1];
