@@ -1772,10 +1772,17 @@ __global__ __launch_bounds__(RB_THREADS) void sweep_stream_panel_kernel(int64_t 
                 const u64 any = __ballot(unused);
                 if (any && lane == __ffsll((long long)any) - 1) atomicMin(&lo_min[block & 1], (int)row);
             }
-            if (unused) {
-                const u64 wv = colw[row * K + l];
-                if (wv & unresolved) {
-                    const int pos = atomicAdd(&win_count, 1);
+            {
+                // (one LDS atomic per wavefront for its candidates' places, not one per row on the one counter)
+                const u64 wv = unused ? colw[row * K + l] : 0ull;
+                const u64 cb = __ballot((wv & unresolved) != 0);
+                int base_pos = 0;
+                if (cb) {                                               // uniform per wavefront
+                    if (lane == 0) base_pos = atomicAdd(&win_count, (int)__popcll(cb));
+                    base_pos = __builtin_amdgcn_readfirstlane(base_pos);
+                }
+                if ((cb >> lane) & 1ull) {
+                    const int pos = base_pos + __builtin_amdgcn_mbcnt_hi((unsigned int)(cb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)cb, 0u));
                     if (pos < RB_WIN) {
                         slot_of[row] = pos;
                         win_row[pos] = (int)row;
