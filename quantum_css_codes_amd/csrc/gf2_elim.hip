@@ -1103,8 +1103,10 @@ __global__ __launch_bounds__(RB_THREADS) void rref_sweep_panel_kernel(const u64*
                                                                      int32_t* __restrict__ pivrow_base, SweepState* __restrict__ states,
                                                                      unsigned char* __restrict__ used_base,
                                                                      const u64* __restrict__ colw_base, u64* __restrict__ d_base,
-                                                                     int64_t dstride, u64* __restrict__ snap_base, int64_t sstride) {
-    // d_base: [K][dstride] coefficients (dstride >= batch * m); snap_base: [K][sstride] pivot-row snapshots (batch x 64 x ld each)
+                                                                     int64_t dstride, u64* __restrict__ snap_base, int64_t sstride,
+                                                                     int32_t* __restrict__ prow_out) {
+    // d_base: [K][dstride] coefficients (dstride >= batch * m); snap_base: [K][sstride] pivot-row snapshots (batch x 64 x ld each),
+    // or nullptr: no snapshots, the pivot rows' numbers go to prow_out [batch][K][64] and the pass reads the rows themselves
     constexpr int NT = K - 1 < 2 ? 2 : K - 1;                           // byte tables held at a time
     __shared__ u64 TT[NT * 2048];
     __shared__ u64 win_w[RB_WIN], win_d[RB_WIN], fin_w[RB_WIN], fin_d[RB_WIN], DP[64], WP[64];
@@ -1309,6 +1311,14 @@ __global__ __launch_bounds__(RB_THREADS) void rref_sweep_panel_kernel(const u64*
             for (int l = 0; l < K; ++l) d_base[(int64_t)l * dstride + mat * m + row] = e_all[l][k];   // (zero for a panel that found nothing)
         }
     }
+    if (snap_base == nullptr) {                                        // (uniform)
+        if (tid < K * 64) prow_out[(mat * K + (tid >> 6)) * 64 + (tid & 63)] = (tid & 63) < tj[tid >> 6] ? prow_all[tid >> 6][tid & 63] : 0;
+        GF2_STAMP(5);
+#if GF2_SWEEP_DIAG
+        if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_panel_diag[7], 1ull);
+#endif
+        return;
+    }
     // snapshots of the pivot rows as they stand in memory (the trailing pass overwrites them).  The K panels' rows as ONE list of
     // 16-byte pieces, four loads in flight per lane before the first store: written as a load-store loop per panel this was sixteen
     // dependent round trips to memory for a 2048 x 4096 matrix (17 of the launch's 104 us with 256 matrices in flight, 4 of 36 alone).
@@ -1368,7 +1378,9 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
                                                   const u64* __restrict__ d_base,
                                                   int64_t dstride, const u64* __restrict__ snap_base,
                                                   int64_t sstride, int64_t pw0,
-                                                  u64* __restrict__ colw_base, u64* out_base) {
+                                                  u64* __restrict__ colw_base, u64* out_base, const int32_t* __restrict__ prow_base = nullptr) {
+    // snap_base == nullptr: the pivot rows are read where they lie (prow_base: their numbers) -- only for a workgroup that owns ALL
+    // rows of its chunk, which reads them for its tables before it writes any row
     // states: what this sweep's panels left (with look-ahead a COPY: the next sweep's panels are writing the state by now);
     // live: the state the next panel kernel reads -- it learns from there that the side buffer holds its column words
     static_assert(K == 2 || K == 4, "two or four panels per sweep");
@@ -1428,7 +1440,9 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
 #pragma unroll
                 for (int jj = 0; jj < K - 1; ++jj)
                     if (j == jj && p >= tg[jj]) p -= tg[jj], j = jj + 1;
-                if (wd < wc_n) v = snap_base[(int64_t)j * sstride + (mat * 64 + p) * ld + cw0 + wd];
+                if (wd < wc_n)
+                    v = snap_base ? snap_base[(int64_t)j * sstride + (mat * 64 + p) * ld + cw0 + wd]
+                                  : a[(int64_t)prow_base[(mat * K + j) * 64 + p] * ld + cw0 + wd];
             }
             P[idx] = v;
         }
@@ -1552,7 +1566,9 @@ __device__ __forceinline__ void sweep_update_unit(u64* T, const int64_t mat, con
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
                 const int idx = tid + TH * it, p = idx / CW, wd = idx & (CW - 1);
-                sv[j][it] = (p < tg[j] && wd < wc_n) ? snap_base[(int64_t)j * sstride + (mat * 64 + p) * ld + cw0 + wd] : 0ull;
+                sv[j][it] = !(p < tg[j] && wd < wc_n) ? 0ull
+                            : snap_base ? snap_base[(int64_t)j * sstride + (mat * 64 + p) * ld + cw0 + wd]
+                                        : a[(int64_t)prow_base[(mat * K + j) * 64 + p] * ld + cw0 + wd];
             }
 #pragma unroll
         for (int j = 0; j < K; ++j)
@@ -1640,7 +1656,8 @@ __global__ __launch_bounds__(TH) void rref_sweep_update_kernel(u64* base, int64_
                                                                const u64* __restrict__ d_base,
                                                                int64_t dstride, const u64* __restrict__ snap_base,
                                                                int64_t sstride, int64_t pw0,
-                                                               u64* __restrict__ colw_base, u64* out_base, int chunk_base, int chunk_skip) {
+                                                               u64* __restrict__ colw_base, u64* out_base, int chunk_base, int chunk_skip,
+                                                               const int32_t* __restrict__ prow_base = nullptr) {
     // the launch covers chunks chunk_base .. chunk_base + gridDim.y - 1 but chunk_skip (look-ahead of the streamed path: the chunk
     // of the next sweep's columns goes first, in a launch of its own)
     extern __shared__ __attribute__((aligned(16))) u64 T[];           // (the lookups address the tables from LDS byte 0: the kernel's only LDS)
@@ -1649,7 +1666,7 @@ __global__ __launch_bounds__(TH) void rref_sweep_update_kernel(u64* base, int64_
     const unsigned int unit = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const int64_t r_lo = (int64_t)blockIdx.x * rows_per_wg;
     sweep_update_unit<K, TH>(T, blockIdx.z, chunk, r_lo, r_lo + rows_per_wg < m ? r_lo + rows_per_wg : m, unit, base, m, ld, states, live, d_base,
-                             dstride, snap_base, sstride, pw0, colw_base, out_base);
+                             dstride, snap_base, sstride, pw0, colw_base, out_base, prow_base);
 }
 
 // The streamed path's big launch as a ONE-dimensional grid: workgroups 0 .. blocks * n_live * batch - 1 are the live ones (chunks from
@@ -2720,6 +2737,11 @@ static int launch_rref_sweeps(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m
     if (rows_wg > 128) rows_wg = gf2_cdiv(m, gf2_cdiv(m, rows_wg));
     if (rows_wg < 128) rows_wg = 128;
     if (ctx->opt[GF2_OPT_RREF_ROWS_WG] >= 64) rows_wg = ctx->opt[GF2_OPT_RREF_ROWS_WG];
+    // A pass workgroup that owns ALL rows of its chunk (large batches) reads the sweep's pivot rows where they lie, for its tables,
+    // before it writes a row: the panel kernel then leaves their numbers instead of copies of them (256 matrices of 2048 x 4096:
+    // 128 KiB read and written per matrix and sweep less; GF2_OPT_RREF_STREAM_VARIANT = 1 keeps the snapshots).
+    const bool direct = rows_wg >= m && ctx->opt[GF2_OPT_RREF_STREAM_VARIANT] != 1;
+    int32_t* const prow = (int32_t*)snap;                              // (the snapshots' place: [batch][K][64] numbers)
     // Every row may have its pivot once m columns have been seen, and a random matrix is done right there or a few columns later:
     // from then on the ranks are read back after every sweep for two sweeps, then after every other one (a stream synchronisation,
     // but it saves the launches of the sweeps that would find nothing left to do -- half of them for a 2048 x 4096 matrix).
@@ -2741,7 +2763,7 @@ static int launch_rref_sweeps(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m
         u64* work = s == 0 ? a_dev : tmp;                              // the first pass takes the batch to the workspace copy
 #define GF2_SP_LAUNCH(RPT)                                                                                                      \
     hipLaunchKernelGGL((rref_sweep_panel_kernel<K, RPT>), dim3((unsigned)batch), dim3(RB_THREADS), 0, on, (const u64*)work, m, n, ld, pw0, \
-                       pivots_dev, cap, pivrow, states, used, (const u64*)colw, dco, dstride, snap, sstride)
+                       pivots_dev, cap, pivrow, states, used, (const u64*)colw, dco, dstride, direct ? (u64*)nullptr : snap, sstride, prow)
         if (rpt <= 1)
             GF2_SP_LAUNCH(1);
         else if (rpt <= 2)
@@ -2751,7 +2773,8 @@ static int launch_rref_sweeps(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t m
 #undef GF2_SP_LAUNCH
         const dim3 grid((unsigned)gf2_cdiv(m, rows_wg), (unsigned)chunks, (unsigned)batch);
         hipLaunchKernelGGL((rref_sweep_update_kernel<K, TH>), grid, dim3(TH), 128 * 1024, on, work, m, ld, rows_wg, (const SweepState*)states,
-                           states, (const u64*)dco, dstride, (const u64*)snap, sstride, pw0, colw, tmp, 0, -1);
+                           states, (const u64*)dco, dstride, direct ? (const u64*)nullptr : (const u64*)snap, sstride, pw0, colw, tmp, 0, -1,
+                           (const int32_t*)prow);
         GF2_HIP(hipGetLastError());
         bool done;
         GF2_TRY(all_done(pw0 + K - 1, &done));

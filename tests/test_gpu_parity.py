@@ -1903,6 +1903,45 @@ def test_rref_sweep_routes(shape, k, ctx):
         ctx.set_option(_native.OPT_RREF_ROWS_WG, None)
 
 
+@pytest.mark.parametrize("k", [4, 2])
+@pytest.mark.parametrize("shape", [(300, 600, 400), (1030, 1100, 300), (257, 4200, 260), (2048, 2100, 130)])
+def test_rref_large_batches_read_pivot_rows_in_place(shape, k, ctx):
+    # Round 5: when the batch is large enough for a trailing-pass workgroup to own ALL rows of its chunk, the panel kernel leaves the
+    # pivot rows' numbers instead of snapshots and the pass builds its tables from the rows where they lie (before it writes any).
+    # Mixed batches as in test_rref_sweep_routes, K = 4 and 2, with the snapshots kept beside it (internal option): the oracle's
+    # matrices, pivots and ranks (bin_matrix.py:8-34).
+    m, n, batch = shape
+    rng = np.random.default_rng(m * 7 + n + batch)
+    distinct = []
+    for b in range(24):
+        a = (rng.random((m, n)) < (0.5 if b % 3 != 1 else 0.03)).astype(np.uint8)
+        if b % 4 == 2:
+            a[:, :min(n, 200)] = 0
+        if b % 5 == 3:
+            a[m // 2:] = a[: m - m // 2]
+        if b % 7 == 6:
+            a[:, ::2] = 0
+        distinct.append(a)
+    want = [c_oracle.rref(c_oracle.pack_rows(a), m, n) for a in distinct]
+    packed_one = [_native.pack_rows(a) for a in distinct]
+    flags = ctx.get_flags()
+    try:
+        ctx.set_flags(flags | _native.F_RREF_NO_SMALL)
+        ctx.set_option(_native.OPT_RREF_SWEEP_K, k)
+        for keep_snapshots in (None, 1):
+            ctx.set_option(_native.OPT_RREF_STREAM_VARIANT, keep_snapshots)
+            packed = np.stack([packed_one[b % 24] for b in range(batch)])
+            pivots, ranks = ctx.rref_batch(packed, batch, m, n)
+            for b in range(batch):
+                w = want[b % 24]
+                assert ranks[b] == w[2] and np.array_equal(packed[b], w[0]), (k, keep_snapshots, b)
+                assert list(pivots[b, :w[2]]) == list(w[1]), (k, keep_snapshots, b)
+    finally:
+        ctx.set_flags(flags)
+        ctx.set_option(_native.OPT_RREF_SWEEP_K, None)
+        ctx.set_option(_native.OPT_RREF_STREAM_VARIANT, None)
+
+
 @pytest.mark.parametrize("shape", [(4100, 700, 2), (5000, 5100, 3), (8200, 8300, 2), (9000, 2000, 1), (4500, 4600, 7), (4097, 65, 2)])
 def test_rref_streamed_sweeps_on_tall_matrices(shape, ctx, route):
     # Round 5: more than 4096 rows take four panels per sweep with the rows STREAMED (sweep_column / sweep_stream_panel / sweep_finish /
