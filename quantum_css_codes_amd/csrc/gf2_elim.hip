@@ -228,13 +228,16 @@ __device__ __forceinline__ u64 transpose64(u64 x, int lane) {
 // ends with the word and the coefficients any row gets for having bit j, and elimination is linear in the row, so every row
 // outside the window is finished with two table lookups instead of replaying the pivots.
 //
-// Lane l holds window rows l and l + 64 and probe row e_l (word and coefficients in registers).  A pivot step: three ballots
-// give column b over the 192 rows; the first window row that has the bit and is no pivot yet becomes the pivot; its word and
-// coefficients come by readlane; the rows of the column (but the pivot row itself) XOR them in, the ballots serving as the lane
-// masks of the selects as they stand.  ~150 ns per pivot.  (Rounds 1 and 2 went through a row-sliced round with ballots over the
-// rows and five readlanes per pivot, and a column-sliced one -- lane = panel column, twelve v_writelane per pivot -- at 325 and
-// 280 ns; eliminating strips of 2, 4 or 8 columns as bit vectors in scalar registers first and applying their pivots afterwards
-// is no faster: 0.99, 1.03, 1.13 ms for the 2048 x 4096 matrix against 0.98.)
+// Lane l holds window rows l and l + 64 and probe row e_l (word and coefficients in registers, as 32-bit halves).  A pivot step
+// (round 5): the rows that have column b are per-lane masks (v_bfe_i32 of the half that holds the column); one ballot finds the
+// first window row of the first 64 that has the bit and is no pivot yet (the other 64 only when there is none); its word and
+// coefficients come by readlane; every row of the column but the pivot row itself takes them, x ^= P & mask, one v_bitop3 per
+// dword.  ~125 ns per pivot, a dependent chain: 24 vector instructions, one branch per pivot and one TAKEN branch per four (a taken
+// branch costs a lone wavefront ~15 ns).  (Before: three ballots as the lane masks of `if (bit) x ^= P`, which the compiler turned
+// into selects -- 44 vector instructions, 170 ns.  Rounds 1 and 2 went through a row-sliced round with ballots over the rows and
+// five readlanes per pivot, and a column-sliced one -- lane = panel column, twelve v_writelane per pivot -- at 325 and 280 ns;
+// eliminating strips of 2, 4 or 8 columns as bit vectors in scalar registers first and applying their pivots afterwards was no
+// faster: 0.99, 1.03, 1.13 ms for the 2048 x 4096 matrix against 0.98.)
 __device__ __forceinline__ void window_round(int lane, int nwin, int t, int64_t rank, int64_t m, u64 unresolved, const u64* win_w,
                                              const u64* win_d, const int* win_row, int* win_piv, u64* fin_w, u64* fin_d,
                                              int* pbit, int* prow_l, u64* DP, u64* WP, int* misc, int* win_q = nullptr) {

@@ -35,7 +35,7 @@
 #define GF2_OPT_RREF_SMALL_BCAST 8  /* wavefront-per-matrix RREF: how the pivot rows reach the other rows.  One at a time: 0 = through LDS, 1 = through v_readlane; 2 = four at a time through a table of their sums in LDS (contiguous rows of whole 16-byte pieces, at most 32 words per lane; otherwise as the default).  Default: 2 for rows of 16 words, half LDS half readlane for at most 64 rows of at most 8 words, else 0 */
 #define GF2_OPT_MC_SAMPLER_WAVES 9  /* gf2_mc_run at n <= 4096, sparse rates: record-sampler wavefronts per CU, 1..9 (default 8)          */
 #define GF2_OPT_MC_TAIL_CAP     10  /* gf2_mc_run at n <= 4096, sparse rates: erroneous qubits of a 512-qubit segment that the record sampler's lanes take in step; a sample with more in a segment is finished by a lane of its own later.  0 (all in step), 2, 4, 6 or 8 (default: by the rate) */
-#define GF2_OPT_RREF_STREAM_VARIANT 11 /* blocked RREF above 4096 rows: development switches of the streamed sweeps (gf2_elim.hip, launch_rref_sweeps_streamed) */
+#define GF2_OPT_RREF_STREAM_VARIANT 11 /* blocked RREF: development switches -- above 4096 rows those of launch_rref_sweeps_streamed (gf2_elim.hip); up to 4096 rows 1 = keep the pivot-row snapshots for large batches */
 #define GF2_OPT_RREF_ROWS_WG    12  /* blocked RREF: rows per workgroup of the trailing pass (>= 64; default: by the batch)            */
-#define GF2_OPT_RREF_SWEEP_K    13  /* blocked RREF up to 4096 rows: panels per sweep, 4 or 2 (default: by the shape); 0 = the round-4 pair kernels */
+#define GF2_OPT_RREF_SWEEP_K    13  /* blocked RREF: panels per sweep, 4 or 2 up to 4096 rows (default: by the shape), 4 with the rows streamed above; 0 = the round-4 pair kernels */
 #define GF2_OPT_COUNT           14
