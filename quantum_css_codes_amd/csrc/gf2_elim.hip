@@ -3062,8 +3062,8 @@ static int launch_rref_blocked(gf2_ctx* ctx, u64* a_dev, int64_t batch, int64_t 
     const int rpt = (int)gf2_cdiv(m, RB_THREADS);
     // up to 4096 rows: K panels per sweep with the rows' column words and coefficients in registers (round 5; eight rows per lane do
     // not fit: 15 ms against 7.8 for four 8192 x 16384 matrices, hence the streamed form above)
-    // more than 4096 rows: four panels per sweep with the rows streamed (32768 x 65536: 26.4 ms and half the traffic against the
-    // pair kernels' 39.3; 8192 x 16384 x 4: 5.3 against 7.5); GF2_OPT_RREF_SWEEP_K = 0 keeps the pair kernels below
+    // more than 4096 rows: four panels per sweep with the rows streamed (32768 x 65536: 23.4 - 24.3 ms and half the traffic against the
+    // pair kernels' 39.3; 8192 x 16384 x 4: 3.8 against 7.5); GF2_OPT_RREF_SWEEP_K = 0 keeps the pair kernels below
     if (rpt > 4 && ctx->opt[GF2_OPT_RREF_SWEEP_K] != 0)
         return launch_rref_sweeps_streamed(ctx, a_dev, batch, m, n, ld, pivots_dev, cap, rank_dev);
     if (rpt <= 4 && ctx->opt[GF2_OPT_RREF_SWEEP_K] != 0) {
